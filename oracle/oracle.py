@@ -1,0 +1,215 @@
+"""ctypes door onto oracle/liboracle.so (the CPU restatement) and oracle/_ref/libntcoding_ref.so.
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+Nothing under segalign_amd/ imports this module (tests/test_no_oracle_in_product.py enforces it).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+_REF = os.path.join(_HERE, "_ref", "libntcoding_ref.so")
+
+SEG_DTYPE = np.dtype([("ref_start", "<u4"), ("query_start", "<u4"), ("len", "<u4"), ("score", "<i4")])
+
+
+def build(with_ref=True):
+    """Compile the checker: liboracle.so always; _ref only where /root/reference exists."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    if with_ref and os.path.isdir("/root/reference/common"):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "_ref"])
+
+
+class _ExtendParams(C.Structure):
+    _fields_ = [("ref", C.c_void_p), ("query", C.c_void_p), ("ref_len", C.c_uint32), ("query_len", C.c_uint32),
+                ("sub_mat", C.c_void_p), ("xdrop", C.c_int), ("hspthresh", C.c_int), ("noentropy", C.c_int),
+                ("log4_is_float", C.c_int)]
+
+
+class _SafStats(C.Structure):
+    _fields_ = [("num_hits", C.c_uint64), ("num_survivors", C.c_uint64), ("num_examined", C.c_uint64),
+                ("num_iter", C.c_uint32)]
+
+
+class _SafParams(C.Structure):
+    _fields_ = [("ext", _ExtendParams), ("index_table", C.c_void_p), ("pos_table", C.c_void_p),
+                ("seed_size", C.c_uint32), ("max_hits", C.c_int64), ("num_threads", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build(with_ref=False)
+        L = C.CDLL(_LIB)
+        L.orc_kmer_index_at_pos.restype = C.c_uint32
+        L.orc_kmer_index_at_pos.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32]
+        L.orc_generate_shape_pos.argtypes = [C.c_char_p]
+        L.orc_generate_seed_pos_table.restype = C.c_uint32
+        L.orc_generate_seed_pos_table.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
+                                                  C.c_void_p, C.c_void_p]
+        L.orc_make_seeds.restype = C.c_size_t
+        L.orc_make_seeds.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
+                                     C.c_void_p]
+        L.orc_extend_hit.argtypes = [C.POINTER(_ExtendParams), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_extend_hit_tiled.argtypes = [C.POINTER(_ExtendParams), C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+        L.orc_seed_and_filter.restype = C.c_size_t
+        L.orc_seed_and_filter.argtypes = [C.POINTER(_SafParams), C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p),
+                                          C.POINTER(_SafStats)]
+        L.orc_seed_and_filter_rm.restype = C.c_size_t
+        L.orc_seed_and_filter_rm.argtypes = [C.POINTER(_SafParams), C.c_void_p, C.c_size_t, C.c_int, C.c_uint32,
+                                             C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(_SafStats)]
+        L.orc_free.argtypes = [C.c_void_p]
+        L.orc_max_hits_for_mem.argtypes = [C.c_uint64]
+        L.orc_encode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
+        L.orc_encode_rev_comp.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.orc_rev_comp_codes.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.orc_rev_comp_ascii.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_size_t, C.c_size_t]
+        L.orc_build_sub_mat.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        _lib = L
+    return _lib
+
+
+def ref_lib():
+    """The real reference ntcoding object, or None when it was never built (e.g. no /root/reference)."""
+    if not os.path.exists(_REF):
+        return None
+    R = C.CDLL(_REF)
+    R.ref_GetKmerIndexAtPos.restype = C.c_uint32
+    R.ref_GetKmerIndexAtPos.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32]
+    R.ref_GenerateShapePos.argtypes = [C.c_char_p]
+    R.ref_RevComp.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_size_t, C.c_size_t]
+    return R
+
+
+# ---------------------------------------------------------------------------------------------------------
+def build_sub_mat(xdrop=910, ambiguous="x", reward=0, penalty=0):
+    m = np.zeros(64, dtype=np.int32)
+    mode = {"x": 0, "n": 1, "iupac": 2}[ambiguous]
+    lib().orc_build_sub_mat(m.ctypes.data, xdrop, mode, reward, penalty)
+    return m
+
+
+def encode(ascii_bytes):
+    out = np.empty(len(ascii_bytes), dtype=np.uint8)
+    lib().orc_encode(bytes(ascii_bytes), len(ascii_bytes), out.ctypes.data)
+    return out
+
+
+def encode_rev_comp(ascii_bytes):
+    n = len(ascii_bytes)
+    f = np.empty(n, dtype=np.uint8)
+    r = np.empty(n, dtype=np.uint8)
+    lib().orc_encode_rev_comp(bytes(ascii_bytes), n, f.ctypes.data, r.ctypes.data)
+    return f, r
+
+
+def rev_comp_codes(codes):
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    out = np.empty_like(codes)
+    lib().orc_rev_comp_codes(codes.ctypes.data, codes.size, out.ctypes.data)
+    return out
+
+
+def rev_comp_ascii(src, start, length):
+    dst = C.create_string_buffer(length)
+    lib().orc_rev_comp_ascii(dst, bytes(src), 0, start, length)
+    return dst.raw
+
+
+def generate_shape_pos(shape):
+    return lib().orc_generate_shape_pos(shape.encode())
+
+
+def is_transition_at_pos(t):
+    return lib().orc_is_transition_at_pos(t)
+
+
+def kmer_index_at_pos(seq, pos, seed_size):
+    return lib().orc_kmer_index_at_pos(bytes(seq), pos, seed_size)
+
+
+def generate_seed_pos_table(ref, start_addr, ref_length, step, shape_size, kmer_size):
+    nkeys = 1 << (2 * kmer_size)
+    index = np.empty(nkeys, dtype=np.uint32)
+    pos = np.empty(max(int(ref_length), 1), dtype=np.uint32)
+    n = lib().orc_generate_seed_pos_table(bytes(ref), start_addr, ref_length, step, shape_size, kmer_size,
+                                          index.ctypes.data, pos.ctypes.data)
+    return index, pos[:n].copy()
+
+
+def make_seeds(qbuf, q_block_start, i, e, seed_size, kmer_size, transition):
+    out = np.empty(max((e - i) * (kmer_size + 1 if transition else 1), 1), dtype=np.uint64)
+    n = lib().orc_make_seeds(bytes(qbuf), q_block_start, i, e, seed_size, kmer_size, int(transition), out.ctypes.data)
+    return out[:n].copy()
+
+
+def _ext_params(ref_codes, query_codes, sub_mat, xdrop, hspthresh, noentropy, log4_is_float=True):
+    p = _ExtendParams()
+    p.ref = ref_codes.ctypes.data
+    p.query = query_codes.ctypes.data
+    p.ref_len = ref_codes.size
+    p.query_len = query_codes.size
+    p.sub_mat = sub_mat.ctypes.data
+    p.xdrop, p.hspthresh, p.noentropy, p.log4_is_float = xdrop, hspthresh, int(noentropy), int(log4_is_float)
+    return p
+
+
+def extend_hit(ref_codes, query_codes, sub_mat, ref_loc, query_loc, xdrop=910, hspthresh=3000, noentropy=False,
+               tiled=0, log4_is_float=True):
+    """Returns (passed, (ref_start, query_start, len, score), examined)."""
+    ref_codes = np.ascontiguousarray(ref_codes, np.uint8)
+    query_codes = np.ascontiguousarray(query_codes, np.uint8)
+    sub_mat = np.ascontiguousarray(sub_mat, np.int32)
+    p = _ext_params(ref_codes, query_codes, sub_mat, xdrop, hspthresh, noentropy, log4_is_float)
+    out = np.zeros(1, dtype=SEG_DTYPE)
+    ex = C.c_uint64(0)
+    if tiled:
+        ok = lib().orc_extend_hit_tiled(C.byref(p), ref_loc, query_loc, tiled, out.ctypes.data)
+    else:
+        ok = lib().orc_extend_hit(C.byref(p), ref_loc, query_loc, out.ctypes.data, C.addressof(ex))
+    return bool(ok), tuple(int(x) for x in out[0]), ex.value
+
+
+def seed_and_filter(ref_codes, query_codes, index_table, pos_table, seeds, sub_mat, seed_size=19, xdrop=910,
+                    hspthresh=3000, noentropy=False, max_hits=1 << 30, num_threads=0, log4_is_float=True,
+                    rm=None):
+    """Full SeedAndFilter restatement.  rm=None -> src/ variant; rm=(rev, ref_start, ref_end) -> repeat masker.
+    Returns (segments structured array incl. header element 0, stats dict)."""
+    ref_codes = np.ascontiguousarray(ref_codes, np.uint8)
+    query_codes = np.ascontiguousarray(query_codes, np.uint8)
+    index_table = np.ascontiguousarray(index_table, np.uint32)
+    pos_table = np.ascontiguousarray(pos_table, np.uint32)
+    seeds = np.ascontiguousarray(seeds, np.uint64)
+    sub_mat = np.ascontiguousarray(sub_mat, np.int32)
+    p = _SafParams()
+    p.ext = _ext_params(ref_codes, query_codes, sub_mat, xdrop, hspthresh, noentropy, log4_is_float)
+    p.index_table = index_table.ctypes.data
+    p.pos_table = pos_table.ctypes.data if pos_table.size else None
+    p.seed_size = seed_size
+    p.max_hits = max_hits
+    p.num_threads = num_threads if num_threads > 0 else (os.cpu_count() or 1)
+    out = C.c_void_p()
+    st = _SafStats()
+    if rm is None:
+        n = lib().orc_seed_and_filter(C.byref(p), seeds.ctypes.data, seeds.size, C.byref(out), C.byref(st))
+    else:
+        rev, rs, re_ = rm
+        n = lib().orc_seed_and_filter_rm(C.byref(p), seeds.ctypes.data, seeds.size, int(rev), rs, re_, C.byref(out),
+                                         C.byref(st))
+    buf = (C.c_char * (n * SEG_DTYPE.itemsize)).from_address(out.value)
+    segs = np.frombuffer(buf, dtype=SEG_DTYPE).copy()
+    lib().orc_free(out)
+    stats = dict(num_hits=st.num_hits, num_survivors=st.num_survivors, num_examined=st.num_examined,
+                 num_iter=st.num_iter)
+    return segs, stats
+
+
+def max_hits_for_mem(total_global_mem):
+    return lib().orc_max_hits_for_mem(total_global_mem)

@@ -1,0 +1,160 @@
+/*
+ * segalign_amd.h -- C-ABI of libsegalign_hip.so, the MI355X (gfx950) seed -> filter -> extend engine.
+ *
+ * This is the drop-in boundary for SegAlign's engine.  The reference boundary is C++-ABI (function pointers
+ * that pass std::vector by value); every entry point below is the plain-C form of one reference
+ * symbol -- plain pointers and sizes, no C++/torch types -- and include/segalign_amd_compat.hpp rebuilds the
+ * exact reference symbols (g_InitializeInterface ... g_SeedAndFilter, GenerateSeedPosTable) on top of it so the
+ * reference host (src/main.cpp, src/seeder.cpp) links unchanged.  See INTEGRATION.md.
+ *
+ * Error behaviour mirrors common/cuda_utils.h:4-37 and seed_filter_interface.cu:53-70: a message on stderr and
+ * exit(code): 1 no device, 10 too many GPUs requested, 11 set-device, 12 malloc, 13 memcpy, 14 free,
+ * 15 kernel launch/synchronise (the reference never checks launches; this engine does).
+ *
+ * Threading mirrors the reference: sa_seed_and_filter* may be called from many host threads concurrently; the
+ * engine hands each call a (device, slot) token from a pool (reference: seed_filter_interface.cu:7-9 +
+ * src/seed_filter.cu:699-706,798-803).  All other entry points are called from one thread at a time
+ * (the reader lambda of src/main.cpp:601-737).
+ */
+#ifndef SEGALIGN_AMD_H
+#define SEGALIGN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SA_BUFFER_DEPTH 2 /* src/graph.h:14 */
+
+/* src/graph.h:25-30 -- hit / HSP record; len = bases - 1 */
+typedef struct sa_segment_pair {
+    uint32_t ref_start;
+    uint32_t query_start;
+    uint32_t len;
+    int32_t score;
+} sa_segment_pair;
+
+/* ---- engine lifecycle ------------------------------------------------------------------------------------ */
+
+/* g_InitializeInterface, common/seed_filter_interface.h:3,8 ; def common/seed_filter_interface.cu:49-80.
+ * num_gpu = -1 -> all visible devices.  Returns the number of devices the engine will use. */
+int sa_initialize_interface(int num_gpu);
+
+/* One-process-per-GPU deployments: restrict the NEXT sa_initialize_interface to these HIP device ordinals
+ * (engine device g = ids[g]).  n = 0 restores the reference behaviour (devices 0..num_gpu-1). */
+void sa_select_devices(const int* ids, int n);
+
+/* g_InitializeProcessor, src/seed_filter.h:4,10 ; def src/seed_filter.cu:830-897.
+ * sub_mat: 64 ints, sub_mat[r*8+q] over codes A0 C1 G2 T3 L4 N5 X6 E7 (common/parameters.h:4-13). */
+void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_size, const int* sub_mat, int xdrop,
+                             int hspthresh, int noentropy);
+
+/* g_ShutdownProcessor, src/seed_filter.h:8,14 ; def src/seed_filter.cu:932-940. */
+void sa_shutdown_processor(void);
+
+/* ---- target block ---------------------------------------------------------------------------------------- */
+
+/* g_SendRefWriteRequest, common/seed_filter_interface.h:4 ; def seed_filter_interface.cu:82-101.
+ * ASCII at seq+addr (borrowed for the call) is uploaded to every device and encoded there. */
+void sa_send_ref_write_request(const char* seq, size_t addr, uint32_t len);
+
+/* g_ClearRef, common/seed_filter_interface.h:5 ; def seed_filter_interface.cu:103-113 (target + both tables). */
+void sa_clear_ref(void);
+
+/* GenerateShapePos, common/ntcoding.h:5 ; def common/ntcoding.cpp:21-37.  Shape string of '1'/'T' (care,
+ * 'T' = transition allowed) and anything else (don't care).  Returns the seed weight (kmer_size).
+ * State used by sa_generate_seed_pos_table and sa_seed_and_filter_range. */
+int sa_generate_shape_pos(const char* shape);
+
+/* GenerateSeedPosTable, common/ntcoding.h:9 ; def common/seed_pos_table.cu:49-109.
+ * Built ON THE DEVICE from the encoded target; when (ref_str+start_addr, ref_length) is the block last sent by
+ * sa_send_ref_write_request (the only way src/main.cpp:615-621 calls it) nothing is uploaded again. */
+void sa_generate_seed_pos_table(const char* ref_str, size_t start_addr, uint32_t ref_length, uint32_t step,
+                                int shape_size, int kmer_size);
+
+/* ---- query block ----------------------------------------------------------------------------------------- */
+
+/* g_SendQueryWriteRequest, src/seed_filter.h:5 ; def src/seed_filter.cu:899-919.  The reference reads the host
+ * global query_DRAM->buffer (src/store.h:7, seed_filter.cu:910); the C form takes that base pointer explicitly. */
+void sa_send_query_write_request(const char* query_buffer, size_t addr, uint32_t len, uint32_t buffer);
+
+/* g_ClearQuery, src/seed_filter.h:7 ; def src/seed_filter.cu:921-930. */
+void sa_clear_query(uint32_t buffer);
+
+/* ---- the hot call ---------------------------------------------------------------------------------------- */
+
+/* g_SeedAndFilter, src/seed_filter.h:6 ; def src/seed_filter.cu:682-828.
+ * seeds[i] = (key << 32) + query_position (src/seeder.cpp:60-61).  Returns the element count of *out
+ * (>= 1): out[0] is the header {len = total anchors, score = (int)num_hits} (seed_filter.cu:806-809), followed by
+ * the HSPs of each iteration in order.  *out is owned by the caller; release with sa_free_segments. */
+size_t sa_seed_and_filter(const uint64_t* seeds, size_t num_seeds, int rev, uint32_t buffer, sa_segment_pair** out);
+
+/* ADDITIVE: same as sa_seed_and_filter, but the seed words of query positions [start, end) of
+ * the resident block `buffer` (strand `rev`) are generated on the device exactly as src/seeder.cpp:57-74 /
+ * :94-109 would on the host (same order), so no seed vector crosses PCIe.  If that chunk has no valid seed the
+ * reference does not call the engine at all (seeder.cpp:76); this returns 0 and *out = NULL in that case. */
+size_t sa_seed_and_filter_range(uint32_t start, uint32_t end, int rev, uint32_t buffer, sa_segment_pair** out);
+
+void sa_free_segments(sa_segment_pair* p);
+
+/* ---- repeat-masker variant (repeat_masker_src/seed_filter.h:4-8) ----------------------------------------- */
+
+/* SendQueryWriteRequest() of the repeat masker: the query IS the target; builds its reverse complement on the
+ * device from the encoded target (repeat_masker_src/seed_filter.cu:951-961). */
+void sa_rm_send_query_write_request(void);
+void sa_rm_clear_query(void); /* repeat_masker_src/seed_filter.cu:964-972 */
+/* SeedAndFilter(seeds, rev, ref_start, ref_end), repeat_masker_src/seed_filter.cu:724-876; header packs the 64-bit
+ * hit / anchor counts as {ref_start,query_start} / {len,score} (:857-861). */
+size_t sa_rm_seed_and_filter(const uint64_t* seeds, size_t num_seeds, int rev, uint32_t ref_start, uint32_t ref_end,
+                             sa_segment_pair** out);
+
+/* ---- knobs the reference derives from its GPU (hazard H4) ------------------------------------------------- */
+
+/* MAX_HITS (src/seed_filter.cu:832-841) decides how SeedAndFilter splits a call into iterations, and dedup scope
+ * is per iteration.  Default: the reference formula applied to THIS device's memory.  Override to reproduce the
+ * output of the reference on a given CUDA GPU (e.g. sa_max_hits_for_mem(16945512448) for a 16 GB V100). */
+void sa_set_max_hits(int64_t max_hits);
+int64_t sa_get_max_hits(void);
+int sa_max_hits_for_mem(uint64_t total_global_mem);
+
+/* ---- introspection (tests, bench, profiling; not part of the reference surface) --------------------------- */
+
+typedef struct sa_call_stats {
+    uint64_t num_seeds;
+    uint64_t num_hits;      /* H */
+    uint64_t num_survivors; /* A before dedup */
+    uint64_t num_anchors;   /* returned HSPs */
+    uint64_t num_examined;  /* E: scored positions; only filled while sa_set_count_examined(1) */
+    uint32_t num_iter;
+    int device;
+} sa_call_stats;
+void sa_get_last_call_stats(sa_call_stats* out); /* stats of the calling thread's most recent hot call */
+void sa_set_count_examined(int on);
+
+/* Per-kernel HIP-event timing on the engine's own streams (bench.py's roofline leg). */
+void sa_profile_enable(int on);
+void sa_profile_reset(void);
+int sa_profile_num_entries(void);
+/* returns 0 on success; name is NUL-terminated into name_buf */
+int sa_profile_get(int i, char* name_buf, size_t name_cap, double* total_ms, uint64_t* launches);
+
+/* Device -> host copies of engine state on device `dev` (parity tests). */
+uint32_t sa_get_ref_len(void);
+uint32_t sa_get_num_index(void);       /* entries in the position table */
+uint32_t sa_get_index_table_size(void); /* 4^kmer_size */
+void sa_copy_ref_codes(int dev, uint8_t* dst);
+void sa_copy_index_table(int dev, uint32_t* dst); /* INCLUSIVE bucket ends == reference d_index_table */
+void sa_copy_pos_table(int dev, uint32_t* dst);
+void sa_copy_query_codes(int dev, uint32_t buffer, int rev, uint8_t* dst);
+uint32_t sa_get_query_len(uint32_t buffer);
+/* seed words the device seeder produces for [start,end) (8f-1), for comparison with src/seeder.cpp's vector */
+size_t sa_device_make_seeds(uint32_t start, uint32_t end, int rev, uint32_t buffer, uint64_t* dst, size_t cap);
+
+const char* sa_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEGALIGN_AMD_H */

@@ -1,0 +1,156 @@
+// dedup.hip -- ordering and de-duplication of the surviving HSPs.
+// Replaces thrust::stable_sort(hspComp) -> thrust::unique_copy(hspEqual) -> thrust::stable_sort(hspCompLastz)
+// (src/seed_filter.cu:776-782) and the five-step chain of the repeat masker (repeat_masker_src/seed_filter.cu:819-831).
+// The reference runs the chain once per iteration; here every record carries its iteration (`seg`) as the most
+// significant sort key and as an extra inequality in the unique predicate, so one pass over all iterations of a
+// call yields exactly the concatenation the reference builds at :811-822.
+// Sorting uses rocPRIM's merge sort (AMD's native device primitive -- what thrust::stable_sort lowers to on ROCm);
+// survivors are orders of magnitude fewer than hits, so this stage is launch-latency, not bandwidth, bound.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "kernels.h"
+
+namespace sa {
+
+// ---- comparators (all compare seg first) --------------------------------------------------------------------------
+struct LessDiag {  // hspComp, seed_filter.cu:54-80: (diag as wrapped u32 [H8], ref_start, len, score desc)
+    __host__ __device__ bool operator()(const HspRec& x, const HspRec& y) const {
+        if (x.seg != y.seg) return x.seg < y.seg;
+        const uint32_t dx = x.ref_start - x.query_start, dy = y.ref_start - y.query_start;
+        if (dx != dy) return dx < dy;
+        if (x.ref_start != y.ref_start) return x.ref_start < y.ref_start;
+        if (x.len != y.len) return x.len < y.len;
+        return x.score > y.score;
+    }
+};
+struct LessLastz {  // hspCompLastz, seed_filter.cu:82-108: (query_start, ref_start, len, score desc)
+    __host__ __device__ bool operator()(const HspRec& x, const HspRec& y) const {
+        if (x.seg != y.seg) return x.seg < y.seg;
+        if (x.query_start != y.query_start) return x.query_start < y.query_start;
+        if (x.ref_start != y.ref_start) return x.ref_start < y.ref_start;
+        if (x.len != y.len) return x.len < y.len;
+        return x.score > y.score;
+    }
+};
+struct LessRmFirst {  // repeat masker hspComp, rm :109-135: (query_start, len desc, ref_start, score desc)
+    __host__ __device__ bool operator()(const HspRec& x, const HspRec& y) const {
+        if (x.seg != y.seg) return x.seg < y.seg;
+        if (x.query_start != y.query_start) return x.query_start < y.query_start;
+        if (x.len != y.len) return x.len > y.len;
+        if (x.ref_start != y.ref_start) return x.ref_start < y.ref_start;
+        return x.score > y.score;
+    }
+};
+struct LessRmDiag {  // hspDiagComp, rm :52-78: (diag, ref_start, query_start, score desc)
+    __host__ __device__ bool operator()(const HspRec& x, const HspRec& y) const {
+        if (x.seg != y.seg) return x.seg < y.seg;
+        const uint32_t dx = x.ref_start - x.query_start, dy = y.ref_start - y.query_start;
+        if (dx != dy) return dx < dy;
+        if (x.ref_start != y.ref_start) return x.ref_start < y.ref_start;
+        if (x.query_start != y.query_start) return x.query_start < y.query_start;
+        return x.score > y.score;
+    }
+};
+struct LessRmFinal {  // hspFinalComp, rm :87-107: (query_start, score desc, ref_start desc)
+    __host__ __device__ bool operator()(const HspRec& x, const HspRec& y) const {
+        if (x.seg != y.seg) return x.seg < y.seg;
+        if (x.query_start != y.query_start) return x.query_start < y.query_start;
+        if (x.score != y.score) return x.score > y.score;
+        return x.ref_start > y.ref_start;
+    }
+};
+
+// hspEqual, seed_filter.cu:47-52 (== hspDiagEqual, rm :45-50): same diagonal and one interval contains the other
+__device__ __forceinline__ bool hsp_contained(const HspRec& x, const HspRec& y) {
+    return ((uint32_t)(x.ref_start - x.query_start) == (uint32_t)(y.ref_start - y.query_start)) &&
+           (((x.ref_start >= y.ref_start) && ((uint32_t)(x.ref_start + x.len) <= (uint32_t)(y.ref_start + y.len))) ||
+            ((y.ref_start >= x.ref_start) && ((uint32_t)(y.ref_start + y.len) <= (uint32_t)(x.ref_start + x.len))));
+}
+__device__ __forceinline__ bool hsp_same(const HspRec& x, const HspRec& y) {  // rm hspEqual :80-85
+    return x.ref_start == y.ref_start && x.query_start == y.query_start && x.len == y.len && x.score == y.score;
+}
+
+template <class Less>
+static void sort_impl(const HspRec* in, HspRec* out, size_t n, void* temp, size_t temp_bytes, hipStream_t s) {
+    size_t bytes = temp_bytes;
+    (void)rocprim::merge_sort(temp, bytes, in, out, n, Less(), s);
+}
+
+size_t sort_temp_bytes(size_t n) {
+    size_t bytes = 0;
+    (void)rocprim::merge_sort(nullptr, bytes, (const HspRec*)nullptr, (HspRec*)nullptr, n, LessDiag(), (hipStream_t)0);
+    return bytes + 256;
+}
+
+void launch_sort(const HspRec* in, HspRec* out, size_t n, SortOrder order, void* temp, size_t temp_bytes, hipStream_t s) {
+    if (n == 0) return;
+    switch (order) {
+        case ORDER_DIAG: sort_impl<LessDiag>(in, out, n, temp, temp_bytes, s); break;
+        case ORDER_LASTZ: sort_impl<LessLastz>(in, out, n, temp, temp_bytes, s); break;
+        case ORDER_RM_FIRST: sort_impl<LessRmFirst>(in, out, n, temp, temp_bytes, s); break;
+        case ORDER_RM_DIAG: sort_impl<LessRmDiag>(in, out, n, temp, temp_bytes, s); break;
+        case ORDER_RM_FINAL: sort_impl<LessRmFinal>(in, out, n, temp, temp_bytes, s); break;
+    }
+}
+
+// ---- adjacent-pair unique, order preserving (thrust::unique_copy device semantics, hazard H3) --------------------
+// keep[i] = i == 0 || seg differs || !pred(in[i-1], in[i]).  One workgroup walks the (small) array in tiles and
+// carries the running output offset; ballot + popcount gives the in-tile rank.
+constexpr int UNQ_THREADS = 1024;
+
+__global__ __launch_bounds__(UNQ_THREADS) void unique_kernel(const HspRec* __restrict__ in, HspRec* __restrict__ out,
+                                                             uint32_t n, int exact, uint32_t* __restrict__ out_count) {
+    __shared__ uint32_t wave_cnt[UNQ_THREADS / 64];
+    __shared__ uint32_t carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += UNQ_THREADS) {
+        const uint32_t i = base + threadIdx.x;
+        bool keep = false;
+        HspRec cur;
+        if (i < n) {
+            cur = in[i];
+            if (i == 0) keep = true;
+            else {
+                const HspRec prev = in[i - 1];
+                keep = (prev.seg != cur.seg) || !(exact ? hsp_same(prev, cur) : hsp_contained(prev, cur));
+            }
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t off = carry;
+        for (int w = 0; w < wave; w++) off += wave_cnt[w];
+        if (keep) out[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = cur;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t t = 0;
+            for (int w = 0; w < UNQ_THREADS / 64; w++) t += wave_cnt[w];
+            carry += t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out_count = carry;
+}
+
+__global__ __launch_bounds__(256) void strip_kernel(const HspRec* __restrict__ in, uint32_t n, uint4* __restrict__ out) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const HspRec r = in[i];
+        out[i] = make_uint4(r.ref_start, r.query_start, r.len, (uint32_t)r.score);
+    }
+}
+
+void launch_unique(const HspRec* in, HspRec* out, uint32_t n, int exact, uint32_t* out_count, hipStream_t s) {
+    hipLaunchKernelGGL(unique_kernel, dim3(1), dim3(UNQ_THREADS), 0, s, in, out, n, exact, out_count);
+}
+void launch_strip(const HspRec* in, uint32_t n, void* out_segment_pairs, hipStream_t s) {
+    if (n == 0) return;
+    uint32_t g = (n + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(strip_kernel, dim3(g), dim3(256), 0, s, in, n, reinterpret_cast<uint4*>(out_segment_pairs));
+}
+
+}  // namespace sa

@@ -1,0 +1,88 @@
+// encode.hip -- ASCII -> 3-bit nucleotide codes (one byte per base), with optional reverse complement.
+// Replaces compress_string (common/seed_filter_interface.cu:18-47), compress_string_rev_comp
+// (src/seed_filter.cu:110-155) and rev_comp_string (repeat_masker_src/seed_filter.cu:137-167).
+// HBM-bound streaming kernels: 16 B per lane per access on the forward stream, 256-entry LUT in LDS.
+#include "kernels.h"
+
+namespace sa {
+
+__device__ __forceinline__ uint8_t code_of(uint8_t ch) {
+    // common/parameters.h:4-13 ; seed_filter_interface.cu:27-43
+    switch (ch) {
+        case 'A': return 0;
+        case 'C': return 1;
+        case 'G': return 2;
+        case 'T': return 3;
+        case 'a': case 'c': case 'g': case 't': return 4;  // L (soft-masked)
+        case 'n': case 'N': return 5;                      // N
+        case '&': return 7;                                // E (record separator)
+        default: return 6;                                 // X
+    }
+}
+__device__ __forceinline__ uint8_t comp_of(uint8_t c) { return c < 4 ? (uint8_t)(3 - c) : c; }
+
+__device__ __forceinline__ uint32_t map4(uint32_t w, const uint8_t* lut) {
+    return (uint32_t)lut[w & 0xff] | ((uint32_t)lut[(w >> 8) & 0xff] << 8) | ((uint32_t)lut[(w >> 16) & 0xff] << 16) |
+           ((uint32_t)lut[w >> 24] << 24);
+}
+
+// Forward encode.  `ascii` and `codes` are both 16-byte aligned (hipMalloc'ed staging / padded sequence buffer
+// with a 64-byte front pad), so the body runs on uint4 and a scalar tail handles len % 16.
+__global__ __launch_bounds__(256) void encode_kernel(const uint8_t* __restrict__ ascii, uint8_t* __restrict__ codes,
+                                                     uint32_t len) {
+    __shared__ uint8_t lut[256];
+    lut[threadIdx.x] = code_of((uint8_t)threadIdx.x);
+    __syncthreads();
+    const uint32_t nvec = len / 16;
+    const uint4* in4 = reinterpret_cast<const uint4*>(ascii);
+    uint4* out4 = reinterpret_cast<uint4*>(codes);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += gridDim.x * blockDim.x) {
+        uint4 v = in4[i];
+        v.x = map4(v.x, lut); v.y = map4(v.y, lut); v.z = map4(v.z, lut); v.w = map4(v.w, lut);
+        out4[i] = v;
+    }
+    if (blockIdx.x == 0) {
+        for (uint32_t i = nvec * 16 + threadIdx.x; i < len; i += blockDim.x) codes[i] = lut[ascii[i]];
+    }
+}
+
+// Reverse complement of an encoded sequence: out[len-1-i] = comp(in[i]).  Each lane produces one aligned dword of
+// the output from four (reversed) input bytes; reads of a wave cover one contiguous 256-byte span.
+__global__ __launch_bounds__(256) void rev_comp_codes_kernel(const uint8_t* __restrict__ codes,
+                                                             uint8_t* __restrict__ rc, uint32_t len) {
+    const uint32_t nw = (len + 3) / 4;
+    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += gridDim.x * blockDim.x) {
+        uint32_t o = w * 4;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            uint32_t op = o + b;
+            if (op < len) packed |= (uint32_t)comp_of(codes[len - 1 - op]) << (8 * b);
+        }
+        if (o + 4 <= len) *reinterpret_cast<uint32_t*>(rc + o) = packed;
+        else for (int b = 0; o + b < len; b++) rc[o + b] = (uint8_t)(packed >> (8 * b));
+    }
+}
+
+static inline int grid_for(uint64_t work_items, int block, int max_blocks = 256 * 8) {
+    uint64_t g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > (uint64_t)max_blocks) g = max_blocks;
+    return (int)g;
+}
+
+void launch_encode(const uint8_t* ascii, uint8_t* codes, uint32_t len, hipStream_t s) {
+    if (len == 0) return;
+    hipLaunchKernelGGL(encode_kernel, dim3(grid_for(len / 16 + 1, 256)), dim3(256), 0, s, ascii, codes, len);
+}
+void launch_rev_comp_codes(const uint8_t* codes, uint8_t* codes_rc, uint32_t len, hipStream_t s) {
+    if (len == 0) return;
+    hipLaunchKernelGGL(rev_comp_codes_kernel, dim3(grid_for((len + 3) / 4, 256)), dim3(256), 0, s, codes, codes_rc, len);
+}
+void launch_encode_rev_comp(const uint8_t* ascii, uint8_t* codes, uint8_t* codes_rc, uint32_t len, hipStream_t s) {
+    // two streaming passes: the second reads the freshly written codes (L2 / Infinity Cache resident)
+    launch_encode(ascii, codes, len, s);
+    launch_rev_comp_codes(codes, codes_rc, len, s);
+}
+
+}  // namespace sa

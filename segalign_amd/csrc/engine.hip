@@ -1,0 +1,985 @@
+// engine.hip -- host side of libsegalign_hip.so: device contexts, the (device, slot) token pool, workspace
+// management, the SeedAndFilter orchestration and the C-ABI of include/segalign_amd.h.
+//
+// Mirrors, entry point by entry point, the reference engine:
+//   common/seed_filter_interface.cu (InitializeInterface, SendRefWriteRequest, ClearRef)
+//   common/seed_pos_table.cu        (GenerateSeedPosTable -- here a DEVICE build)
+//   src/seed_filter.cu              (InitializeProcessor, SendQueryWriteRequest, ClearQuery, SeedAndFilter,
+//                                    ShutdownProcessor)
+//   repeat_masker_src/seed_filter.cu (the self-alignment variant)
+// There is no CPU fallback: without a HIP device every entry point exits exactly like the reference does.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/segalign_amd.h"
+#include "kernels.h"
+#include "plan.h"
+
+namespace sa {
+
+// ------------------------------------------------------------------------------------------------------------------
+// error handling -- exit codes of common/cuda_utils.h:4-37 (+15 for launches, which the reference never checks)
+// ------------------------------------------------------------------------------------------------------------------
+static void die(int code, const char* what, const char* tag, hipError_t err) {
+    fprintf(stderr, "Error: %s for %s failed with error \" %s \" \n", what, tag, hipGetErrorString(err));
+    exit(code);
+}
+static inline void check_set_device(int dev, const char* tag) {
+    hipError_t e = hipSetDevice(dev);
+    if (e != hipSuccess) die(11, "hipSetDevice", tag, e);
+}
+static inline void* dev_malloc(size_t bytes, const char* tag) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        fprintf(stderr, "Error: hipMalloc of %lu bytes for %s failed with error \" %s \" \n", (unsigned long)bytes, tag,
+                hipGetErrorString(e));
+        exit(12);
+    }
+    return p;
+}
+static inline void check_memcpy(hipError_t e, const char* tag) {
+    if (e != hipSuccess) die(13, "hipMemcpy", tag, e);
+}
+static inline void dev_free(void* p, const char* tag) {
+    if (!p) return;
+    hipError_t e = hipFree(p);
+    if (e != hipSuccess) die(14, "hipFree", tag, e);
+}
+static inline void check_launch(const char* tag) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) die(15, "kernel launch", tag, e);
+}
+static inline void check_sync(hipStream_t s, const char* tag) {
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) die(15, "hipStreamSynchronize", tag, e);
+}
+
+template <typename T>
+struct DevBuf {  // grow-only device buffer
+    T* p = nullptr;
+    size_t cap = 0;  // elements
+    void ensure(size_t n, const char* tag, bool keep = false, hipStream_t s = 0) {
+        if (n <= cap) return;
+        size_t ncap = std::max(n, cap + cap / 2);
+        T* np = (T*)dev_malloc(ncap * sizeof(T), tag);
+        if (keep && p && cap) {
+            check_memcpy(hipMemcpyAsync(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice, s), tag);
+            check_sync(s, tag);
+        }
+        dev_free(p, tag);
+        p = np;
+        cap = ncap;
+    }
+    void release(const char* tag) {
+        dev_free(p, tag);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct SeqBuf {  // encoded sequence with SEQ_PAD guard bytes on both sides
+    uint8_t* alloc = nullptr;
+    uint8_t* codes = nullptr;
+    uint32_t len = 0;
+    void create(uint32_t n, const char* tag, hipStream_t s) {
+        release(tag);
+        size_t bytes = (size_t)n + 2 * SEQ_PAD + 64;  // +64: the k-mer window reads 32 bytes from any position
+        alloc = (uint8_t*)dev_malloc(bytes, tag);
+        check_memcpy(hipMemsetAsync(alloc, 7 /*E*/, bytes, s), tag);
+        codes = alloc + SEQ_PAD;
+        len = n;
+    }
+    void release(const char* tag) {
+        dev_free(alloc, tag);
+        alloc = codes = nullptr;
+        len = 0;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// profiling: HIP events on the engine's own streams
+// ------------------------------------------------------------------------------------------------------------------
+struct ProfEntry {
+    std::string name;
+    double total_ms = 0;
+    uint64_t launches = 0;
+};
+static std::mutex g_prof_mu;
+static std::vector<ProfEntry> g_prof;
+static bool g_prof_on = false;
+
+struct Slot;
+struct ProfRec {
+    int id;
+    hipEvent_t e0, e1;
+};
+
+static int prof_id(const char* name) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (size_t i = 0; i < g_prof.size(); i++)
+        if (g_prof[i].name == name) return (int)i;
+    ProfEntry e;
+    e.name = name;
+    g_prof.push_back(e);
+    return (int)g_prof.size() - 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// per-device state
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int SLOTS_PER_DEVICE = 2;  // calls in flight per device (the reference allows one: token == device)
+
+struct Counters {  // device-side scalars of one slot
+    uint32_t survivors;
+    uint32_t uniq;
+    uint32_t uniq2;
+    uint32_t pad;
+    unsigned long long examined;
+};
+
+struct Slot {
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    DevBuf<uint64_t> seeds;
+    DevBuf<uint32_t> start, count, flags, flag_prefix;
+    DevBuf<uint64_t> prefix;
+    DevBuf<uint8_t> scan_temp, sort_temp;
+    DevBuf<Hit> hits;
+    DevBuf<HspRec> recA, recB;
+    DevBuf<sa_segment_pair> out16;
+    IterPlan* d_plan = nullptr;
+    Counters* d_cnt = nullptr;
+    // pinned host staging
+    IterPlan* h_plan = nullptr;
+    Counters* h_cnt = nullptr;
+    uint64_t* h_seeds = nullptr;
+    size_t h_seeds_cap = 0;
+    sa_segment_pair* h_out = nullptr;
+    size_t h_out_cap = 0;
+    // profiling
+    std::vector<ProfRec> prof_pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
+    size_t events_used = 0;
+};
+
+struct DevCtx {
+    int dev = 0;
+    hipStream_t admin = nullptr;
+    size_t total_mem = 0;
+    int* d_sub_mat = nullptr;
+    SeqBuf ref;
+    const char* ref_host_ptr = nullptr;  // identity of the block last sent (to skip a second upload for the table)
+    SeqBuf ref_rc;                       // repeat masker
+    uint32_t* bucket_start = nullptr;    // 4^k + 1
+    uint32_t* pos_table = nullptr;
+    uint32_t num_index = 0;
+    uint32_t nkeys = 0;
+    SeqBuf query[SA_BUFFER_DEPTH], query_rc[SA_BUFFER_DEPTH];
+    Slot slots[SLOTS_PER_DEVICE];
+};
+
+static int g_ndev = 0;
+static std::vector<int> g_selected;  // sa_select_devices
+static std::vector<DevCtx*> g_dev;
+static std::mutex g_mu;  // token pool (seed_filter_interface.cu:7-9)
+static std::condition_variable g_cv;
+static std::vector<std::pair<int, int>> g_tokens;
+
+static bool g_proc_init = false;
+static int g_transition = 1;
+static uint32_t g_wga_chunk = 250000;
+static uint32_t g_seed_size = 19;
+static int g_sub_mat[64];
+static int g_xdrop = 910, g_hspthresh = 3000, g_noentropy = 0;
+static int64_t g_max_seeds = 0;
+static int64_t g_max_hits = 0;
+static bool g_max_hits_overridden = false;
+static bool g_count_examined = false;
+static SeedShape g_shape = {0, 0, 0, {0}};
+static uint32_t g_query_len[SA_BUFFER_DEPTH] = {0, 0};
+
+static thread_local sa_call_stats t_stats;
+
+static int max_hits_for_mem(uint64_t total_global_mem) {  // src/seed_filter.cu:832-841, literally
+    float global_mem_gb = static_cast<float>(total_global_mem / 1073741824.0f);
+    return (int)(4194304 * global_mem_gb);
+}
+
+// ---- profiling scope ------------------------------------------------------------------------------------------------
+struct ProfScope {
+    Slot* sl;
+    bool on;
+    ProfRec r;
+    ProfScope(Slot* s, const char* name) : sl(s), on(g_prof_on) {
+        if (!on) return;
+        if (sl->events_used == sl->event_pool.size()) {
+            hipEvent_t a, b;
+            hipEventCreate(&a);
+            hipEventCreate(&b);
+            sl->event_pool.push_back({a, b});
+        }
+        r.id = prof_id(name);
+        r.e0 = sl->event_pool[sl->events_used].first;
+        r.e1 = sl->event_pool[sl->events_used].second;
+        sl->events_used++;
+        hipEventRecord(r.e0, sl->stream);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        hipEventRecord(r.e1, sl->stream);
+        sl->prof_pending.push_back(r);
+    }
+};
+static void prof_flush(Slot* sl) {  // call after the slot's stream has been synchronised
+    if (sl->prof_pending.empty()) { sl->events_used = 0; return; }
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : sl->prof_pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            g_prof[r.id].total_ms += ms;
+            g_prof[r.id].launches += 1;
+        }
+    }
+    sl->prof_pending.clear();
+    sl->events_used = 0;
+}
+
+// ---- token pool ------------------------------------------------------------------------------------------------------
+static Slot* acquire_slot() {  // src/seed_filter.cu:699-708
+    std::unique_lock<std::mutex> lk(g_mu);
+    g_cv.wait(lk, [] { return !g_tokens.empty(); });
+    auto t = g_tokens.back();
+    g_tokens.pop_back();
+    lk.unlock();
+    check_set_device(g_dev[t.first]->dev, "SeedAndFilter");
+    return &g_dev[t.first]->slots[t.second];
+}
+static void release_slot(Slot* s) {  // src/seed_filter.cu:798-803
+    int di = -1, si = -1;
+    for (int d = 0; d < g_ndev; d++)
+        for (int k = 0; k < SLOTS_PER_DEVICE; k++)
+            if (&g_dev[d]->slots[k] == s) { di = d; si = k; }
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_tokens.push_back({di, si});
+    }
+    g_cv.notify_one();
+}
+
+static void slot_init(Slot& s, int dev) {
+    s.dev = dev;
+    hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+    s.d_plan = (IterPlan*)dev_malloc(sizeof(IterPlan), "plan");
+    s.d_cnt = (Counters*)dev_malloc(sizeof(Counters), "counters");
+    if (hipHostMalloc((void**)&s.h_plan, sizeof(IterPlan)) != hipSuccess ||
+        hipHostMalloc((void**)&s.h_cnt, sizeof(Counters)) != hipSuccess) {
+        fprintf(stderr, "Error: hipHostMalloc for slot staging failed\n");
+        exit(12);
+    }
+}
+static void slot_destroy(Slot& s) {
+    s.seeds.release("seeds"); s.start.release("start"); s.count.release("count"); s.flags.release("flags");
+    s.flag_prefix.release("flag_prefix"); s.prefix.release("prefix"); s.scan_temp.release("scan_temp");
+    s.sort_temp.release("sort_temp"); s.hits.release("hits"); s.recA.release("recA"); s.recB.release("recB");
+    s.out16.release("out16");
+    dev_free(s.d_plan, "plan"); dev_free(s.d_cnt, "counters");
+    s.d_plan = nullptr; s.d_cnt = nullptr;
+    if (s.h_plan) hipHostFree(s.h_plan);
+    if (s.h_cnt) hipHostFree(s.h_cnt);
+    if (s.h_seeds) hipHostFree(s.h_seeds);
+    if (s.h_out) hipHostFree(s.h_out);
+    s.h_plan = nullptr; s.h_cnt = nullptr; s.h_seeds = nullptr; s.h_out = nullptr;
+    s.h_seeds_cap = s.h_out_cap = 0;
+    for (auto& e : s.event_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    s.event_pool.clear();
+    if (s.stream) hipStreamDestroy(s.stream);
+    s.stream = nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// SeedAndFilter core: seeds already in slot->seeds (device), n of them.
+// ------------------------------------------------------------------------------------------------------------------
+struct CoreArgs {
+    const uint8_t* query;
+    uint32_t query_len;
+    int rm;
+    int rm_rev;
+    uint32_t rm_win_start, rm_win_end;
+};
+
+static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa_segment_pair** out) {
+    hipStream_t st = sl->stream;
+    memset(&t_stats, 0, sizeof(t_stats));
+    t_stats.num_seeds = num_seeds;
+    t_stats.device = dc->dev;
+
+    uint64_t num_hits = 0;
+    uint32_t n_final = 0;
+    uint32_t survivors = 0;
+
+    if (num_seeds > 0) {
+        // ---- bucket lookup + prefix (find_num_hits :157-182 ; inclusive_scan :714) ----
+        sl->start.ensure(num_seeds, "seed start");
+        sl->count.ensure(num_seeds, "seed count");
+        sl->prefix.ensure((size_t)num_seeds + 1, "hit prefix");
+        sl->scan_temp.ensure(scan_temp_bytes(num_seeds), "scan temp");
+        {
+            ProfScope p(sl, "seed_lookup");
+            launch_seed_lookup(sl->seeds.p, num_seeds, dc->bucket_start, dc->nkeys, sl->start.p, sl->count.p, st);
+        }
+        {
+            ProfScope p(sl, "hit_prefix_scan");
+            launch_exclusive_scan_u64(sl->count.p, sl->prefix.p, num_seeds, sl->scan_temp.p, st);
+        }
+        // ---- iteration plan (:718-745), one D2H ----
+        {
+            ProfScope p(sl, "iteration_plan");
+            launch_plan(sl->prefix.p, num_seeds, (uint64_t)(uint32_t)g_max_hits, ca.rm ? 0 : 1, sl->d_plan, st);
+        }
+        check_launch("lookup/scan/plan");
+        check_memcpy(hipMemcpyAsync(sl->h_plan, sl->d_plan, sizeof(IterPlan), hipMemcpyDeviceToHost, st), "plan");
+        check_memcpy(hipMemsetAsync(sl->d_cnt, 0, sizeof(Counters), st), "counters");
+        check_sync(st, "plan");
+        memset(sl->h_cnt, 0, sizeof(Counters));
+        const IterPlan& plan = *sl->h_plan;
+        if (plan.overflow) {
+            fprintf(stderr, "Error: SeedAndFilter needs %u iterations (> %u); MAX_HITS=%ld is too small for %lu hits\n",
+                    plan.overflow, PLAN_MAX_ITER, (long)g_max_hits, (unsigned long)plan.num_hits);
+            exit(15);
+        }
+        num_hits = plan.num_hits;
+        t_stats.num_iter = plan.num_iter;
+
+        if (num_hits > 0 && plan.num_iter > 0) {
+            // ---- batches of consecutive iterations: expand (find_hits) + extend (find_hsps) ----
+            const uint64_t HIT_BATCH = 1ull << 27;  // 128 Mi hits (1 GiB of 8-byte hits) per batch unless one iteration is larger
+            sl->recA.ensure((size_t)std::max<uint64_t>(1u << 20, std::min<uint64_t>(num_hits, 1ull << 26)), "survivors");
+            uint32_t it = 0;
+            int64_t seed_lo = 0;
+            uint64_t hit_lo = 0;
+            while (it < plan.num_iter) {
+                ExtendArgs ea;
+                memset(&ea, 0, sizeof(ea));
+                int nseg = 0;
+                int64_t b_seed_lo = seed_lo, b_seed_hi = seed_lo;
+                uint64_t b_hit_lo = hit_lo, b_hit_hi = hit_lo;
+                uint32_t it0 = it;
+                while (it < plan.num_iter && nseg < MAX_SEGS) {
+                    uint64_t upto = plan.upto[it];
+                    if (nseg > 0 && upto - b_hit_lo > HIT_BATCH) break;
+                    ea.seg_end[nseg++] = upto;
+                    b_seed_hi = plan.limit_pos[it] + 1;
+                    b_hit_hi = upto;
+                    it++;
+                }
+                seed_lo = b_seed_hi;
+                hit_lo = b_hit_hi;
+                const uint64_t bh = b_hit_hi - b_hit_lo;
+                if (bh == 0 || b_seed_hi <= b_seed_lo) continue;  // iterations without hits produce nothing (H5)
+                sl->hits.ensure((size_t)bh, "hits");
+                {
+                    ProfScope p(sl, "expand_hits");
+                    launch_expand_hits(sl->seeds.p, sl->start.p, sl->count.p, sl->prefix.p, (uint32_t)b_seed_lo,
+                                       (uint32_t)b_seed_hi, b_hit_lo, dc->pos_table, g_seed_size, sl->hits.p, st);
+                }
+                ea.ref = dc->ref.codes;
+                ea.query = ca.query;
+                ea.ref_len = dc->ref.len;
+                ea.query_len = ca.query_len;
+                ea.sub_mat = dc->d_sub_mat;
+                ea.xdrop = g_xdrop;
+                ea.hspthresh = g_hspthresh;
+                ea.noentropy = g_noentropy;
+                ea.hits = sl->hits.p;
+                ea.num_hits = bh;
+                ea.hit_base = b_hit_lo;
+                ea.num_segs = nseg;
+                ea.seg_base = it0;
+                ea.out_count = &sl->d_cnt->survivors;
+                ea.examined = g_count_examined ? &sl->d_cnt->examined : nullptr;
+                ea.rm = ca.rm;
+                ea.rm_rev = ca.rm_rev;
+                ea.rm_win_start = ca.rm_win_start;
+                ea.rm_win_end = ca.rm_win_end;
+                const Counters before = *sl->h_cnt;  // counters as of the previous batch (zero for the first)
+                for (;;) {  // rerun the batch with a larger survivor buffer if it overflowed (writes are guarded)
+                    ea.out = sl->recA.p;
+                    ea.out_cap = (uint32_t)std::min<size_t>(sl->recA.cap, 0xFFFFFFFFu);
+                    {
+                        ProfScope p(sl, "extend_hits");
+                        launch_extend(ea, st);
+                    }
+                    check_launch("expand/extend");
+                    check_memcpy(hipMemcpyAsync(sl->h_cnt, sl->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st), "counters");
+                    check_sync(st, "extend");
+                    if (sl->h_cnt->survivors <= ea.out_cap) break;
+                    const uint32_t need = sl->h_cnt->survivors;
+                    sl->recA.ensure(need, "survivors(grow)", true, st);
+                    check_memcpy(hipMemcpy(sl->d_cnt, &before, sizeof(Counters), hipMemcpyHostToDevice), "counter reset");
+                }
+                survivors = sl->h_cnt->survivors;
+            }
+            t_stats.num_examined = sl->h_cnt->examined;
+
+            // ---- order + de-duplicate (:776-782 ; rm :819-831) ----
+            if (survivors > 0) {
+                sl->recB.ensure(std::max<size_t>(survivors, sl->recA.cap), "survivors B");
+                size_t tb = sort_temp_bytes(survivors);
+                sl->sort_temp.ensure(tb, "sort temp");
+                HspRec* fin = nullptr;
+                if (!ca.rm) {
+                    { ProfScope p(sl, "sort_diag");  launch_sort(sl->recA.p, sl->recB.p, survivors, ORDER_DIAG, sl->sort_temp.p, sl->sort_temp.cap, st); }
+                    { ProfScope p(sl, "unique");     launch_unique(sl->recB.p, sl->recA.p, survivors, 0, &sl->d_cnt->uniq, st); }
+                    check_launch("sort/unique");
+                    check_memcpy(hipMemcpyAsync(sl->h_cnt, sl->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st), "counters");
+                    check_sync(st, "unique");
+                    n_final = sl->h_cnt->uniq;
+                    { ProfScope p(sl, "sort_lastz"); launch_sort(sl->recA.p, sl->recB.p, n_final, ORDER_LASTZ, sl->sort_temp.p, sl->sort_temp.cap, st); }
+                    fin = sl->recB.p;
+                } else {
+                    { ProfScope p(sl, "sort_rm_first"); launch_sort(sl->recA.p, sl->recB.p, survivors, ORDER_RM_FIRST, sl->sort_temp.p, sl->sort_temp.cap, st); }
+                    { ProfScope p(sl, "unique");        launch_unique(sl->recB.p, sl->recA.p, survivors, 1, &sl->d_cnt->uniq, st); }
+                    check_launch("sort/unique");
+                    check_memcpy(hipMemcpyAsync(sl->h_cnt, sl->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st), "counters");
+                    check_sync(st, "unique");
+                    uint32_t n1 = sl->h_cnt->uniq;
+                    { ProfScope p(sl, "sort_rm_diag");  launch_sort(sl->recA.p, sl->recB.p, n1, ORDER_RM_DIAG, sl->sort_temp.p, sl->sort_temp.cap, st); }
+                    { ProfScope p(sl, "unique");        launch_unique(sl->recB.p, sl->recA.p, n1, 0, &sl->d_cnt->uniq2, st); }
+                    check_launch("sort/unique 2");
+                    check_memcpy(hipMemcpyAsync(sl->h_cnt, sl->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st), "counters");
+                    check_sync(st, "unique 2");
+                    n_final = sl->h_cnt->uniq2;
+                    { ProfScope p(sl, "sort_rm_final"); launch_sort(sl->recA.p, sl->recB.p, n_final, ORDER_RM_FINAL, sl->sort_temp.p, sl->sort_temp.cap, st); }
+                    fin = sl->recB.p;
+                }
+                if (n_final > 0) {
+                    sl->out16.ensure(n_final, "out16");
+                    if (sl->h_out_cap < n_final) {
+                        if (sl->h_out) hipHostFree(sl->h_out);
+                        sl->h_out_cap = std::max<size_t>(n_final, 1u << 16);
+                        if (hipHostMalloc((void**)&sl->h_out, sl->h_out_cap * sizeof(sa_segment_pair)) != hipSuccess) {
+                            fprintf(stderr, "Error: hipHostMalloc for hsp_output failed\n");
+                            exit(12);
+                        }
+                    }
+                    { ProfScope p(sl, "strip"); launch_strip(fin, n_final, sl->out16.p, st); }
+                    check_launch("final sort/strip");
+                    check_memcpy(hipMemcpyAsync(sl->h_out, sl->out16.p, (size_t)n_final * sizeof(sa_segment_pair),
+                                                hipMemcpyDeviceToHost, st), "hsp_output");  // :788
+                }
+                check_sync(st, "hsp_output");
+            }
+        }
+    }
+    prof_flush(sl);
+
+    // ---- return vector: header + HSPs (:804-827 ; rm :857-861) ----
+    sa_segment_pair* res = (sa_segment_pair*)malloc(((size_t)n_final + 1) * sizeof(sa_segment_pair));
+    memset(&res[0], 0, sizeof(sa_segment_pair));
+    if (!ca.rm) {
+        res[0].len = n_final;
+        res[0].score = (int32_t)(uint32_t)num_hits;
+    } else {
+        uint64_t ta = n_final;
+        res[0].ref_start = (uint32_t)(num_hits & 0xFFFFFFFFull);
+        res[0].query_start = (uint32_t)(num_hits >> 32);
+        res[0].len = (uint32_t)(ta & 0xFFFFFFFFull);
+        res[0].score = (int32_t)(ta >> 32);
+    }
+    if (n_final) memcpy(res + 1, sl->h_out, (size_t)n_final * sizeof(sa_segment_pair));
+    t_stats.num_hits = num_hits;
+    t_stats.num_survivors = survivors;
+    t_stats.num_anchors = n_final;
+    *out = res;
+    return (size_t)n_final + 1;
+}
+
+static void upload_seeds(Slot* sl, const uint64_t* seeds, size_t n) {
+    sl->seeds.ensure(std::max<size_t>(n, (size_t)g_max_seeds), "seed_offsets");
+    if (n == 0) return;
+    if (sl->h_seeds_cap < n) {
+        if (sl->h_seeds) hipHostFree(sl->h_seeds);
+        sl->h_seeds_cap = std::max<size_t>(n, (size_t)g_max_seeds);
+        if (hipHostMalloc((void**)&sl->h_seeds, sl->h_seeds_cap * sizeof(uint64_t)) != hipSuccess) {
+            fprintf(stderr, "Error: hipHostMalloc for seed_offsets failed\n");
+            exit(12);
+        }
+    }
+    memcpy(sl->h_seeds, seeds, n * sizeof(uint64_t));  // reference copies the vector too (:694-697)
+    ProfScope p(sl, "h2d_seeds");
+    check_memcpy(hipMemcpyAsync(sl->seeds.p, sl->h_seeds, n * sizeof(uint64_t), hipMemcpyHostToDevice, sl->stream),
+                 "seed_offsets");  // :710
+}
+
+// device-side seeder (8f-1): fills sl->seeds for query positions [start,end); returns number of seed words
+static uint32_t device_seeds(Slot* sl, const uint8_t* qcodes, uint32_t start, uint32_t end) {
+    if (end <= start) return 0;
+    hipStream_t st = sl->stream;
+    const uint32_t n = end - start;
+    SeedShape sh = g_shape;
+    sh.span = (int)g_seed_size;
+    const uint32_t tmask = g_transition ? (sh.transition_mask & ((1u << sh.weight) - 1u)) : 0u;
+    const uint32_t per = 1u + (uint32_t)__builtin_popcount(tmask);
+    sl->flags.ensure(n, "seed flags");
+    sl->flag_prefix.ensure((size_t)n + 1, "seed flag prefix");
+    sl->scan_temp.ensure(scan_temp_bytes(n), "scan temp");
+    {
+        ProfScope p(sl, "seed_flags");
+        launch_seed_flags(qcodes, start, end, sh, sl->flags.p, st);
+    }
+    {
+        ProfScope p(sl, "seed_flag_scan");
+        launch_exclusive_scan_u32(sl->flags.p, sl->flag_prefix.p, n, sl->scan_temp.p, st);
+    }
+    check_launch("seed flags");
+    uint32_t nvalid = 0;
+    check_memcpy(hipMemcpyAsync(&sl->h_cnt->pad, sl->flag_prefix.p + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st), "nvalid");
+    check_sync(st, "seed flags");
+    nvalid = sl->h_cnt->pad;
+    const uint64_t nseeds = (uint64_t)nvalid * per;
+    if (nseeds == 0) return 0;
+    sl->seeds.ensure(std::max<size_t>((size_t)nseeds, (size_t)g_max_seeds), "seed_offsets");
+    {
+        ProfScope p(sl, "seed_emit");
+        launch_seed_emit(qcodes, start, end, sh, g_transition, sl->flag_prefix.p, sl->seeds.p, st);
+    }
+    check_launch("seed emit");
+    return (uint32_t)nseeds;
+}
+
+static void require_init(const char* who) {
+    if (g_ndev <= 0) {
+        fprintf(stderr, "Error: %s called before InitializeInterface\n", who);
+        exit(1);
+    }
+}
+
+}  // namespace sa
+
+using namespace sa;
+
+// ====================================================================================================================
+// C-ABI
+// ====================================================================================================================
+extern "C" {
+
+const char* sa_version(void) { return "segalign_amd 0.1 (gfx950)"; }
+
+void sa_select_devices(const int* ids, int n) {
+    g_selected.clear();
+    for (int i = 0; i < n; i++) g_selected.push_back(ids[i]);
+}
+
+int sa_initialize_interface(int num_gpu) {  // seed_filter_interface.cu:49-80
+    int n = 0;
+    hipError_t err = hipGetDeviceCount(&n);
+    if (err != hipSuccess || n <= 0) {
+        fprintf(stderr, "Error: No GPU device found!\n");
+        exit(1);
+    }
+    if (!g_selected.empty()) {
+        for (int id : g_selected)
+            if (id < 0 || id >= n) {
+                fprintf(stderr, "Requested GPUs greater than available GPUs\n");
+                exit(10);
+            }
+        n = (int)g_selected.size();
+    }
+    int use;
+    if (num_gpu == -1) use = n;
+    else if (num_gpu <= n) use = num_gpu;
+    else {
+        fprintf(stderr, "Requested GPUs greater than available GPUs\n");
+        exit(10);
+    }
+    fprintf(stderr, "Using %d GPU(s)\n", use);
+    for (auto* d : g_dev) delete d;
+    g_dev.clear();
+    g_tokens.clear();
+    g_ndev = use;
+    for (int g = 0; g < use; g++) {
+        const int ord = g_selected.empty() ? g : g_selected[g];
+        check_set_device(ord, "InitializeInterface");
+        DevCtx* dc = new DevCtx();
+        dc->dev = ord;
+        hipStreamCreateWithFlags(&dc->admin, hipStreamNonBlocking);
+        hipDeviceProp_t prop;
+        hipGetDeviceProperties(&prop, ord);
+        dc->total_mem = prop.totalGlobalMem;
+        g_dev.push_back(dc);
+    }
+    return use;
+}
+
+void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_size, const int* sub_mat, int xdrop,
+                             int hspthresh, int noentropy) {  // src/seed_filter.cu:830-897
+    require_init("InitializeProcessor");
+    g_transition = transition ? 1 : 0;
+    g_wga_chunk = wga_chunk;
+    g_max_seeds = transition ? 13ll * wga_chunk : (int64_t)wga_chunk;  // :836-839
+    if (!g_max_hits_overridden) g_max_hits = max_hits_for_mem(g_dev[0]->total_mem);  // :832-841 (device 0)
+    g_seed_size = seed_size;
+    memcpy(g_sub_mat, sub_mat, sizeof(g_sub_mat));
+    g_xdrop = xdrop;
+    g_hspthresh = hspthresh;
+    g_noentropy = noentropy ? 1 : 0;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_tokens.clear();
+    for (int g = 0; g < g_ndev; g++) {
+        DevCtx* dc = g_dev[g];
+        check_set_device(dc->dev, "InitializeProcessor");
+        if (!dc->d_sub_mat) dc->d_sub_mat = (int*)dev_malloc(64 * sizeof(int), "sub_mat");
+        check_memcpy(hipMemcpy(dc->d_sub_mat, g_sub_mat, 64 * sizeof(int), hipMemcpyHostToDevice), "sub_mat");
+        for (int k = 0; k < SLOTS_PER_DEVICE; k++) {
+            if (!dc->slots[k].stream) slot_init(dc->slots[k], dc->dev);
+            dc->slots[k].seeds.ensure((size_t)g_max_seeds, "seed_offsets");
+        }
+    }
+    // LIFO pool like available_gpus (:895): slot-major so that concurrent callers spread over devices first
+    for (int k = SLOTS_PER_DEVICE - 1; k >= 0; k--)
+        for (int g = g_ndev - 1; g >= 0; g--) g_tokens.push_back({g, k});
+    g_proc_init = true;
+}
+
+void sa_shutdown_processor(void) {  // src/seed_filter.cu:932-940
+    for (auto* dc : g_dev) {
+        check_set_device(dc->dev, "ShutdownProcessor");
+        hipDeviceSynchronize();
+        for (int k = 0; k < SLOTS_PER_DEVICE; k++) slot_destroy(dc->slots[k]);
+        dc->ref.release("d_ref_seq");
+        dc->ref_rc.release("d_seq_rc");
+        dev_free(dc->bucket_start, "d_index_table");
+        dev_free(dc->pos_table, "d_pos_table");
+        dc->bucket_start = dc->pos_table = nullptr;
+        for (int b = 0; b < SA_BUFFER_DEPTH; b++) {
+            dc->query[b].release("d_query_seq");
+            dc->query_rc[b].release("d_query_rc_seq");
+        }
+        dev_free(dc->d_sub_mat, "sub_mat");
+        dc->d_sub_mat = nullptr;
+        if (dc->admin) hipStreamDestroy(dc->admin);
+        delete dc;
+    }
+    g_dev.clear();
+    g_tokens.clear();
+    g_ndev = 0;
+    g_proc_init = false;
+}
+
+// ---- target ---------------------------------------------------------------------------------------------------------
+void sa_send_ref_write_request(const char* seq, size_t addr, uint32_t len) {  // seed_filter_interface.cu:82-101
+    require_init("SendRefWriteRequest");
+    for (auto* dc : g_dev) {
+        check_set_device(dc->dev, "SendRefWriteRequest");
+        uint8_t* tmp = (uint8_t*)dev_malloc((size_t)len + 16, "tmp_ref_seq");
+        check_memcpy(hipMemcpyAsync(tmp, seq + addr, len, hipMemcpyHostToDevice, dc->admin), "ref_seq");
+        dc->ref.create(len, "ref_seq", dc->admin);
+        launch_encode(tmp, dc->ref.codes, len, dc->admin);
+        check_launch("compress_string");
+        check_sync(dc->admin, "SendRefWriteRequest");
+        dev_free(tmp, "d_ref_seq_tmp");
+        dc->ref_host_ptr = seq + addr;
+    }
+}
+
+void sa_clear_ref(void) {  // seed_filter_interface.cu:103-113
+    for (auto* dc : g_dev) {
+        check_set_device(dc->dev, "ClearRef");
+        dc->ref.release("d_ref_seq");
+        dc->ref_host_ptr = nullptr;
+        dev_free(dc->bucket_start, "d_index_table");
+        dev_free(dc->pos_table, "d_pos_table");
+        dc->bucket_start = dc->pos_table = nullptr;
+        dc->num_index = 0;
+    }
+}
+
+int sa_generate_shape_pos(const char* shape) {  // ntcoding.cpp:21-37
+    SeedShape sh;
+    memset(&sh, 0, sizeof(sh));
+    int n = 0, span = 0;
+    for (int i = 0; shape[i] != '\0'; i++, span++) {
+        if (shape[i] == '1' || shape[i] == 'T') {
+            if (n >= MAX_CARE) {
+                fprintf(stderr, "Error: seed weight above %d is not supported\n", MAX_CARE - 1);
+                exit(1);
+            }
+            sh.pos[n] = (uint8_t)i;
+            if (shape[i] == 'T') sh.transition_mask |= 1u << n;
+            n++;
+        }
+    }
+    if (span > 32) {
+        fprintf(stderr, "Error: seed span above 32 is not supported\n");
+        exit(1);
+    }
+    sh.weight = n;
+    sh.span = span;
+    g_shape = sh;
+    return n;
+}
+
+void sa_generate_seed_pos_table(const char* ref_str, size_t start_addr, uint32_t ref_length, uint32_t step, int shape_size,
+                                int kmer_size) {  // seed_pos_table.cu:49-109
+    require_init("GenerateSeedPosTable");
+    if (!(kmer_size <= 15 && kmer_size > 3)) {  // asserts at :51-52
+        fprintf(stderr, "Error: GenerateSeedPosTable requires 3 < kmer_size <= 15\n");
+        exit(1);
+    }
+    if (step == 0) step = 1;
+    const uint32_t offset = (uint32_t)(shape_size + 1) % step;                       // :58
+    const uint32_t start_offset = step - offset;                                     // :59
+    const uint32_t nkeys = (uint32_t)1 << (2 * kmer_size);                           // :61
+    const uint32_t num_steps = ref_length >= (uint32_t)shape_size ? (ref_length - (uint32_t)shape_size + offset) / step : 0;  // :64
+    SeedShape sh = g_shape;
+    sh.span = shape_size;
+    for (auto* dc : g_dev) {
+        check_set_device(dc->dev, "GenerateSeedPosTable");
+        hipStream_t st = dc->admin;
+        const uint8_t* codes = dc->ref.codes;
+        SeqBuf tmp_codes;
+        if (!(dc->ref.codes && dc->ref_host_ptr == ref_str + start_addr && dc->ref.len == ref_length)) {
+            // not the resident block: encode a private copy
+            uint8_t* tmp = (uint8_t*)dev_malloc((size_t)ref_length + 16, "tmp table seq");
+            check_memcpy(hipMemcpyAsync(tmp, ref_str + start_addr, ref_length, hipMemcpyHostToDevice, st), "table seq");
+            tmp_codes.create(ref_length, "table codes", st);
+            launch_encode(tmp, tmp_codes.codes, ref_length, st);
+            check_sync(st, "table encode");
+            dev_free(tmp, "tmp table seq");
+            codes = tmp_codes.codes;
+        }
+        dev_free(dc->bucket_start, "d_index_table");
+        dev_free(dc->pos_table, "d_pos_table");
+        uint32_t* hist = (uint32_t*)dev_malloc(((size_t)nkeys + 1) * sizeof(uint32_t), "kmer histogram");
+        dc->bucket_start = (uint32_t*)dev_malloc(((size_t)nkeys + 1) * sizeof(uint32_t), "index_table");
+        void* scan_tmp = dev_malloc(scan_temp_bytes(nkeys), "scan temp");
+        check_memcpy(hipMemsetAsync(hist, 0, ((size_t)nkeys + 1) * sizeof(uint32_t), st), "histogram");
+        launch_table_count(codes, num_steps, start_offset, step, sh, hist, st);
+        launch_exclusive_scan_u32(hist, dc->bucket_start, nkeys, scan_tmp, st);
+        check_launch("table count/scan");
+        uint32_t num_index = 0;
+        check_memcpy(hipMemcpyAsync(&num_index, dc->bucket_start + nkeys, sizeof(uint32_t), hipMemcpyDeviceToHost, st),
+                     "num_index");
+        check_sync(st, "table count");
+        dc->pos_table = (uint32_t*)dev_malloc((size_t)std::max<uint32_t>(num_index, 1) * sizeof(uint32_t), "pos_table");
+        check_memcpy(hipMemsetAsync(hist, 0, ((size_t)nkeys + 1) * sizeof(uint32_t), st), "cursor");
+        launch_table_fill(codes, num_steps, start_offset, step, sh, dc->bucket_start, hist, dc->pos_table, st);
+        launch_table_sort_buckets(dc->bucket_start, nkeys, dc->pos_table, st);
+        check_launch("table fill/sort");
+        check_sync(st, "table fill");
+        dev_free(hist, "kmer histogram");
+        dev_free(scan_tmp, "scan temp");
+        tmp_codes.release("table codes");
+        dc->num_index = num_index;
+        dc->nkeys = nkeys;
+    }
+}
+
+// ---- query ----------------------------------------------------------------------------------------------------------
+void sa_send_query_write_request(const char* query_buffer, size_t addr, uint32_t len, uint32_t buffer) {  // :899-919
+    require_init("SendQueryWriteRequest");
+    if (buffer >= SA_BUFFER_DEPTH) {
+        fprintf(stderr, "Error: query buffer %u out of range\n", buffer);
+        exit(1);
+    }
+    g_query_len[buffer] = len;
+    for (auto* dc : g_dev) {
+        check_set_device(dc->dev, "SendQueryWriteRequest");
+        hipStream_t st = dc->admin;
+        uint8_t* tmp = (uint8_t*)dev_malloc((size_t)len + 16, "tmp query_seq");
+        check_memcpy(hipMemcpyAsync(tmp, query_buffer + addr, len, hipMemcpyHostToDevice, st), "query_seq");
+        dc->query[buffer].create(len, "query_seq", st);
+        dc->query_rc[buffer].create(len, "query_rc_seq", st);
+        launch_encode_rev_comp(tmp, dc->query[buffer].codes, dc->query_rc[buffer].codes, len, st);
+        check_launch("compress_string_rev_comp");
+        check_sync(st, "SendQueryWriteRequest");
+        dev_free(tmp, "d_query_seq_tmp");
+    }
+}
+
+void sa_clear_query(uint32_t buffer) {  // :921-930
+    if (buffer >= SA_BUFFER_DEPTH) return;
+    for (auto* dc : g_dev) {
+        check_set_device(dc->dev, "ClearQuery");
+        dc->query[buffer].release("d_query_seq");
+        dc->query_rc[buffer].release("d_query_rc_seq");
+    }
+}
+
+// ---- hot calls ------------------------------------------------------------------------------------------------------
+size_t sa_seed_and_filter(const uint64_t* seeds, size_t num_seeds, int rev, uint32_t buffer, sa_segment_pair** out) {
+    require_init("SeedAndFilter");
+    if ((int64_t)num_seeds > g_max_seeds) {  // :688-692
+        printf("MAX_SEEDS exceeded\n");
+        fprintf(stderr, "Assertion `num_seeds <= MAX_SEEDS' failed.\n");
+        abort();
+    }
+    Slot* sl = acquire_slot();
+    DevCtx* dc = g_dev[0];
+    for (auto* d : g_dev) if (d->dev == sl->dev) dc = d;
+    upload_seeds(sl, seeds, num_seeds);
+    CoreArgs ca = {rev ? dc->query_rc[buffer].codes : dc->query[buffer].codes, g_query_len[buffer], 0, 0, 0, 0};  // :762-767
+    size_t n = saf_core(dc, sl, (uint32_t)num_seeds, ca, out);
+    release_slot(sl);
+    return n;
+}
+
+size_t sa_seed_and_filter_range(uint32_t start, uint32_t end, int rev, uint32_t buffer, sa_segment_pair** out) {
+    require_init("SeedAndFilterRange");
+    Slot* sl = acquire_slot();
+    DevCtx* dc = g_dev[0];
+    for (auto* d : g_dev) if (d->dev == sl->dev) dc = d;
+    const uint8_t* q = rev ? dc->query_rc[buffer].codes : dc->query[buffer].codes;
+    uint32_t qlen = g_query_len[buffer];
+    // a seed window must lie inside the block: positions j with j + span <= len
+    uint32_t lim = qlen >= g_seed_size ? qlen - g_seed_size + 1 : 0;
+    if (end > lim) end = lim;
+    uint32_t ns = device_seeds(sl, q, start, end);
+    size_t n = 0;
+    *out = nullptr;
+    if (ns > 0) {  // seeder.cpp:76: the engine is only called for a non-empty seed vector
+        CoreArgs ca = {q, qlen, 0, 0, 0, 0};
+        n = saf_core(dc, sl, ns, ca, out);
+    } else {
+        prof_flush(sl);
+        memset(&t_stats, 0, sizeof(t_stats));
+    }
+    release_slot(sl);
+    return n;
+}
+
+void sa_free_segments(sa_segment_pair* p) { free(p); }
+
+size_t sa_device_make_seeds(uint32_t start, uint32_t end, int rev, uint32_t buffer, uint64_t* dst, size_t cap) {
+    require_init("DeviceMakeSeeds");
+    Slot* sl = acquire_slot();
+    DevCtx* dc = g_dev[0];
+    for (auto* d : g_dev) if (d->dev == sl->dev) dc = d;
+    const uint8_t* q = rev ? dc->query_rc[buffer].codes : dc->query[buffer].codes;
+    uint32_t qlen = g_query_len[buffer];
+    uint32_t lim = qlen >= g_seed_size ? qlen - g_seed_size + 1 : 0;
+    if (end > lim) end = lim;
+    uint32_t ns = device_seeds(sl, q, start, end);
+    size_t ncopy = std::min<size_t>(ns, cap);
+    if (ncopy) {
+        check_memcpy(hipMemcpyAsync(dst, sl->seeds.p, ncopy * sizeof(uint64_t), hipMemcpyDeviceToHost, sl->stream), "seeds d2h");
+        check_sync(sl->stream, "seeds d2h");
+    }
+    prof_flush(sl);
+    release_slot(sl);
+    return ns;
+}
+
+// ---- repeat masker --------------------------------------------------------------------------------------------------
+void sa_rm_send_query_write_request(void) {  // rm :951-961
+    require_init("SendQueryWriteRequest");
+    for (auto* dc : g_dev) {
+        check_set_device(dc->dev, "SendQueryWriteRequest");
+        dc->ref_rc.create(dc->ref.len, "seq_rc", dc->admin);
+        launch_rev_comp_codes(dc->ref.codes, dc->ref_rc.codes, dc->ref.len, dc->admin);
+        check_launch("rev_comp_string");
+        check_sync(dc->admin, "SendQueryWriteRequest");
+    }
+}
+void sa_rm_clear_query(void) {  // rm :964-972
+    for (auto* dc : g_dev) {
+        check_set_device(dc->dev, "ClearQuery");
+        dc->ref_rc.release("d_seq_rc");
+    }
+}
+size_t sa_rm_seed_and_filter(const uint64_t* seeds, size_t num_seeds, int rev, uint32_t ref_start, uint32_t ref_end,
+                             sa_segment_pair** out) {  // rm :724-876
+    require_init("SeedAndFilter");
+    if ((int64_t)num_seeds > g_max_seeds) {
+        printf("MAX_SEEDS exceeded\n");
+        fprintf(stderr, "Assertion `num_seeds <= MAX_SEEDS' failed.\n");
+        abort();
+    }
+    Slot* sl = acquire_slot();
+    DevCtx* dc = g_dev[0];
+    for (auto* d : g_dev) if (d->dev == sl->dev) dc = d;
+    upload_seeds(sl, seeds, num_seeds);
+    CoreArgs ca = {rev ? dc->ref_rc.codes : dc->ref.codes, dc->ref.len, 1, rev ? 1 : 0, ref_start, ref_end};  // rm :805-810
+    size_t n = saf_core(dc, sl, (uint32_t)num_seeds, ca, out);
+    release_slot(sl);
+    return n;
+}
+
+// ---- knobs ----------------------------------------------------------------------------------------------------------
+void sa_set_max_hits(int64_t max_hits) {
+    if (max_hits <= 0) {
+        g_max_hits_overridden = false;
+        if (g_ndev > 0) g_max_hits = max_hits_for_mem(g_dev[0]->total_mem);
+    } else {
+        g_max_hits = max_hits;
+        g_max_hits_overridden = true;
+    }
+}
+int64_t sa_get_max_hits(void) { return g_max_hits; }
+int sa_max_hits_for_mem(uint64_t total_global_mem) { return max_hits_for_mem(total_global_mem); }
+
+// ---- introspection --------------------------------------------------------------------------------------------------
+void sa_get_last_call_stats(sa_call_stats* o) { *o = t_stats; }
+void sa_set_count_examined(int on) { g_count_examined = on != 0; }
+void sa_profile_enable(int on) { g_prof_on = on != 0; }
+void sa_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& e : g_prof) { e.total_ms = 0; e.launches = 0; }
+}
+int sa_profile_num_entries(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    return (int)g_prof.size();
+}
+int sa_profile_get(int i, char* name_buf, size_t name_cap, double* total_ms, uint64_t* launches) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (i < 0 || i >= (int)g_prof.size()) return -1;
+    if (name_buf && name_cap) {
+        strncpy(name_buf, g_prof[i].name.c_str(), name_cap - 1);
+        name_buf[name_cap - 1] = '\0';
+    }
+    if (total_ms) *total_ms = g_prof[i].total_ms;
+    if (launches) *launches = g_prof[i].launches;
+    return 0;
+}
+
+uint32_t sa_get_ref_len(void) { return g_ndev ? g_dev[0]->ref.len : 0; }
+uint32_t sa_get_num_index(void) { return g_ndev ? g_dev[0]->num_index : 0; }
+uint32_t sa_get_index_table_size(void) { return g_ndev ? g_dev[0]->nkeys : 0; }
+uint32_t sa_get_query_len(uint32_t buffer) { return buffer < SA_BUFFER_DEPTH ? g_query_len[buffer] : 0; }
+
+static DevCtx* ctx_of(int dev) {
+    if (dev < 0 || dev >= g_ndev) {
+        fprintf(stderr, "Error: device %d out of range\n", dev);
+        exit(11);
+    }
+    check_set_device(g_dev[dev]->dev, "copy");
+    return g_dev[dev];
+}
+void sa_copy_ref_codes(int dev, uint8_t* dst) {
+    DevCtx* dc = ctx_of(dev);
+    check_memcpy(hipMemcpy(dst, dc->ref.codes, dc->ref.len, hipMemcpyDeviceToHost), "ref codes");
+}
+void sa_copy_index_table(int dev, uint32_t* dst) {
+    DevCtx* dc = ctx_of(dev);
+    check_memcpy(hipMemcpy(dst, dc->bucket_start + 1, (size_t)dc->nkeys * sizeof(uint32_t), hipMemcpyDeviceToHost), "index table");
+}
+void sa_copy_pos_table(int dev, uint32_t* dst) {
+    DevCtx* dc = ctx_of(dev);
+    check_memcpy(hipMemcpy(dst, dc->pos_table, (size_t)dc->num_index * sizeof(uint32_t), hipMemcpyDeviceToHost), "pos table");
+}
+void sa_copy_query_codes(int dev, uint32_t buffer, int rev, uint8_t* dst) {
+    DevCtx* dc = ctx_of(dev);
+    SeqBuf& b = rev ? dc->query_rc[buffer] : dc->query[buffer];
+    check_memcpy(hipMemcpy(dst, b.codes, b.len, hipMemcpyDeviceToHost), "query codes");
+}
+
+}  // extern "C"

@@ -1,0 +1,113 @@
+// kernels.h -- launcher declarations of the gfx950 kernels of the seed -> filter -> extend engine.
+// Every launcher enqueues on the given HIP stream and returns; none allocates or synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sa {
+
+// Sequences live in HBM as one code byte per base (A0 C1 G2 T3 L4 N5 X6 E7, common/parameters.h:4-13) inside
+// an allocation padded by SEQ_PAD bytes on both sides, so the 8-byte window loads of the extension kernel may
+// over-read without faulting (the over-read bytes are never scored: every position is bounds-checked).
+constexpr int SEQ_PAD = 64;
+
+constexpr int MAX_CARE = 16;  // seed weight limit; reference asserts 3 < kmer_size <= 15 (seed_pos_table.cu:51-52)
+constexpr int MAX_SEGS = 8;   // reference iterations handled by one extension batch
+
+struct SeedShape {            // device copy of the state GenerateShapePos keeps (ntcoding.cpp:6-8)
+    int weight;               // # care positions (kmer_size)
+    int span;                 // seed_size (19 for 12of19)
+    uint32_t transition_mask; // bit t set <=> IsTransitionAtPos(t) (flag of the t-th care position in shape order,
+                              // ntcoding.cpp:21-37); the seeder applies it as key ^ (2 << 2t) (seeder.cpp:65-68, H10)
+    uint8_t pos[MAX_CARE];    // care offsets inside the span, in shape order (first = most significant 2 bits)
+};
+
+struct Hit {                  // 8 B form of the reference's 16 B hit record (len/score are always 0 there)
+    uint32_t ref_loc;         // bucket position + seed_size (seed_filter.cu:220)
+    uint32_t query_loc;       // query position + seed_size (seed_filter.cu:204)
+};
+
+struct HspRec {               // survivor: reference segmentPair + the reference iteration it belongs to
+    uint32_t ref_start;
+    uint32_t query_start;
+    uint32_t len;
+    int32_t score;
+    uint32_t seg;
+};
+
+struct ExtendArgs {
+    const uint8_t* ref;       // encoded target (points past the front pad)
+    const uint8_t* query;     // encoded query, fwd or rc
+    uint32_t ref_len;
+    uint32_t query_len;
+    const int* sub_mat;       // 64 ints in HBM
+    int xdrop;
+    int hspthresh;
+    int noentropy;
+    const Hit* hits;
+    uint64_t num_hits;
+    uint64_t hit_base;        // global index of hits[0] inside the call (segment boundaries are global)
+    int num_segs;
+    uint64_t seg_end[MAX_SEGS]; // exclusive global hit index where segment s ends
+    uint32_t seg_base;        // segment id of the first segment of this batch
+    HspRec* out;              // survivors, appended
+    uint32_t out_cap;         // capacity of out[]; the counter keeps counting past it, writes are dropped
+    uint32_t* out_count;      // device counter
+    unsigned long long* examined; // optional (null = do not count)
+    // repeat-masker deltas (repeat_masker_src/seed_filter.cu:239-244, 305-333, 705-708)
+    int rm;
+    uint32_t rm_win_start, rm_win_end;
+    int rm_rev;
+};
+
+// ---- encode.hip ------------------------------------------------------------------------------------------------
+void launch_encode(const uint8_t* ascii, uint8_t* codes, uint32_t len, hipStream_t s);
+void launch_encode_rev_comp(const uint8_t* ascii, uint8_t* codes, uint8_t* codes_rc, uint32_t len, hipStream_t s);
+void launch_rev_comp_codes(const uint8_t* codes, uint8_t* codes_rc, uint32_t len, hipStream_t s);
+
+// ---- scan.hip --------------------------------------------------------------------------------------------------
+// exclusive prefix of n u32 values; out_excl[n] receives the total.  OutT = uint32_t or uint64_t.
+size_t scan_temp_bytes(uint64_t n);
+void launch_exclusive_scan_u32(const uint32_t* in, uint32_t* out_excl, uint64_t n, void* temp, hipStream_t s);
+void launch_exclusive_scan_u64(const uint32_t* in, uint64_t* out_excl, uint64_t n, void* temp, hipStream_t s);
+
+// ---- table.hip -------------------------------------------------------------------------------------------------
+// histogram of valid k-mers of positions start_offset + i*step, i < num_steps  (seed_pos_table.cu:69-81)
+void launch_table_count(const uint8_t* ref, uint32_t num_steps, uint32_t start_offset, uint32_t step, SeedShape sh,
+                        uint32_t* hist, hipStream_t s);
+// scatter positions into buckets (seed_pos_table.cu:89-101); cursor must be zero on entry
+void launch_table_fill(const uint8_t* ref, uint32_t num_steps, uint32_t start_offset, uint32_t step, SeedShape sh,
+                       const uint32_t* bucket_start, uint32_t* cursor, uint32_t* pos_table, hipStream_t s);
+// canonical (ascending) order inside every bucket -- the reference order is atomic arrival order (H7)
+void launch_table_sort_buckets(const uint32_t* bucket_start, uint32_t nkeys, uint32_t* pos_table, hipStream_t s);
+
+// ---- seeds.hip -------------------------------------------------------------------------------------------------
+// device-side seeder: valid flags for query positions [start,end), then ordered emission
+void launch_seed_flags(const uint8_t* query, uint32_t start, uint32_t end, SeedShape sh, uint32_t* flags, hipStream_t s);
+void launch_seed_emit(const uint8_t* query, uint32_t start, uint32_t end, SeedShape sh, int transition,
+                      const uint32_t* flag_prefix_excl, uint64_t* seeds, hipStream_t s);
+// per seed: bucket start + bucket size  (find_num_hits, seed_filter.cu:157-182)
+void launch_seed_lookup(const uint64_t* seeds, uint32_t num_seeds, const uint32_t* bucket_start /*4^k+1*/, uint32_t nkeys,
+                        uint32_t* start_out, uint32_t* count_out, hipStream_t s);
+// load-balanced bucket expansion (find_hits, seed_filter.cu:184-230)
+void launch_expand_hits(const uint64_t* seeds, const uint32_t* start, const uint32_t* count,
+                        const uint64_t* hit_prefix_excl, uint32_t seed_lo, uint32_t seed_hi, uint64_t hit_base,
+                        const uint32_t* pos_table, uint32_t seed_size, Hit* hits, hipStream_t s);
+// iteration plan (lower_bound chain of seed_filter.cu:718-745) computed on the device into *plan
+struct IterPlan;
+void launch_plan(const uint64_t* hit_prefix_excl, uint32_t num_seeds, uint64_t max_hits, int wrap32, IterPlan* plan,
+                 hipStream_t s);
+
+// ---- extend.hip ------------------------------------------------------------------------------------------------
+void launch_extend(const ExtendArgs& a, hipStream_t s);
+
+// ---- dedup.hip -------------------------------------------------------------------------------------------------
+enum SortOrder { ORDER_DIAG = 0, ORDER_LASTZ = 1, ORDER_RM_FIRST = 2, ORDER_RM_DIAG = 3, ORDER_RM_FINAL = 4 };
+size_t sort_temp_bytes(size_t n);
+void launch_sort(const HspRec* in, HspRec* out, size_t n, SortOrder order, void* temp, size_t temp_bytes, hipStream_t s);
+// adjacent-pair unique (thrust::unique_copy on device, hazard H3) within each segment; order preserving.
+// exact = 0: hspEqual of seed_filter.cu:47-52 ; exact = 1: field equality (repeat masker :80-85)
+void launch_unique(const HspRec* in, HspRec* out, uint32_t n, int exact, uint32_t* out_count, hipStream_t s);
+void launch_strip(const HspRec* in, uint32_t n, void* out_segment_pairs, hipStream_t s);
+
+}  // namespace sa

@@ -1,0 +1,272 @@
+"""ctypes binding of libsegalign_hip.so with the reference's own entry-point names.
+
+This is plumbing for tests and bench.py: every function forwards 1:1 to the C-ABI of include/segalign_amd.h
+(which in turn replaces, symbol by symbol, the engine boundary of gsneha26/SegAlign -- see INTEGRATION.md).
+There is NO fallback: if the HIP library is missing or no GPU is present, calls fail loudly.
+
+Reference symbol                       -> here
+  g_InitializeInterface(num_gpu)        -> InitializeInterface        (common/seed_filter_interface.cu:49-80)
+  g_InitializeProcessor(...)            -> InitializeProcessor        (src/seed_filter.cu:830-897)
+  g_SendRefWriteRequest(seq,addr,len)   -> SendRefWriteRequest        (common/seed_filter_interface.cu:82-101)
+  GenerateShapePos(shape)               -> GenerateShapePos           (common/ntcoding.cpp:21-37)
+  GenerateSeedPosTable(...)             -> GenerateSeedPosTable       (common/seed_pos_table.cu:49-109)
+  g_SendQueryWriteRequest(addr,len,buf) -> SendQueryWriteRequest      (src/seed_filter.cu:899-919)
+  g_SeedAndFilter(seeds,rev,buf)        -> SeedAndFilter              (src/seed_filter.cu:682-828)
+  g_ClearRef / g_ClearQuery / g_ShutdownProcessor
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsegalign_hip.so")
+
+SEG_DTYPE = np.dtype([("ref_start", "<u4"), ("query_start", "<u4"), ("len", "<u4"), ("score", "<i4")])
+
+# every symbol include/segalign_amd.h declares (tests check the library exports all of them)
+C_ABI_SYMBOLS = [
+    "sa_select_devices", "sa_initialize_interface", "sa_initialize_processor", "sa_shutdown_processor", "sa_send_ref_write_request",
+    "sa_clear_ref", "sa_generate_shape_pos", "sa_generate_seed_pos_table", "sa_send_query_write_request",
+    "sa_clear_query", "sa_seed_and_filter", "sa_seed_and_filter_range", "sa_free_segments",
+    "sa_rm_send_query_write_request", "sa_rm_clear_query", "sa_rm_seed_and_filter", "sa_set_max_hits",
+    "sa_get_max_hits", "sa_max_hits_for_mem", "sa_get_last_call_stats", "sa_set_count_examined",
+    "sa_profile_enable", "sa_profile_reset", "sa_profile_num_entries", "sa_profile_get", "sa_get_ref_len",
+    "sa_get_num_index", "sa_get_index_table_size", "sa_copy_ref_codes", "sa_copy_index_table", "sa_copy_pos_table",
+    "sa_copy_query_codes", "sa_get_query_len", "sa_device_make_seeds", "sa_version",
+]
+
+
+class CallStats(C.Structure):
+    _fields_ = [("num_seeds", C.c_uint64), ("num_hits", C.c_uint64), ("num_survivors", C.c_uint64),
+                ("num_anchors", C.c_uint64), ("num_examined", C.c_uint64), ("num_iter", C.c_uint32),
+                ("device", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library.  Raises if it has not been built -- there is no CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libsegalign_hip.so is missing (%s). Build it with `python -m segalign_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.sa_initialize_interface.restype = C.c_int
+    L.sa_initialize_interface.argtypes = [C.c_int]
+    L.sa_select_devices.argtypes = [C.POINTER(C.c_int), C.c_int]
+    L.sa_initialize_processor.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.sa_send_ref_write_request.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32]
+    L.sa_generate_shape_pos.restype = C.c_int
+    L.sa_generate_shape_pos.argtypes = [C.c_char_p]
+    L.sa_generate_seed_pos_table.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
+    L.sa_send_query_write_request.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32]
+    L.sa_clear_query.argtypes = [C.c_uint32]
+    L.sa_seed_and_filter.restype = C.c_size_t
+    L.sa_seed_and_filter.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.sa_seed_and_filter_range.restype = C.c_size_t
+    L.sa_seed_and_filter_range.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.sa_free_segments.argtypes = [C.c_void_p]
+    L.sa_rm_seed_and_filter.restype = C.c_size_t
+    L.sa_rm_seed_and_filter.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.sa_set_max_hits.argtypes = [C.c_int64]
+    L.sa_get_max_hits.restype = C.c_int64
+    L.sa_max_hits_for_mem.restype = C.c_int
+    L.sa_max_hits_for_mem.argtypes = [C.c_uint64]
+    L.sa_get_last_call_stats.argtypes = [C.POINTER(CallStats)]
+    L.sa_set_count_examined.argtypes = [C.c_int]
+    L.sa_profile_enable.argtypes = [C.c_int]
+    L.sa_profile_num_entries.restype = C.c_int
+    L.sa_profile_get.restype = C.c_int
+    L.sa_profile_get.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    for f in ("sa_get_ref_len", "sa_get_num_index", "sa_get_index_table_size"):
+        getattr(L, f).restype = C.c_uint32
+    L.sa_get_query_len.restype = C.c_uint32
+    L.sa_get_query_len.argtypes = [C.c_uint32]
+    L.sa_copy_ref_codes.argtypes = [C.c_int, C.c_void_p]
+    L.sa_copy_index_table.argtypes = [C.c_int, C.c_void_p]
+    L.sa_copy_pos_table.argtypes = [C.c_int, C.c_void_p]
+    L.sa_copy_query_codes.argtypes = [C.c_int, C.c_uint32, C.c_int, C.c_void_p]
+    L.sa_device_make_seeds.restype = C.c_size_t
+    L.sa_device_make_seeds.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t]
+    L.sa_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+# ---- the reference surface --------------------------------------------------------------------------------------
+def select_devices(ids):
+    """One process per GPU: make the next InitializeInterface use exactly these HIP device ordinals."""
+    arr = (C.c_int * len(ids))(*ids)
+    lib().sa_select_devices(arr, len(ids))
+
+
+def InitializeInterface(num_gpu=-1):
+    return lib().sa_initialize_interface(num_gpu)
+
+
+def InitializeProcessor(transition, wga_chunk, seed_size, sub_mat, xdrop, hspthresh, noentropy):
+    m = np.ascontiguousarray(sub_mat, dtype=np.int32)
+    assert m.size == 64
+    lib().sa_initialize_processor(int(bool(transition)), wga_chunk, seed_size, m.ctypes.data, xdrop, hspthresh,
+                                  int(bool(noentropy)))
+
+
+def ShutdownProcessor():
+    lib().sa_shutdown_processor()
+
+
+def _as_u8(buf):
+    """ASCII host buffer -> contiguous uint8 ndarray (kept alive by the caller for the duration of the call)."""
+    if isinstance(buf, np.ndarray):
+        return np.ascontiguousarray(buf, dtype=np.uint8)
+    return np.frombuffer(bytes(buf), dtype=np.uint8)
+
+
+def SendRefWriteRequest(seq, addr, length):
+    a = _as_u8(seq)
+    lib().sa_send_ref_write_request(a.ctypes.data, addr, length)
+    return a
+
+
+def ClearRef():
+    lib().sa_clear_ref()
+
+
+def GenerateShapePos(shape):
+    return lib().sa_generate_shape_pos(shape.encode())
+
+
+def GenerateSeedPosTable(ref_str, start_addr, ref_length, step, shape_size, kmer_size):
+    a = _as_u8(ref_str)
+    lib().sa_generate_seed_pos_table(a.ctypes.data, start_addr, ref_length, step, shape_size, kmer_size)
+
+
+def SendQueryWriteRequest(query_buffer, addr, length, buffer):
+    a = _as_u8(query_buffer)
+    lib().sa_send_query_write_request(a.ctypes.data, addr, length, buffer)
+
+
+def ClearQuery(buffer):
+    lib().sa_clear_query(buffer)
+
+
+def _take(n, out):
+    if n == 0 or not out.value:
+        return np.zeros(0, dtype=SEG_DTYPE)
+    buf = (C.c_char * (n * SEG_DTYPE.itemsize)).from_address(out.value)
+    segs = np.frombuffer(buf, dtype=SEG_DTYPE).copy()
+    lib().sa_free_segments(out)
+    return segs
+
+
+def SeedAndFilter(seed_offset_vector, rev, buffer):
+    """-> structured array; element 0 is the header {len = #anchors, score = #hits} (seed_filter.cu:806-809)."""
+    s = np.ascontiguousarray(seed_offset_vector, dtype=np.uint64)
+    out = C.c_void_p()
+    n = lib().sa_seed_and_filter(s.ctypes.data, s.size, int(bool(rev)), buffer, C.byref(out))
+    return _take(n, out)
+
+
+def SeedAndFilterRange(start, end, rev, buffer):
+    """Additive entry: device-side seeding of query positions [start,end). Empty array when the
+    chunk holds no valid seed (the reference would not call the engine then, seeder.cpp:76)."""
+    out = C.c_void_p()
+    n = lib().sa_seed_and_filter_range(start, end, int(bool(rev)), buffer, C.byref(out))
+    return _take(n, out)
+
+
+# ---- repeat masker ----------------------------------------------------------------------------------------------
+def RmSendQueryWriteRequest():
+    lib().sa_rm_send_query_write_request()
+
+
+def RmClearQuery():
+    lib().sa_rm_clear_query()
+
+
+def RmSeedAndFilter(seed_offset_vector, rev, ref_start, ref_end):
+    s = np.ascontiguousarray(seed_offset_vector, dtype=np.uint64)
+    out = C.c_void_p()
+    n = lib().sa_rm_seed_and_filter(s.ctypes.data, s.size, int(bool(rev)), ref_start, ref_end, C.byref(out))
+    return _take(n, out)
+
+
+# ---- knobs / introspection ---------------------------------------------------------------------------------------
+def set_max_hits(v):
+    lib().sa_set_max_hits(v)
+
+
+def get_max_hits():
+    return lib().sa_get_max_hits()
+
+
+def max_hits_for_mem(total_global_mem):
+    return lib().sa_max_hits_for_mem(total_global_mem)
+
+
+def last_call_stats():
+    st = CallStats()
+    lib().sa_get_last_call_stats(C.byref(st))
+    return {k: getattr(st, k) for k, _ in CallStats._fields_}
+
+
+def set_count_examined(on):
+    lib().sa_set_count_examined(int(bool(on)))
+
+
+def profile_enable(on=True):
+    lib().sa_profile_enable(int(bool(on)))
+
+
+def profile_reset():
+    lib().sa_profile_reset()
+
+
+def profile_entries():
+    """{kernel name: (total_ms, launches)} measured with HIP events on the engine's own streams."""
+    out = {}
+    L = lib()
+    for i in range(L.sa_profile_num_entries()):
+        name = C.create_string_buffer(64)
+        ms = C.c_double()
+        n = C.c_uint64()
+        if L.sa_profile_get(i, name, 64, C.byref(ms), C.byref(n)) == 0:
+            out[name.value.decode()] = (ms.value, n.value)
+    return out
+
+
+def copy_ref_codes(dev=0):
+    out = np.empty(lib().sa_get_ref_len(), dtype=np.uint8)
+    lib().sa_copy_ref_codes(dev, out.ctypes.data)
+    return out
+
+
+def copy_index_table(dev=0):
+    out = np.empty(lib().sa_get_index_table_size(), dtype=np.uint32)
+    lib().sa_copy_index_table(dev, out.ctypes.data)
+    return out
+
+
+def copy_pos_table(dev=0):
+    out = np.empty(lib().sa_get_num_index(), dtype=np.uint32)
+    if out.size:
+        lib().sa_copy_pos_table(dev, out.ctypes.data)
+    return out
+
+
+def copy_query_codes(buffer, rev, dev=0):
+    out = np.empty(lib().sa_get_query_len(buffer), dtype=np.uint8)
+    lib().sa_copy_query_codes(dev, buffer, int(bool(rev)), out.ctypes.data)
+    return out
+
+
+def device_make_seeds(start, end, rev, buffer, per=13):
+    cap = max((end - start) * per, 1)
+    out = np.empty(cap, dtype=np.uint64)
+    n = lib().sa_device_make_seeds(start, end, int(bool(rev)), buffer, out.ctypes.data, cap)
+    return out[:min(n, cap)].copy()

@@ -66,12 +66,33 @@ def join_records(records):
     return np.concatenate(parts)
 
 
+_COMP = np.zeros(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGTacgtNn&", b"TGCAtgcaNn&"):
+    _COMP[_a] = _b
+
+
+def reverse_complement(seq):
+    return _COMP[seq[::-1]]
+
+
+def invert_blocks(seq, seed, block=20000, frac=0.3):
+    """Reverse-complement ~frac of the `block`-sized pieces in place (inversions -> minus-strand HSPs)."""
+    rng = np.random.default_rng(seed)
+    out = seq.copy()
+    for s in range(0, out.size - block + 1, block):
+        if rng.random() < frac:
+            out[s:s + block] = reverse_complement(out[s:s + block])
+    return out
+
+
 def make_pair(target_len, seed_t, seed_q, sub_rate=0.08, mask_frac=0.0, records=1, indel_every=0,
-              n_runs=0):
+              n_runs=0, invert_frac=0.3, invert_block=20000):
     """(target_ascii, query_ascii) uint8 arrays."""
     per = target_len // records
     t_recs = [random_dna(per, seed_t + 1000 * i) for i in range(records)]
     q_recs = [mutate(r, seed_q + 1000 * i, sub_rate, indel_every) for i, r in enumerate(t_recs)]
+    if invert_frac > 0:
+        q_recs = [invert_blocks(r, seed_q + 31 + i, invert_block, invert_frac) for i, r in enumerate(q_recs)]
     if mask_frac > 0:
         t_recs = [soft_mask(r, seed_t + 77 + i, mask_frac) for i, r in enumerate(t_recs)]
         q_recs = [soft_mask(r, seed_q + 77 + i, mask_frac) for i, r in enumerate(q_recs)]

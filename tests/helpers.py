@@ -1,0 +1,68 @@
+"""Shared set-up for parity tests: drive the engine and the oracle through the same call sequence
+(src/main.cpp:297-298,613-621,659-661 ; src/seeder.cpp:47-121) on the same synthetic block pair."""
+import numpy as np
+
+SHAPE_12OF19 = "TTT0T00TT00T0T0TTTT"  # src/main.cpp:160-163
+
+
+class Case:
+    """One target block x one query block, default parameters of the reference unless overridden."""
+
+    def __init__(self, target, query, shape=SHAPE_12OF19, step=1, transition=True, xdrop=910, hspthresh=3000,
+                 noentropy=False, chunk=250000, sub_mat=None):
+        self.target = np.ascontiguousarray(target, np.uint8)
+        self.query = np.ascontiguousarray(query, np.uint8)
+        self.shape, self.step, self.transition = shape, step, transition
+        self.xdrop, self.hspthresh, self.noentropy, self.chunk = xdrop, hspthresh, noentropy, chunk
+        self.seed_size = len(shape)
+        self.sub_mat = sub_mat
+
+    # ---- oracle side ---------------------------------------------------------------------------------------
+    def oracle_setup(self, O):
+        self.O = O
+        self.kmer_size = O.generate_shape_pos(self.shape)
+        if self.sub_mat is None:
+            self.sub_mat = O.build_sub_mat(self.xdrop)
+        self.o_ref = O.encode(self.target.tobytes())
+        self.o_q, self.o_qrc = O.encode_rev_comp(self.query.tobytes())
+        self.o_index, self.o_pos = O.generate_seed_pos_table(self.target.tobytes(), 0, self.target.size, self.step,
+                                                             self.seed_size, self.kmer_size)
+        self.query_rc_ascii = np.frombuffer(O.rev_comp_ascii(self.query.tobytes(), 0, self.query.size), dtype=np.uint8)
+        return self
+
+    def host_seeds(self, start, end, rev):
+        """seeder.cpp:57-74 / :94-109."""
+        buf = self.query_rc_ascii if rev else self.query
+        return self.O.make_seeds(buf.tobytes(), 0, start, end, self.seed_size, self.kmer_size, self.transition)
+
+    def oracle_saf(self, seeds, rev, max_hits=1 << 30):
+        q = self.o_qrc if rev else self.o_q
+        return self.O.seed_and_filter(self.o_ref, q, self.o_index, self.o_pos, seeds, self.sub_mat,
+                                      seed_size=self.seed_size, xdrop=self.xdrop, hspthresh=self.hspthresh,
+                                      noentropy=self.noentropy, max_hits=max_hits)
+
+    # ---- engine side (reference call order) ----------------------------------------------------------------
+    def engine_setup(self, E, num_gpu=1):
+        self.E = E
+        E.InitializeInterface(num_gpu)
+        k = E.GenerateShapePos(self.shape)
+        if self.sub_mat is None:
+            raise RuntimeError("call oracle_setup first or pass sub_mat")
+        E.InitializeProcessor(self.transition, self.chunk, self.seed_size, self.sub_mat, self.xdrop, self.hspthresh,
+                              self.noentropy)
+        self._ref_keep = E.SendRefWriteRequest(self.target, 0, self.target.size)
+        E.GenerateSeedPosTable(self._ref_keep, 0, self.target.size, self.step, self.seed_size, k)
+        E.SendQueryWriteRequest(self.query, 0, self.query.size, 0)
+        return self
+
+    def chunks(self):
+        """(start, end) chunk bounds over [0, len - seed_size) like src/main.cpp:383-393 + seeder.cpp:48-51."""
+        end_pos = self.query.size - self.seed_size
+        out = []
+        for i in range(0, max(end_pos, 0), self.chunk):
+            out.append((i, min(i + self.chunk, end_pos)))
+        return out
+
+
+def seg_equal(a, b):
+    return a.shape == b.shape and bool(np.all(a == b))

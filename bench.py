@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""bench.py -- Gbp of query seeded + filtered + extended per second on MI355X.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
+torch.distributed.run with one rank per GPU.  One JSON line on stdout from rank 0.
+
+Workload = BASELINE.json configs[1] (ce11 x cb4, default 12of19 seed, 1 x MI355X).  The real assemblies cannot
+be downloaded here, so the stand-in of BASELINE.md / SURVEY.md 8(d) is generated deterministically: a
+~100 Mbp, 7-record target and a query that is an 8 %-diverged copy with 20 % soft-masked runs and inversions.
+A *step* is one 10 Mbp query interval (the reference's lastz_interval, src/graph.h:11) on BOTH strands against
+the resident target: 40 + 40 SeedAndFilter calls of 250 kbp (DEFAULT_WGA_CHUNK), seeds generated on the device
+ so the whole "seeded + filtered + extended" metric is inside the timed region and no seed vector
+crosses PCIe.  Target upload, encoding and the seed-table build happen before the timed region (reported
+separately, as the reference does under --debug, src/main.cpp:617-629).
+
+Multi-GPU: query intervals are independent shards: rank r takes intervals r, r+N, ...; every rank
+holds the target + table; there is NO data-path collective.  Per-GPU work is fixed => "scaling": "weak".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SHAPE = "TTT0T00TT00T0T0TTTT"  # 12of19, src/main.cpp:160-163
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--target-mbp", type=float, default=100.0, help="synthetic target size (ce11 ~ 100.3 Mbp)")
+    ap.add_argument("--interval", type=int, default=10_000_000)
+    ap.add_argument("--chunk", type=int, default=250_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU baseline budget")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world != 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    from segalign_amd import engine as E
+    from segalign_amd import synth
+
+    # ---------------- workload: ce11 x cb4 stand-in ----------------
+    t_gen0 = time.time()
+    tlen = int(args.target_mbp * 1e6)
+    target, query = synth.make_pair(tlen, 3, 4, sub_rate=0.08, mask_frac=0.2, records=7, indel_every=0,
+                                    invert_frac=0.3, invert_block=100_000)
+    t_gen = time.time() - t_gen0
+
+    # default parameters of the reference (src/main.cpp:61-124)
+    xdrop, hspthresh, seed_size = 910, 3000, len(SHAPE)
+    sub_mat = default_sub_mat(xdrop)
+
+    E.select_devices([local_rank])
+    E.InitializeInterface(1)
+    kmer = E.GenerateShapePos(SHAPE)
+    E.InitializeProcessor(True, args.chunk, seed_size, sub_mat, xdrop, hspthresh, False)
+    t0 = time.time()
+    keep = E.SendRefWriteRequest(target, 0, target.size)
+    t_ref = time.time() - t0
+    t0 = time.time()
+    E.GenerateSeedPosTable(keep, 0, target.size, 1, seed_size, kmer)
+    t_table = time.time() - t0
+    t0 = time.time()
+    E.SendQueryWriteRequest(query, 0, query.size, 0)
+    t_query = time.time() - t0
+
+    # intervals like src/main.cpp:383-393 over [0, len - seed_size)
+    end_pos = query.size - seed_size
+    intervals = [(s, min(s + args.interval, end_pos)) for s in range(0, end_pos, args.interval)]
+    q_block_len = end_pos  # q_len handed to the seeder (main.cpp:708)
+
+    def run_interval(iv, collect=None):
+        s, e = iv
+        bases = e - s
+        hsps = 0
+        for rev in (False, True):
+            if rev:  # rc coordinates, seeder.cpp:33-34
+                a, b = q_block_len - e, q_block_len - s
+            else:
+                a, b = s, e
+            for c in range(a, b, args.chunk):
+                out = E.SeedAndFilterRange(c, min(c + args.chunk, b), rev, 0)
+                if out.size:
+                    hsps += out.size - 1
+                if collect is not None:
+                    collect.append(E.last_call_stats())
+        return bases, hsps
+
+    my = [intervals[i] for i in range(rank, len(intervals), world)] or intervals
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---------------- warmup (untimed) ----------------
+    for w in range(args.warmup):
+        run_interval(my[w % len(my)])
+
+    # ---------------- timed region ----------------
+    E.profile_reset()
+    E.profile_enable(True)
+    call_stats = []
+    barrier()
+    t0 = time.perf_counter()
+    bases = 0
+    hsps = 0
+    for k in range(args.steps):
+        b, h = run_interval(my[k % len(my)], call_stats)
+        bases += b
+        hsps += h
+    barrier()
+    elapsed = time.perf_counter() - t0
+    E.profile_enable(False)
+    prof = E.profile_entries()
+
+    # max over ranks, sum of bases
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        tb = torch.tensor([bases, hsps], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        bases, hsps = int(tb[0].item()), int(tb[1].item())
+
+    # ---------------- roofline of the dominant kernel (rank 0's own launches) ----------------
+    roof = None
+    if rank == 0 and prof:
+        # E per hit from one instrumented (untimed) interval: deterministic, identical work
+        E.set_count_examined(True)
+        sample_stats = []
+        run_interval(my[0], sample_stats)
+        E.set_count_examined(False)
+        sH = sum(s["num_hits"] for s in sample_stats)
+        sE = sum(s["num_examined"] for s in sample_stats)
+        e_per_hit = sE / max(sH, 1)
+        H = sum(s["num_hits"] for s in call_stats)
+        A = sum(s["num_survivors"] for s in call_stats)
+        S = sum(s["num_seeds"] for s in call_stats)
+        dom = max(prof.items(), key=lambda kv: kv[1][0])
+        name, (ms, launches) = dom
+        kernels = {k: {"ms_total": round(v[0], 3), "launches": v[1], "avg_us": round(1e3 * v[0] / max(v[1], 1), 2)}
+                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+        # algorithmic bytes (SURVEY 8d / DESIGN.md): extension 8H + 2E + 20A ; lookup+expand 16S + 12H
+        ext_bytes = 8.0 * H + 2.0 * e_per_hit * H + 20.0 * A
+        look_bytes = 16.0 * S + 12.0 * H
+        def gbs(nbytes, key):
+            v = prof.get(key)
+            return (nbytes / (v[0] * 1e-3) / 1e9) if v and v[0] > 0 else None
+        ext_gbs = gbs(ext_bytes, "extend_hits")
+        look_ms = sum(prof[k][0] for k in ("seed_lookup", "expand_hits") if k in prof)
+        look_gbs = look_bytes / (look_ms * 1e-3) / 1e9 if look_ms > 0 else None
+        achieved = ext_gbs if name == "extend_hits" else (look_gbs if name in ("seed_lookup", "expand_hits") else None)
+        roof = {
+            "bound": "hbm", "kernel": name, "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
+            "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
+            "algorithmic_bytes_per_launch": round(ext_bytes / max(prof.get("extend_hits", (0, 1))[1], 1)),
+            "per_hit": {"examined_bases": round(e_per_hit, 2), "survivor_frac": round(A / max(H, 1), 5)},
+            "lookup_expand": {"achieved": round(look_gbs, 1) if look_gbs else None,
+                              "frac": round(look_gbs / HBM_PEAK_GBS, 4) if look_gbs else None,
+                              "bytes": "16*S + 12*H"},
+            "kernels": kernels,
+        }
+
+    # ---------------- CPU baseline (rank 0, N == 1 only, bounded sample) ----------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(E, target, query, sub_mat, seed_size, kmer, args, xdrop, hspthresh)
+
+    if rank == 0:
+        value = bases / elapsed / 1e9
+        line = {
+            "metric": "Gbp query seeded+filtered+extended per sec", "value": round(value, 5), "unit": "Gbp/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "ce11 x cb4 stand-in (BASELINE configs[1]): %.0f Mbp 7-record target x 8%%-diverged "
+                                   "soft-masked query, 12of19 + transitions, HOXD70, xdrop 910, hspthresh 3000; "
+                                   "step = one %d bp query interval, both strands, %d bp chunks, device-side seeding"
+                                   % (args.target_mbp, args.interval, args.chunk),
+                       "parallelism": "query-interval shards x%d, no collective" % world,
+                       "hsps_per_step": hsps // max(args.steps * world, 1)},
+            "setup_s": {"generate": round(t_gen, 2), "target_upload_encode": round(t_ref, 3),
+                        "seed_table_build": round(t_table, 3), "query_upload_encode": round(t_query, 3)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+        sys.stdout.flush()
+    E.ShutdownProcessor()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def default_sub_mat(xdrop):
+    """HOXD70 + L/N/X/E rows exactly as src/main.cpp:187-268 builds them for the default --ambiguous=x."""
+    m = np.zeros((8, 8), dtype=np.int32)
+    m[:4, :4] = [[91, -114, -31, -123], [-114, 100, -125, -31], [-31, -125, 100, -114], [-123, -31, -114, 91]]
+    m[:4, 4] = m[4, :4] = -1000; m[4, 4] = -1000          # lower case (L)
+    m[:5, 5] = m[5, :5] = -1000; m[5, 5] = -1000          # N
+    m[:4, 6] = m[6, :4] = -100; m[4:6, 6] = m[6, 4:6] = -1000; m[6, 6] = -100  # X
+    m[:, 7] = m[7, :] = -10 * xdrop                       # E ('&')
+    return m.reshape(64)
+
+
+def cpu_baseline(E, target, query, sub_mat, seed_size, kmer, args, xdrop, hspthresh):
+    """The oracle (a port: the reference cannot be compiled here and LASTZ is absent) timed on the host cores on a
+    bounded sample of the SAME workload: whole 250 kbp chunks, both strands, until ~cpu_seconds have been spent.
+    The seed table is copied from the device (it is parity-tested; building it on one CPU core takes longer than
+    the whole budget) -- table build is outside the metric on both sides."""
+    from oracle import oracle as O
+    O.build(with_ref=False)
+    cores = os.cpu_count() or 1
+    O.generate_shape_pos(SHAPE)
+    index = E.copy_index_table()
+    pos = E.copy_pos_table()
+    ref_codes = E.copy_ref_codes()
+    q_codes = E.copy_query_codes(0, False)
+    qrc_codes = E.copy_query_codes(0, True)
+    qb = query.tobytes()
+    qrc = O.rev_comp_ascii(qb, 0, query.size)
+    done_bases, spent, chunks = 0, 0.0, 0
+    end_pos = query.size - seed_size
+    c = 0
+    while spent < args.cpu_seconds and c < end_pos:
+        e = min(c + args.chunk, end_pos)
+        t0 = time.perf_counter()
+        for rev, buf, codes in ((False, qb, q_codes), (True, qrc, qrc_codes)):
+            a, b = (c, e) if not rev else (end_pos - e, end_pos - c)
+            seeds = O.make_seeds(buf, 0, a, b, seed_size, kmer, True)
+            O.seed_and_filter(ref_codes, codes, index, pos, seeds, sub_mat, seed_size=seed_size, xdrop=xdrop,
+                              hspthresh=hspthresh, noentropy=False, num_threads=cores)
+        spent += time.perf_counter() - t0
+        done_bases += e - c
+        chunks += 1
+        c = e
+    return {"value": round(done_bases / spent / 1e9, 6), "unit": "Gbp/s", "cores": cores, "kind": "port",
+            "sample": "%d x %d bp query chunks, both strands, vs the full target (%.1f s CPU wall); host seeding loop + "
+                      "OpenMP extension of oracle/segalign_oracle.c" % (chunks, args.chunk, spent)}
+
+
+if __name__ == "__main__":
+    main()

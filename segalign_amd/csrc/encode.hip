@@ -64,6 +64,22 @@ __global__ __launch_bounds__(256) void rev_comp_codes_kernel(const uint8_t* __re
     }
 }
 
+// out[i] = codes[i] << 3 : the extension kernel ORs this with the query codes to get the matrix index r*8+q
+__global__ __launch_bounds__(256) void row_code_kernel(const uint8_t* __restrict__ codes, uint8_t* __restrict__ out,
+                                                       uint32_t len) {
+    const uint32_t nvec = len / 16;
+    const uint4* in4 = reinterpret_cast<const uint4*>(codes);
+    uint4* out4 = reinterpret_cast<uint4*>(out);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += gridDim.x * blockDim.x) {
+        uint4 v = in4[i];
+        v.x = (v.x << 3) & 0x38383838u; v.y = (v.y << 3) & 0x38383838u;
+        v.z = (v.z << 3) & 0x38383838u; v.w = (v.w << 3) & 0x38383838u;
+        out4[i] = v;
+    }
+    if (blockIdx.x == 0)
+        for (uint32_t i = nvec * 16 + threadIdx.x; i < len; i += blockDim.x) out[i] = (uint8_t)(codes[i] << 3);
+}
+
 static inline int grid_for(uint64_t work_items, int block, int max_blocks = 256 * 8) {
     uint64_t g = (work_items + block - 1) / block;
     if (g < 1) g = 1;
@@ -78,6 +94,10 @@ void launch_encode(const uint8_t* ascii, uint8_t* codes, uint32_t len, hipStream
 void launch_rev_comp_codes(const uint8_t* codes, uint8_t* codes_rc, uint32_t len, hipStream_t s) {
     if (len == 0) return;
     hipLaunchKernelGGL(rev_comp_codes_kernel, dim3(grid_for((len + 3) / 4, 256)), dim3(256), 0, s, codes, codes_rc, len);
+}
+void launch_row_code(const uint8_t* codes, uint8_t* out, uint32_t len, hipStream_t s) {
+    if (len == 0) return;
+    hipLaunchKernelGGL(row_code_kernel, dim3(grid_for(len / 16 + 1, 256)), dim3(256), 0, s, codes, out, len);
 }
 void launch_encode_rev_comp(const uint8_t* ascii, uint8_t* codes, uint8_t* codes_rc, uint32_t len, hipStream_t s) {
     // two streaming passes: the second reads the freshly written codes (L2 / Infinity Cache resident)

@@ -177,6 +177,7 @@ struct DevCtx {
     size_t total_mem = 0;
     int* d_sub_mat = nullptr;
     SeqBuf ref;
+    SeqBuf ref8;                         // row-coded copy (code << 3) read by the extension kernel
     const char* ref_host_ptr = nullptr;  // identity of the block last sent (to skip a second upload for the table)
     SeqBuf ref_rc;                       // repeat masker
     uint32_t* bucket_start = nullptr;    // 4^k + 1
@@ -204,6 +205,8 @@ static int64_t g_max_seeds = 0;
 static int64_t g_max_hits = 0;
 static bool g_max_hits_overridden = false;
 static bool g_count_examined = false;
+static int g_fin_batch = 16;      // SEGALIGN_AMD_FIN_BATCH
+static int g_bufs_per_wave = 8;   // SEGALIGN_AMD_BUFS_PER_WAVE
 static SeedShape g_shape = {0, 0, 0, {0}};
 static uint32_t g_query_len[SA_BUFFER_DEPTH] = {0, 0};
 
@@ -391,7 +394,9 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     launch_expand_hits(sl->seeds.p, sl->start.p, sl->count.p, sl->prefix.p, (uint32_t)b_seed_lo,
                                        (uint32_t)b_seed_hi, b_hit_lo, dc->pos_table, g_seed_size, sl->hits.p, st);
                 }
-                ea.ref = dc->ref.codes;
+                ea.ref8 = dc->ref8.codes;
+                ea.fin_batch = g_fin_batch;
+                ea.bufs_per_wave = g_bufs_per_wave;
                 ea.query = ca.query;
                 ea.ref_len = dc->ref.len;
                 ea.query_len = ca.query_len;
@@ -623,6 +628,12 @@ int sa_initialize_interface(int num_gpu) {  // seed_filter_interface.cu:49-80
 void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_size, const int* sub_mat, int xdrop,
                              int hspthresh, int noentropy) {  // src/seed_filter.cu:830-897
     require_init("InitializeProcessor");
+    if (const char* e = getenv("SEGALIGN_AMD_FIN_BATCH")) g_fin_batch = std::max(1, std::min(64, atoi(e)));
+    if (const char* e = getenv("SEGALIGN_AMD_BUFS_PER_WAVE")) g_bufs_per_wave = std::max(1, atoi(e));
+    if (xdrop >= (1 << 27) || xdrop <= -(1 << 27)) {
+        fprintf(stderr, "Error: |xdrop| must be below 2^27\n");
+        exit(1);
+    }
     g_transition = transition ? 1 : 0;
     g_wga_chunk = wga_chunk;
     g_max_seeds = transition ? 13ll * wga_chunk : (int64_t)wga_chunk;  // :836-839
@@ -656,6 +667,7 @@ void sa_shutdown_processor(void) {  // src/seed_filter.cu:932-940
         hipDeviceSynchronize();
         for (int k = 0; k < SLOTS_PER_DEVICE; k++) slot_destroy(dc->slots[k]);
         dc->ref.release("d_ref_seq");
+        dc->ref8.release("d_ref_seq rows");
         dc->ref_rc.release("d_seq_rc");
         dev_free(dc->bucket_start, "d_index_table");
         dev_free(dc->pos_table, "d_pos_table");
@@ -684,6 +696,8 @@ void sa_send_ref_write_request(const char* seq, size_t addr, uint32_t len) {  //
         check_memcpy(hipMemcpyAsync(tmp, seq + addr, len, hipMemcpyHostToDevice, dc->admin), "ref_seq");
         dc->ref.create(len, "ref_seq", dc->admin);
         launch_encode(tmp, dc->ref.codes, len, dc->admin);
+        dc->ref8.create(len, "ref_seq rows", dc->admin);
+        launch_row_code(dc->ref.codes, dc->ref8.codes, len, dc->admin);
         check_launch("compress_string");
         check_sync(dc->admin, "SendRefWriteRequest");
         dev_free(tmp, "d_ref_seq_tmp");
@@ -695,6 +709,7 @@ void sa_clear_ref(void) {  // seed_filter_interface.cu:103-113
     for (auto* dc : g_dev) {
         check_set_device(dc->dev, "ClearRef");
         dc->ref.release("d_ref_seq");
+        dc->ref8.release("d_ref_seq rows");
         dc->ref_host_ptr = nullptr;
         dev_free(dc->bucket_start, "d_index_table");
         dev_free(dc->pos_table, "d_pos_table");

@@ -36,7 +36,7 @@ struct HspRec {               // survivor: reference segmentPair + the reference
 };
 
 struct ExtendArgs {
-    const uint8_t* ref;       // encoded target (points past the front pad)
+    const uint8_t* ref8;      // ROW-CODED target: byte = code << 3 (points past the front pad)
     const uint8_t* query;     // encoded query, fwd or rc
     uint32_t ref_len;
     uint32_t query_len;
@@ -44,6 +44,8 @@ struct ExtendArgs {
     int xdrop;
     int hspthresh;
     int noentropy;
+    int fin_batch;            // finished lanes a wave accumulates before it finalises + refills them
+    int bufs_per_wave;        // launch heuristic: 64-hit buffers each wave should own at least
     const Hit* hits;
     uint64_t num_hits;
     uint64_t hit_base;        // global index of hits[0] inside the call (segment boundaries are global)
@@ -64,6 +66,8 @@ struct ExtendArgs {
 void launch_encode(const uint8_t* ascii, uint8_t* codes, uint32_t len, hipStream_t s);
 void launch_encode_rev_comp(const uint8_t* ascii, uint8_t* codes, uint8_t* codes_rc, uint32_t len, hipStream_t s);
 void launch_rev_comp_codes(const uint8_t* codes, uint8_t* codes_rc, uint32_t len, hipStream_t s);
+// row-coded copy of the target for the extension kernel: out[i] = codes[i] << 3
+void launch_row_code(const uint8_t* codes, uint8_t* out, uint32_t len, hipStream_t s);
 
 // ---- scan.hip --------------------------------------------------------------------------------------------------
 // exclusive prefix of n u32 values; out_excl[n] receives the total.  OutT = uint32_t or uint64_t.

@@ -144,6 +144,8 @@ struct Counters {  // device-side scalars of one slot
     uint32_t uniq2;
     uint32_t pad;
     unsigned long long examined;
+    uint32_t n_long;  // hits parked for the long kernel (this batch)
+    uint32_t n_ent;   // entropy candidates (this batch)
 };
 
 struct Slot {
@@ -155,6 +157,8 @@ struct Slot {
     DevBuf<uint8_t> scan_temp, sort_temp;
     DevBuf<Hit> hits;
     DevBuf<HspRec> recA, recB;
+    DevBuf<LongRec> long_list;
+    DevBuf<EntRec> ent_list;
     DevBuf<sa_segment_pair> out16;
     IterPlan* d_plan = nullptr;
     Counters* d_cnt = nullptr;
@@ -207,6 +211,7 @@ static bool g_max_hits_overridden = false;
 static bool g_count_examined = false;
 static int g_fin_batch = 16;      // SEGALIGN_AMD_FIN_BATCH
 static int g_bufs_per_wave = 8;   // SEGALIGN_AMD_BUFS_PER_WAVE
+static int g_long_cap = 128;      // SEGALIGN_AMD_LONG_CAP: bases per side before a hit goes to the long kernel
 static SeedShape g_shape = {0, 0, 0, {0}};
 static uint32_t g_query_len[SA_BUFFER_DEPTH] = {0, 0};
 
@@ -294,6 +299,7 @@ static void slot_destroy(Slot& s) {
     s.flag_prefix.release("flag_prefix"); s.prefix.release("prefix"); s.scan_temp.release("scan_temp");
     s.sort_temp.release("sort_temp"); s.hits.release("hits"); s.recA.release("recA"); s.recB.release("recB");
     s.out16.release("out16");
+    s.long_list.release("long list"); s.ent_list.release("entropy list");
     dev_free(s.d_plan, "plan"); dev_free(s.d_cnt, "counters");
     s.d_plan = nullptr; s.d_cnt = nullptr;
     if (s.h_plan) hipHostFree(s.h_plan);
@@ -415,10 +421,24 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                 ea.rm_rev = ca.rm_rev;
                 ea.rm_win_start = ca.rm_win_start;
                 ea.rm_win_end = ca.rm_win_end;
-                const Counters before = *sl->h_cnt;  // counters as of the previous batch (zero for the first)
-                for (;;) {  // rerun the batch with a larger survivor buffer if it overflowed (writes are guarded)
+                ea.long_cap = (uint32_t)g_long_cap;
+                ea.long_count = &sl->d_cnt->n_long;
+                ea.ent_count = &sl->d_cnt->n_ent;
+                ea.long_blocks = 512;  // 2048 waves stride over the parked hits
+                ea.ent_blocks = 64;
+                sl->long_list.ensure((size_t)std::max<uint64_t>(1u << 16, bh / 32), "long list");
+                sl->ent_list.ensure((size_t)std::max<uint64_t>(1u << 16, bh / 32), "entropy list");
+                Counters before = *sl->h_cnt;  // counters as of the previous batch (zero for the first)
+                before.n_long = 0;
+                before.n_ent = 0;
+                check_memcpy(hipMemsetAsync(&sl->d_cnt->n_long, 0, 2 * sizeof(uint32_t), st), "counters");
+                for (;;) {  // rerun the batch with larger lists if one overflowed (device writes are guarded)
                     ea.out = sl->recA.p;
                     ea.out_cap = (uint32_t)std::min<size_t>(sl->recA.cap, 0xFFFFFFFFu);
+                    ea.long_list = sl->long_list.p;
+                    ea.long_cap_recs = (uint32_t)std::min<size_t>(sl->long_list.cap, 0xFFFFFFFFu);
+                    ea.ent_list = sl->ent_list.p;
+                    ea.ent_cap_recs = (uint32_t)std::min<size_t>(sl->ent_list.cap, 0xFFFFFFFFu);
                     {
                         ProfScope p(sl, "extend_hits");
                         launch_extend(ea, st);
@@ -426,9 +446,16 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     check_launch("expand/extend");
                     check_memcpy(hipMemcpyAsync(sl->h_cnt, sl->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st), "counters");
                     check_sync(st, "extend");
-                    if (sl->h_cnt->survivors <= ea.out_cap) break;
-                    const uint32_t need = sl->h_cnt->survivors;
-                    sl->recA.ensure(need, "survivors(grow)", true, st);
+                    const Counters& c = *sl->h_cnt;
+                    if (c.survivors <= ea.out_cap && c.n_long <= ea.long_cap_recs && c.n_ent <= ea.ent_cap_recs) break;
+                    // an overflowing long list also truncates what the later kernels saw: size everything from the
+                    // counts of this attempt (upper bounds for the rerun: survivors <= hits, entropy candidates <= hits)
+                    if (c.n_long > ea.long_cap_recs) sl->long_list.ensure((size_t)c.n_long, "long list(grow)");
+                    if (c.n_ent > ea.ent_cap_recs || c.n_long > ea.long_cap_recs)
+                        sl->ent_list.ensure((size_t)std::min<uint64_t>(bh, (uint64_t)c.n_ent + c.n_long), "entropy list(grow)");
+                    if (c.survivors > ea.out_cap || c.n_long > ea.long_cap_recs)
+                        sl->recA.ensure((size_t)std::min<uint64_t>((uint64_t)before.survivors + bh, (uint64_t)c.survivors + c.n_long + c.n_ent),
+                                        "survivors(grow)", true, st);
                     check_memcpy(hipMemcpy(sl->d_cnt, &before, sizeof(Counters), hipMemcpyHostToDevice), "counter reset");
                 }
                 survivors = sl->h_cnt->survivors;
@@ -630,6 +657,7 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
     require_init("InitializeProcessor");
     if (const char* e = getenv("SEGALIGN_AMD_FIN_BATCH")) g_fin_batch = std::max(1, std::min(64, atoi(e)));
     if (const char* e = getenv("SEGALIGN_AMD_BUFS_PER_WAVE")) g_bufs_per_wave = std::max(1, atoi(e));
+    if (const char* e = getenv("SEGALIGN_AMD_LONG_CAP")) g_long_cap = std::max(0, atoi(e)) & ~7;
     if (xdrop >= (1 << 27) || xdrop <= -(1 << 27)) {
         fprintf(stderr, "Error: |xdrop| must be below 2^27\n");
         exit(1);

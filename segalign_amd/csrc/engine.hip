@@ -144,7 +144,7 @@ struct Counters {  // device-side scalars of one slot
     uint32_t uniq2;
     uint32_t pad;
     unsigned long long examined;
-    uint32_t n_long;  // hits parked for the long kernel (this batch)
+    uint32_t n_long;  // candidates the filter forwarded to the exact kernel (this batch)
     uint32_t n_ent;   // entropy candidates (this batch)
 };
 
@@ -157,7 +157,7 @@ struct Slot {
     DevBuf<uint8_t> scan_temp, sort_temp;
     DevBuf<Hit> hits;
     DevBuf<HspRec> recA, recB;
-    DevBuf<LongRec> long_list;
+    DevBuf<CandRec> cand_list;
     DevBuf<EntRec> ent_list;
     DevBuf<sa_segment_pair> out16;
     IterPlan* d_plan = nullptr;
@@ -209,9 +209,12 @@ static int64_t g_max_seeds = 0;
 static int64_t g_max_hits = 0;
 static bool g_max_hits_overridden = false;
 static bool g_count_examined = false;
-static int g_fin_batch = 16;      // SEGALIGN_AMD_FIN_BATCH
+static int g_fin_batch = 32;      // SEGALIGN_AMD_FIN_BATCH
 static int g_bufs_per_wave = 8;   // SEGALIGN_AMD_BUFS_PER_WAVE
 static int g_long_cap = 128;      // SEGALIGN_AMD_LONG_CAP: bases per side before a hit goes to the long kernel
+static int g_long_blocks = 1792;  // SEGALIGN_AMD_LONG_BLOCKS: grid of the long kernel (4 waves per block)
+static int g_max_waves = 4096;    // SEGALIGN_AMD_MAX_WAVES: waves of the filter kernel (4 per SIMD saturate instruction issue)
+static int g_fast_filter = 0;     // derived in InitializeProcessor: xdrop >= 0 && 7*max(M) <= xdrop
 static SeedShape g_shape = {0, 0, 0, {0}};
 static uint32_t g_query_len[SA_BUFFER_DEPTH] = {0, 0};
 
@@ -299,7 +302,7 @@ static void slot_destroy(Slot& s) {
     s.flag_prefix.release("flag_prefix"); s.prefix.release("prefix"); s.scan_temp.release("scan_temp");
     s.sort_temp.release("sort_temp"); s.hits.release("hits"); s.recA.release("recA"); s.recB.release("recB");
     s.out16.release("out16");
-    s.long_list.release("long list"); s.ent_list.release("entropy list");
+    s.cand_list.release("candidate list"); s.ent_list.release("entropy list");
     dev_free(s.d_plan, "plan"); dev_free(s.d_cnt, "counters");
     s.d_plan = nullptr; s.d_cnt = nullptr;
     if (s.h_plan) hipHostFree(s.h_plan);
@@ -422,11 +425,13 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                 ea.rm_win_start = ca.rm_win_start;
                 ea.rm_win_end = ca.rm_win_end;
                 ea.long_cap = (uint32_t)g_long_cap;
-                ea.long_count = &sl->d_cnt->n_long;
+                ea.cand_count = &sl->d_cnt->n_long;
+                ea.fast_filter = g_fast_filter;
                 ea.ent_count = &sl->d_cnt->n_ent;
-                ea.long_blocks = 512;  // 2048 waves stride over the parked hits
+                ea.long_blocks = (uint32_t)g_long_blocks;
+                ea.max_waves = (uint32_t)g_max_waves;
                 ea.ent_blocks = 64;
-                sl->long_list.ensure((size_t)std::max<uint64_t>(1u << 16, bh / 32), "long list");
+                sl->cand_list.ensure((size_t)std::max<uint64_t>(1u << 16, bh / 16), "candidate list");
                 sl->ent_list.ensure((size_t)std::max<uint64_t>(1u << 16, bh / 32), "entropy list");
                 Counters before = *sl->h_cnt;  // counters as of the previous batch (zero for the first)
                 before.n_long = 0;
@@ -435,8 +440,8 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                 for (;;) {  // rerun the batch with larger lists if one overflowed (device writes are guarded)
                     ea.out = sl->recA.p;
                     ea.out_cap = (uint32_t)std::min<size_t>(sl->recA.cap, 0xFFFFFFFFu);
-                    ea.long_list = sl->long_list.p;
-                    ea.long_cap_recs = (uint32_t)std::min<size_t>(sl->long_list.cap, 0xFFFFFFFFu);
+                    ea.cand_list = sl->cand_list.p;
+                    ea.cand_cap_recs = (uint32_t)std::min<size_t>(sl->cand_list.cap, 0xFFFFFFFFu);
                     ea.ent_list = sl->ent_list.p;
                     ea.ent_cap_recs = (uint32_t)std::min<size_t>(sl->ent_list.cap, 0xFFFFFFFFu);
                     {
@@ -447,13 +452,13 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     check_memcpy(hipMemcpyAsync(sl->h_cnt, sl->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st), "counters");
                     check_sync(st, "extend");
                     const Counters& c = *sl->h_cnt;
-                    if (c.survivors <= ea.out_cap && c.n_long <= ea.long_cap_recs && c.n_ent <= ea.ent_cap_recs) break;
+                    if (c.survivors <= ea.out_cap && c.n_long <= ea.cand_cap_recs && c.n_ent <= ea.ent_cap_recs) break;
                     // an overflowing long list also truncates what the later kernels saw: size everything from the
                     // counts of this attempt (upper bounds for the rerun: survivors <= hits, entropy candidates <= hits)
-                    if (c.n_long > ea.long_cap_recs) sl->long_list.ensure((size_t)c.n_long, "long list(grow)");
-                    if (c.n_ent > ea.ent_cap_recs || c.n_long > ea.long_cap_recs)
+                    if (c.n_long > ea.cand_cap_recs) sl->cand_list.ensure((size_t)c.n_long, "candidate list(grow)");
+                    if (c.n_ent > ea.ent_cap_recs || c.n_long > ea.cand_cap_recs)
                         sl->ent_list.ensure((size_t)std::min<uint64_t>(bh, (uint64_t)c.n_ent + c.n_long), "entropy list(grow)");
-                    if (c.survivors > ea.out_cap || c.n_long > ea.long_cap_recs)
+                    if (c.survivors > ea.out_cap || c.n_long > ea.cand_cap_recs)
                         sl->recA.ensure((size_t)std::min<uint64_t>((uint64_t)before.survivors + bh, (uint64_t)c.survivors + c.n_long + c.n_ent),
                                         "survivors(grow)", true, st);
                     check_memcpy(hipMemcpy(sl->d_cnt, &before, sizeof(Counters), hipMemcpyHostToDevice), "counter reset");
@@ -658,8 +663,10 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
     if (const char* e = getenv("SEGALIGN_AMD_FIN_BATCH")) g_fin_batch = std::max(1, std::min(64, atoi(e)));
     if (const char* e = getenv("SEGALIGN_AMD_BUFS_PER_WAVE")) g_bufs_per_wave = std::max(1, atoi(e));
     if (const char* e = getenv("SEGALIGN_AMD_LONG_CAP")) g_long_cap = std::max(0, atoi(e)) & ~7;
-    if (xdrop >= (1 << 27) || xdrop <= -(1 << 27)) {
-        fprintf(stderr, "Error: |xdrop| must be below 2^27\n");
+    if (const char* e = getenv("SEGALIGN_AMD_LONG_BLOCKS")) g_long_blocks = std::max(1, atoi(e));
+    if (const char* e = getenv("SEGALIGN_AMD_MAX_WAVES")) g_max_waves = std::max(4, atoi(e));
+    if (xdrop >= (1 << 25) || xdrop <= -(1 << 25)) {
+        fprintf(stderr, "Error: |xdrop| must be below 2^25\n");
         exit(1);
     }
     g_transition = transition ? 1 : 0;
@@ -671,6 +678,12 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
     g_xdrop = xdrop;
     g_hspthresh = hspthresh;
     g_noentropy = noentropy ? 1 : 0;
+    {
+        int mx = g_sub_mat[0];
+        for (int i = 1; i < 64; i++) mx = std::max(mx, g_sub_mat[i]);
+        g_fast_filter = (xdrop >= 0 && (int64_t)7 * std::max(mx, 0) <= (int64_t)xdrop) ? 1 : 0;
+        if (getenv("SEGALIGN_AMD_NO_FAST_FILTER")) g_fast_filter = 0;
+    }
     std::lock_guard<std::mutex> lk(g_mu);
     g_tokens.clear();
     for (int g = 0; g < g_ndev; g++) {

@@ -4,44 +4,44 @@
 // Scalar recurrence per side (k = 0,1,.. right of the anchor; k = 1,2,.. left of it), which is what the reference's
 // 32-lane tile loop computes (:326-453 right, :478-604 left) independently of its tile width:
 //     score += M[r][q];  if (max(best,score) - score > xdrop) stop;  if (score > best) { best = score; bestpos = k; }
-// stop also at the first position outside either sequence.
+// stop also at the first position outside either sequence.  A hit survives iff
+// (int)((float)(bestR + bestL) * entropy) >= hspthresh (:633).
 //
-// Design (wave64, CDNA4) -- NOT the reference's shape (one 32-lane warp per hit, four shuffle scans + ~10 syncs
-// per 32 bases, although a random hit dies after ~20-60 bases).  Three kernels:
+// Design (wave64, CDNA4) -- NOT the reference's shape (one 32-lane warp per hit, four shuffle scans + ~10 syncs per
+// 32 bases, although ~98 % of all hits are random and die after ~20-60 bases below the threshold).  Three kernels:
 //
-//  1. extend_main_kernel: ONE LANE OWNS ONE HIT, lanes are PERSISTENT.  Each lane runs a small state machine
-//     (right side -> left side -> finished); every trip of the wave loop advances every live lane by 8 bases.
-//     Finished lanes are finalised in batches and REFILLED from the wave's queue (a register-held, double-buffered
-//     64-hit buffer; buffers are dealt round-robin to the waves of the grid -- no atomics on the fetch side).
-//     A side that is still alive after `long_cap` bases is almost surely real homology and may run for kilobases:
-//     the lane PARKS the hit with its state in the long list and takes new work, so no wave ever waits on one lane.
-//  2. extend_long_kernel: ONE WAVE OWNS ONE PARKED HIT and advances it 512 bases per step with an exact segmented
-//     scan: lane l scores bases [8l, 8l+8) of the window, a wave sum-scan gives every lane its entry score, a wave
+//  1. extend_filter_kernel -- the X-DROP FILTER.  ONE LANE OWNS ONE HIT, lanes are PERSISTENT.  Each lane runs a
+//     small state machine (right side -> left side -> finished) that tracks only the running score and the best score
+//     of the side -- no positions: 4.5 VALU + 1 ds_read_b32 per base.  Every trip of the wave loop advances every
+//     live lane by 8 bases; finished lanes are handled in batches and REFILLED from the wave's queue (a register-held,
+//     double-buffered 64-hit buffer; buffers are dealt round-robin to the waves of the grid, no atomics on the fetch
+//     side).  A hit whose bestR + bestL can pass the threshold, or whose side is still alive after `long_cap` bases
+//     (real homology, may run for kilobases), becomes a CANDIDATE (12-byte record, wave-aggregated append).
+//  2. extend_exact_kernel -- ONE WAVE OWNS ONE CANDIDATE and extends it exactly, 512 bases per step, with a segmented
+//     scan: lane l scores bases [8l, 8l+8) of the window, a DPP wave sum-scan gives every lane its entry score, a DPP
 //     max-scan (ties -> earlier position) its entry best, then each lane REPLAYS its 8 bases with the exact entry
 //     state; the first lane that drops holds the final (best, bestpos).  ~0.25 wave-instructions per base.
-//  3. extend_entropy_kernel: the few hits with hspthresh <= score <= 3*hspthresh (:608) get their fp64 entropy
-//     factor here, one lane per candidate, so the hot kernels carry no fp64 code or registers.
+//  3. extend_entropy_kernel -- the few hits with hspthresh <= score <= 3*hspthresh (:608) get their fp64 entropy
+//     factor here, one lane per hit, so the hot kernels carry no fp64 code or registers.
 //
 // Shared machinery:
 //   * The target is kept in HBM a second time "row coded" (r<<3, one byte per base) so that `rw | qw` of two
 //     8-byte windows IS the 8 matrix indices r*8+q; one unaligned global_load_dwordx2 per sequence per 8 bases.
-//     The left side byte-swaps its window so both directions share the same straight-line code.
+//     The left side reverses its window with the same two v_perm_b32 (per-lane selector) the right side uses.
 //   * The 8x8 matrix sits in LDS as one 128-entry table: entries 64..127 hold a large negative "terminator" that
 //     out-of-range positions are mapped to (bit 6 OR-ed into their index byte), which folds the sequence-edge
 //     test (:332,:482) into the X-drop test.  ACGTxACGT pairs occupy 16 distinct banks: conflict-free.
-//     Address = one SDWA byte-select shift; per base: 1 ds_read_b32 + 7 VALU.
-//   * Once a side has dropped its running score is pinned to DEAD, which makes every later base of the chunk a
-//     no-op without per-base predication; "side finished" is read off the score after the chunk.
-//   * Integer DP only (no MFMA).  Survivors are appended with one atomicAdd per wave per batch (ballot + popcount
-//     prefix).  Append order is arbitrary; the dedup stage sorts on a total order, so the output is deterministic.
+//     Address = one SDWA byte-select shift.
+//   * Integer DP only (no MFMA).  Survivors are appended with wave-aggregated atomics.  Append order is arbitrary;
+//     the dedup stage sorts on a total order, so the output is deterministic.
 #include "kernels.h"
 #include "kmer_dev.h"  // load8u
 
 namespace sa {
 
 constexpr int EXT_THREADS = 256;
-constexpr int NEG = -(1 << 28);   // score of a terminator pair: forces the drop test for any |xdrop| < 2^27
-constexpr int DEAD = -(1 << 29);  // sticky running score of a side that has dropped
+constexpr int NEG = -(1 << 26);   // terminator score: 8 of them still fit an int, one forces the drop test (|xdrop| < 2^25)
+constexpr int DEAD = -(1 << 29);  // sticky running score of a side that has dropped (exact / counting paths)
 constexpr uint64_t TERM_ALL = 0x4040404040404040ull;
 constexpr uint32_t BIAS = SEQ_PAD;  // offsets are kept unsigned: base pointers point at the start of the front pad
 
@@ -49,16 +49,49 @@ __device__ __forceinline__ int f64_to_i32(double x) { return (int)x; }  // v_cvt
 
 enum : int { PH_RIGHT = 0, PH_LEFT = 1, PH_FIN = 2, PH_IDLE = 3 };
 
-// One 8-base chunk of the recurrence on the packed index word x (byte j = matrix index of offset k+j).
+// ---- DPP helpers (row shifts inside 16-lane rows + row broadcasts: the classic 6-step wave64 scan) -----------------
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ int dpp_mov(int old, int v) {
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+    v += (uint32_t)dpp_mov<0x111>(0, (int)v);        // row_shr:1
+    v += (uint32_t)dpp_mov<0x112>(0, (int)v);        // row_shr:2
+    v += (uint32_t)dpp_mov<0x114>(0, (int)v);        // row_shr:4
+    v += (uint32_t)dpp_mov<0x118>(0, (int)v);        // row_shr:8
+    v += (uint32_t)dpp_mov<0x142, 0xa>(0, (int)v);   // row_bcast:15 -> rows 1,3
+    v += (uint32_t)dpp_mov<0x143, 0xc>(0, (int)v);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+// inclusive max-scan of (value, position); ties keep the EARLIER lane's pair (:350 strict ">" + :361-372 ">=")
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void max_step(int& mv, int& mp) {
+    const int tv = dpp_mov<CTRL, ROW_MASK>(INT32_MIN, mv);
+    const int tp = dpp_mov<CTRL, ROW_MASK>(0, mp);
+    const bool take = tv >= mv;
+    mp = take ? tp : mp;
+    mv = take ? tv : mv;
+}
+__device__ __forceinline__ void wave_inclusive_max(int& mv, int& mp) {
+    max_step<0x111, 0xf>(mv, mp);
+    max_step<0x112, 0xf>(mv, mp);
+    max_step<0x114, 0xf>(mv, mp);
+    max_step<0x118, 0xf>(mv, mp);
+    max_step<0x142, 0xa>(mv, mp);
+    max_step<0x143, 0xc>(mv, mp);
+}
+
+// ---- pieces shared by the kernels -------------------------------------------------------------------------------------
+// exact per-base recurrence with positions on the packed index word x (byte j = matrix index of offset k+j)
 template <bool COUNT_EXAMINED, bool XDROP_NONNEG>
-__device__ __forceinline__ void chunk8(const int* __restrict__ s_tab, uint64_t x, uint32_t k, int xdrop, int& score,
-                                       int& best, int& bpos, unsigned long long& examined) {
+__device__ __forceinline__ void chunk8_exact(const int* __restrict__ s_tab, uint64_t x, uint32_t k, int xdrop, int& score,
+                                             int& best, int& bpos, uint32_t& examined) {
     const uint32_t xlo = (uint32_t)x, xhi = (uint32_t)(x >> 32);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const uint32_t w = j < 4 ? xlo : xhi;
         const uint32_t idx = (w >> (8 * (j & 3))) & 0xffu;  // SDWA byte select
-        if (COUNT_EXAMINED) examined += (score > (DEAD >> 1) && idx < 64u) ? 1ull : 0ull;
+        if (COUNT_EXAMINED) examined += (score > (DEAD >> 1) && idx < 64u) ? 1u : 0u;
         const int t = score + s_tab[idx];
         const int nb = max(best, t);
         const bool drop = (nb - t) > xdrop;  // :374 / :523 (also fires on a terminator = sequence edge :332/:482)
@@ -74,20 +107,6 @@ __device__ __forceinline__ void chunk8(const int* __restrict__ s_tab, uint64_t x
     }
 }
 
-// The 8 matrix indices of offsets k..k+7 of one side.  `remaining` = in-range positions from k on (<= 0: none).
-__device__ __forceinline__ uint64_t fetch_indices(const uint8_t* __restrict__ R8b, const uint8_t* __restrict__ Qb,
-                                                  uint32_t ref_loc, uint32_t query_loc, bool left, uint32_t k, int remaining) {
-    uint64_t x = 0;
-    if (remaining > 0) {
-        const uint32_t roff = left ? ref_loc + BIAS - k - 7u : ref_loc + BIAS + k;
-        const uint32_t qoff = left ? query_loc + BIAS - k - 7u : query_loc + BIAS + k;
-        x = load8u(R8b + roff) | load8u(Qb + qoff);
-        if (left) x = __builtin_bswap64(x);  // byte j <-> offset k+j on both sides
-    }
-    if (remaining < 8) x |= (remaining <= 0) ? TERM_ALL : (TERM_ALL << (8 * remaining));
-    return x;
-}
-
 __device__ __forceinline__ uint32_t seg_of(const ExtendArgs& a, uint64_t local_idx) {
     uint32_t seg = 0;
     const uint64_t g = a.hit_base + local_idx;
@@ -97,11 +116,10 @@ __device__ __forceinline__ uint32_t seg_of(const ExtendArgs& a, uint64_t local_i
     return a.seg_base + seg;
 }
 
-// What to do with a finished hit: 0 = reject, 1 = survivor with entropy 1, 2 = entropy candidate (:608,:633)
+// What to do with a finished hit: 0 = reject, 1 = survivor with entropy 1, 2 = needs the entropy factor (:608,:633)
 __device__ __forceinline__ int classify(const ExtendArgs& a, int total) {
     if (!a.noentropy && total >= a.hspthresh && total <= 3 * a.hspthresh) return 2;
-    // entropy stays 1.0: (int)((float)total * 1.0) >= hspthresh
-    return (f64_to_i32((double)(float)total) >= a.hspthresh) ? 1 : 0;
+    return (f64_to_i32((double)(float)total) >= a.hspthresh) ? 1 : 0;  // entropy stays 1.0
 }
 
 __device__ __forceinline__ HspRec make_rec(const ExtendArgs& a, uint32_t ref_loc, uint32_t query_loc, int boffL, int extent,
@@ -117,8 +135,8 @@ __device__ __forceinline__ HspRec make_rec(const ExtendArgs& a, uint32_t ref_loc
     return rec;
 }
 
-// wave-aggregated append of one record per flagged lane; returns nothing (overflowing writes are dropped, the
-// counter keeps counting so that the host can grow the list and rerun the batch)
+// wave-aggregated append of one record per flagged lane (overflowing writes are dropped, the counter keeps counting
+// so that the host can grow the list and rerun the batch)
 template <typename T>
 __device__ __forceinline__ void wave_append(bool flag, const T& rec, T* __restrict__ list, uint32_t* __restrict__ counter,
                                             uint32_t cap, int lane, unsigned long long lane_lt) {
@@ -127,20 +145,62 @@ __device__ __forceinline__ void wave_append(bool flag, const T& rec, T* __restri
         const int leader = __ffsll((long long)m) - 1;
         uint32_t wbase = 0;
         if (lane == leader) wbase = atomicAdd(counter, (uint32_t)__popcll(m));
-        wbase = __shfl(wbase, leader, 64);
+        wbase = (uint32_t)__builtin_amdgcn_readlane((int)wbase, leader);
         const uint32_t slot = wbase + (uint32_t)__popcll(m & lane_lt);
         if (flag && slot < cap) list[slot] = rec;
     }
 }
 
+
+// ---- per-wave LDS staging: records are collected 64 at a time so that one atomicAdd (and one coalesced store) serves
+// 64 appends -- single-address atomics cost ~11 ns each and would otherwise bound these kernels -----------------------
+constexpr int STAGE_CAP = 128;  // records per wave: < 64 pending + <= 64 new
+
+template <typename T>
+__device__ __forceinline__ void stage_flush(const T* __restrict__ stage, int cnt, T* __restrict__ list,
+                                            uint32_t* __restrict__ counter, uint32_t cap, int lane) {
+    if (cnt <= 0) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(counter, (uint32_t)cnt);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < cnt && base + (uint32_t)lane < cap) list[base + (uint32_t)lane] = stage[lane];
+}
+
+// append one record per flagged lane to the wave's stage; flush the first 64 when they are complete.  n is wave-uniform.
+template <typename T>
+__device__ __forceinline__ void stage_append(T* __restrict__ stage, int& n, bool flag, const T& rec, T* __restrict__ list,
+                                             uint32_t* __restrict__ counter, uint32_t cap, int lane, unsigned long long lane_lt) {
+    const unsigned long long m = __ballot(flag);
+    if (m == 0ull) return;
+    if (flag) stage[n + __popcll(m & lane_lt)] = rec;
+    n += __popcll(m);
+    __builtin_amdgcn_wave_barrier();
+    if (n >= 64) {
+        stage_flush(stage, 64, list, counter, cap, lane);
+        const int rest = n - 64;
+        T tmp = rec;
+        if (lane < rest) tmp = stage[64 + lane];
+        __builtin_amdgcn_wave_barrier();
+        if (lane < rest) stage[lane] = tmp;
+        __builtin_amdgcn_wave_barrier();
+        n = rest;
+    }
+}
+
 // =====================================================================================================================
-// 1. main kernel: persistent lanes
+// 1. the X-drop filter: persistent lanes, best scores only
 // =====================================================================================================================
-template <bool COUNT_EXAMINED, bool XDROP_NONNEG>
-__global__ __launch_bounds__(EXT_THREADS) void extend_main_kernel(ExtendArgs a) {
+// FAST: xdrop >= 0 and 7*max(M) <= xdrop, so after a drop the remaining <= 7 bases of the chunk can never lift the
+// score above the best again: no sticky select is needed, "dropped" = max over the chunk of (runmax - score) > xdrop.
+template <bool COUNT_EXAMINED, bool FAST>
+__global__ __launch_bounds__(EXT_THREADS) void extend_filter_kernel(ExtendArgs a) {
     __shared__ int s_tab[128];
+    __shared__ CandRec s_cand[EXT_THREADS / 64][STAGE_CAP];
     if (threadIdx.x < 128) s_tab[threadIdx.x] = threadIdx.x < 64 ? a.sub_mat[threadIdx.x] : NEG;
     __syncthreads();
+    CandRec* stage = s_cand[threadIdx.x >> 6];
+    int n_stage = 0;
 
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
@@ -167,47 +227,79 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_main_kernel(ExtendArgs a) 
 
     // ---- per-lane state ----
     int phase = PH_FIN;  // "finished" with nothing to emit: the first trip refills every lane
-    bool has_hit = false;
+    bool has_hit = false, forward = false;
     uint32_t ref_loc = 0, query_loc = 0, hidx = 0;
-    uint32_t k = 0, lim = 0;
-    int score = 0, best = 0, bpos = 0, bestR = 0, bposR = 0;
+    uint32_t roff = 0, qoff = 0;            // byte offsets (from the padded bases) of the next 8-byte window
+    int dstep = 8;                          // +8 on the right side, -8 on the left
+    uint32_t sel_lo = 0x03020100u, sel_hi = 0x07060504u;  // v_perm selectors: identity (right) / byte reversal (left)
+    int remaining = 0;                      // in-range positions left on this side
+    uint32_t walked = 0;                    // bases walked on this side
+    int score = 0, best = 0, bestR = 0;
+    uint32_t ex_hit = 0;
     unsigned long long examined = 0;
 
     for (;;) {
         // ================= 1. advance every live lane by one 8-base chunk =================
         if (phase < PH_FIN) {
-            const bool left = phase == PH_LEFT;
-            // in-range positions from k on; a live lane always has k <= lim (+1 on the left), so no underflow
-            const uint32_t rem_u = left ? lim - k + 1u : lim - k;
-            const int remaining = (int)min(rem_u, 8u);
-            const uint64_t x = fetch_indices(R8b, Qb, ref_loc, query_loc, left, k, remaining);
-            chunk8<COUNT_EXAMINED, XDROP_NONNEG>(s_tab, x, k, xdrop, score, best, bpos, examined);
-            k += 8;
-            const bool dead = score < (DEAD >> 1);
-            if (dead) {
-                if (!left) {  // -> left side (:457-476): anchor-1, anchor-2, ...
+            uint32_t xlo = 0, xhi = 0;
+            if (remaining > 0) {
+                const uint64_t x = load8u(R8b + roff) | load8u(Qb + qoff);  // 8 matrix indices r<<3|q
+                xlo = __builtin_amdgcn_perm((uint32_t)(x >> 32), (uint32_t)x, sel_lo);  // byte j <-> offset +j on both sides
+                xhi = __builtin_amdgcn_perm((uint32_t)(x >> 32), (uint32_t)x, sel_hi);
+            }
+            if (remaining < 8) {  // sequence edge inside this window: terminators from byte `remaining` on
+                const uint64_t t = remaining <= 0 ? TERM_ALL : (TERM_ALL << (8 * remaining));
+                xlo |= (uint32_t)t;
+                xhi |= (uint32_t)(t >> 32);
+            }
+            bool dropped;
+            if (FAST && !COUNT_EXAMINED) {
+                int t = score, m = best, dmax = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const uint32_t w = j < 4 ? xlo : xhi;
+                    t += s_tab[(w >> (8 * (j & 3))) & 0xffu];
+                    m = max(m, t);
+                    const int d0 = m - t;
+                    t += s_tab[(w >> (8 * ((j + 1) & 3))) & 0xffu];
+                    m = max(m, t);
+                    const int d1 = m - t;
+                    dmax = max(dmax, max(d0, d1));  // v_max3_i32
+                }
+                dropped = dmax > xdrop;  // :374 / :523 ; a terminator (edge :332/:482) always trips it
+                score = t;
+                best = m;  // == best before the drop (see FAST)
+            } else {
+                int dummy = 0;
+                uint32_t ex = 0;
+                const uint64_t x = ((uint64_t)xhi << 32) | xlo;
+                if (xdrop >= 0) chunk8_exact<COUNT_EXAMINED, true>(s_tab, x, 0u, xdrop, score, best, dummy, ex);
+                else chunk8_exact<COUNT_EXAMINED, false>(s_tab, x, 0u, xdrop, score, best, dummy, ex);
+                if (COUNT_EXAMINED) ex_hit += ex;
+                dropped = score < (DEAD >> 1);
+            }
+            roff += (uint32_t)dstep;
+            qoff += (uint32_t)dstep;
+            remaining -= 8;
+            walked += 8;
+            if (dropped) {
+                if (phase == PH_RIGHT) {  // -> left side (:457-476): anchor-1, anchor-2, ...
                     bestR = best;
-                    bposR = bpos;
                     phase = PH_LEFT;
-                    k = 1;
-                    lim = min(ref_loc, query_loc);  // offsets 1..lim are in range (:482)
+                    roff = ref_loc + BIAS - 8u;   // bytes loc-8 .. loc-1 ; reversed: byte 0 <-> offset 1
+                    qoff = query_loc + BIAS - 8u;
+                    dstep = -8;
+                    sel_lo = 0x04050607u;
+                    sel_hi = 0x00010203u;
+                    remaining = (int)min(min(ref_loc, query_loc), 0x7fffffffu);  // offsets 1..lim are in range (:482)
+                    walked = 0;
                     score = 0;
                     best = 0;
-                    bpos = 0;
                 } else {
                     phase = PH_FIN;
                 }
-            }
-        }
-        // ---- park sides that outlived long_cap: hand the hit (with its state) to the long kernel ----
-        {
-            const bool park = phase < PH_FIN && (k - (uint32_t)phase) >= long_cap;
-            LongRec lr;
-            lr.ref_loc = ref_loc; lr.query_loc = query_loc; lr.hidx = hidx; lr.side = (uint32_t)phase; lr.k = k;
-            lr.score = score; lr.best = best; lr.bpos = bpos; lr.bestR = bestR; lr.bposR = bposR;
-            wave_append(park, lr, a.long_list, a.long_count, a.long_cap_recs, lane, lane_lt);
-            if (park) {
-                has_hit = false;  // nothing to finalise here
+            } else if (walked >= long_cap) {  // still alive after long_cap bases: real homology -> exact kernel
+                forward = true;
                 phase = PH_FIN;
             }
         }
@@ -216,24 +308,16 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_main_kernel(ExtendArgs a) 
         const unsigned long long fin = __ballot(phase == PH_FIN);
         const unsigned long long live = __ballot(phase < PH_FIN);
         if (fin != 0ull && (__popcll(fin) >= fin_batch || live == 0ull)) {
-            // ---- score + filter (:608-647) for lanes that hold a finished hit ----
-            int cls = 0;
-            int total = 0, extent = 0;
-            uint32_t seg = 0;
+            // ---- candidates: capped walks, and finished hits whose bestR + bestL can survive (:608-633) ----
+            bool cand = false;
             if (phase == PH_FIN && has_hit) {
-                total = bestR + best;   // best/bpos hold the left side now
-                extent = bposR + bpos;
-                cls = classify(a, total);
-                if (cls) seg = seg_of(a, hidx);
+                cand = forward || classify(a, bestR + best) != 0;
+                if (COUNT_EXAMINED && !cand) examined += ex_hit;  // candidates are re-extended (and counted) by the exact kernel
             }
             {
-                const HspRec rec = make_rec(a, ref_loc, query_loc, bpos, extent, total, seg);  // entropy 1: score = total (:638)
-                wave_append(cls == 1, rec, a.out, a.out_count, a.out_cap, lane, lane_lt);
-            }
-            {
-                EntRec er;
-                er.ref_loc = ref_loc; er.query_loc = query_loc; er.bposR = bposR; er.boffL = bpos; er.total = total; er.seg = seg;
-                wave_append(cls == 2, er, a.ent_list, a.ent_count, a.ent_cap_recs, lane, lane_lt);
+                CandRec cr;
+                cr.ref_loc = ref_loc; cr.query_loc = query_loc; cr.hidx = hidx;
+                stage_append(stage, n_stage, cand, cr, a.cand_list, a.cand_count, a.cand_cap_recs, lane, lane_lt);
             }
             // ---- refill the finished lanes from the wave's queue (wave-uniform control flow) ----
             unsigned long long need = fin;
@@ -268,6 +352,8 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_main_kernel(ExtendArgs a) 
                 need &= ~__ballot(take);
             }
             if (phase == PH_FIN) {
+                forward = false;
+                ex_hit = 0;
                 if (got) {
                     has_hit = true;
                     ref_loc = mine.ref_loc;
@@ -276,17 +362,21 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_main_kernel(ExtendArgs a) 
                     bool skip = false;
                     if (a.rm)  // repeat masker: hits outside [ref_start, ref_end] are not extended (rm :239-244,:305-333)
                         skip = !(ref_loc >= a.rm_win_start && ref_loc <= a.rm_win_end);
-                    if (skip) {  // both loops skipped: total 0, extent 0 (:311)
-                        bestR = 0; bposR = 0; best = 0; bpos = 0;
+                    bestR = 0;
+                    best = 0;
+                    if (skip) {  // both loops skipped: total 0
                         phase = PH_FIN;
                     } else {
                         phase = PH_RIGHT;  // :299-324
-                        k = 0;
-                        lim = (ref_loc < a.ref_len && query_loc < a.query_len)
-                                  ? min(a.ref_len - ref_loc, a.query_len - query_loc) : 0u;
+                        roff = ref_loc + BIAS;
+                        qoff = query_loc + BIAS;
+                        dstep = 8;
+                        sel_lo = 0x03020100u;
+                        sel_hi = 0x07060504u;
+                        remaining = (ref_loc < a.ref_len && query_loc < a.query_len)
+                                        ? (int)min(min(a.ref_len - ref_loc, a.query_len - query_loc), 0x7fffffffu) : 0;
+                        walked = 0;
                         score = 0;
-                        best = 0;
-                        bpos = -1;
                     }
                 } else {
                     has_hit = false;
@@ -296,6 +386,7 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_main_kernel(ExtendArgs a) 
         }
         if (__ballot(phase != PH_IDLE) == 0ull) break;
     }
+    stage_flush(stage, n_stage, a.cand_list, a.cand_count, a.cand_cap_recs, lane);
 
     if (COUNT_EXAMINED) {
         unsigned long long v = examined;
@@ -306,129 +397,131 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_main_kernel(ExtendArgs a) 
 }
 
 // =====================================================================================================================
-// 2. long kernel: one wave per parked hit, 512 bases per step
+// 2. exact extension of the candidates: one wave per hit, 512 bases per step
 // =====================================================================================================================
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 template <bool COUNT_EXAMINED, bool XDROP_NONNEG>
-__global__ __launch_bounds__(EXT_THREADS) void extend_long_kernel(ExtendArgs a) {
+__global__ __launch_bounds__(EXT_THREADS) void extend_exact_kernel(ExtendArgs a) {
     __shared__ int s_tab[128];
+    __shared__ HspRec s_out[EXT_THREADS / 64][64];
+    __shared__ EntRec s_ent[EXT_THREADS / 64][64];
     if (threadIdx.x < 128) s_tab[threadIdx.x] = threadIdx.x < 64 ? a.sub_mat[threadIdx.x] : NEG;
     __syncthreads();
+    HspRec* st_out = s_out[threadIdx.x >> 6];
+    EntRec* st_ent = s_ent[threadIdx.x >> 6];
+    int n_out = 0, n_ent = 0;
 
     const int lane = threadIdx.x & 63;
     const uint8_t* __restrict__ R8b = a.ref8 - BIAS;
     const uint8_t* __restrict__ Qb = a.query - BIAS;
     const int xdrop = a.xdrop;
-    const uint32_t n_long = min(*a.long_count, a.long_cap_recs);
+    const uint32_t n_cand = min(*a.cand_count, a.cand_cap_recs);
     const uint32_t G = gridDim.x * (EXT_THREADS / 64);
     unsigned long long examined = 0;
 
-    for (uint32_t i = blockIdx.x * (EXT_THREADS / 64) + (threadIdx.x >> 6); i < n_long; i += G) {
-        const LongRec lr = a.long_list[i];  // same address in every lane: one broadcast load
-        const uint32_t ref_loc = (uint32_t)rfl((int)lr.ref_loc), query_loc = (uint32_t)rfl((int)lr.query_loc);
-        int side = rfl((int)lr.side);
-        uint32_t k0 = (uint32_t)rfl((int)lr.k);
-        int score_in = rfl(lr.score), best_in = rfl(lr.best), bpos_in = rfl(lr.bpos);
-        int bestR = rfl(lr.bestR), bposR = rfl(lr.bposR);
+    for (uint32_t i = blockIdx.x * (EXT_THREADS / 64) + (threadIdx.x >> 6); i < n_cand; i += G) {
+        const CandRec cr = a.cand_list[i];  // same address in every lane: one broadcast load
+        const uint32_t ref_loc = (uint32_t)rfl((int)cr.ref_loc), query_loc = (uint32_t)rfl((int)cr.query_loc);
+        const uint32_t hidx = (uint32_t)rfl((int)cr.hidx);
+        int bestR = 0, bposR = -1, bestL = 0, boffL = 0;
 
-        for (;;) {  // sides
-            const bool left = side == PH_LEFT;
+        bool skip = false;
+        if (a.rm) skip = !(ref_loc >= a.rm_win_start && ref_loc <= a.rm_win_end);  // rm :239-244,:305-333
+        if (skip) bposR = 0;  // extent stays 0 (:311)
+
+        for (int side = skip ? 2 : 0; side < 2; side++) {
+            const bool left = side == 1;
             const uint32_t lim = left ? min(ref_loc, query_loc)
                                       : ((ref_loc < a.ref_len && query_loc < a.query_len)
                                              ? min(a.ref_len - ref_loc, a.query_len - query_loc) : 0u);
+            uint32_t k0 = left ? 1u : 0u;             // :327 / :479
+            int score_in = 0, best_in = 0, bpos_in = left ? 0 : -1;  // :308-310 / :465-467
             for (;;) {  // 512-base windows
                 const uint32_t k = k0 + 8u * (uint32_t)lane;
-                // in-range positions from k on; clamp far-away lanes so the int cast cannot wrap
+                // in-range positions from k on, clamped to [0, 8]
                 const int64_t rem64 = left ? (int64_t)lim - (int64_t)k + 1 : (int64_t)lim - (int64_t)k;
                 const int remaining = rem64 > 8 ? 8 : (rem64 < 0 ? 0 : (int)rem64);
-                const uint64_t x = fetch_indices(R8b, Qb, ref_loc, query_loc, left, k, remaining);
-                // ---- local prefix sums of the 8 scores; local maximum prefix ----
-                int s[8];
+                uint64_t x = 0;
+                if (remaining > 0) {
+                    const uint32_t roff = left ? ref_loc + BIAS - k - 7u : ref_loc + BIAS + k;
+                    const uint32_t qoff = left ? query_loc + BIAS - k - 7u : query_loc + BIAS + k;
+                    x = load8u(R8b + roff) | load8u(Qb + qoff);
+                    if (left) x = __builtin_bswap64(x);  // byte j <-> offset k+j on both sides
+                }
+                if (remaining < 8) x |= (remaining <= 0) ? TERM_ALL : (TERM_ALL << (8 * remaining));
+                // ---- local prefix sums of the 8 scores, local maximum prefix (first position attaining it) ----
+                // (sums are formed in uint32: lanes past a sequence edge accumulate terminators and may wrap; they lie
+                //  after the first dropping lane and are discarded)
+                uint32_t run = 0;
+                int mx = INT32_MIN, amx = 0;
                 {
                     const uint32_t xlo = (uint32_t)x, xhi = (uint32_t)(x >> 32);
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
                         const uint32_t w = j < 4 ? xlo : xhi;
-                        s[j] = s_tab[(w >> (8 * (j & 3))) & 0xffu];
+                        run += (uint32_t)s_tab[(w >> (8 * (j & 3))) & 0xffu];
+                        const bool up = (int)run > mx;
+                        amx = up ? j : amx;
+                        mx = up ? (int)run : mx;
                     }
                 }
-                // (sums are formed in uint32: lanes past a sequence edge accumulate terminators and may wrap; they lie
-                //  after the first dropping lane and are discarded)
-                uint32_t run = 0;
-                int mx = INT32_MIN, amx = 0;
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    run += (uint32_t)s[j];
-                    if ((int)run > mx) { mx = (int)run; amx = j; }  // first position attaining the local maximum
-                }
-                // ---- entry score of every lane: exclusive wave sum-scan ----
-                uint32_t inc = run;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const uint32_t t = (uint32_t)__shfl_up((int)inc, off, 64);
-                    if (lane >= off) inc += t;
-                }
+                // ---- entry score of every lane: exclusive wave sum-scan (DPP) ----
+                const uint32_t inc = wave_inclusive_sum(run);
                 const int base = (int)((uint32_t)score_in + inc - run);
-                // ---- entry best of every lane: exclusive wave max-scan, ties keep the EARLIER position (:350,:361-372) ----
+                // ---- entry best of every lane: exclusive max-scan, ties keep the EARLIER position ----
                 int mv = (int)((uint32_t)base + (uint32_t)mx), mp = (int)(k + (uint32_t)amx);
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int tv = __shfl_up(mv, off, 64);
-                    const int tp = __shfl_up(mp, off, 64);
-                    if (lane >= off && tv >= mv) { mv = tv; mp = tp; }
-                }
-                int ev = __shfl_up(mv, 1, 64), ep = __shfl_up(mp, 1, 64);  // exclusive: best over earlier lanes
-                if (lane == 0 || best_in >= ev) { ev = best_in; ep = bpos_in; }  // the carried-in best is the earliest of all
+                wave_inclusive_max(mv, mp);
+                int ev = dpp_mov<0x138>(INT32_MIN, mv);  // wave_shr:1 -> best over earlier lanes
+                int ep = dpp_mov<0x138>(0, mp);
+                if (best_in >= ev) { ev = best_in; ep = bpos_in; }  // the carried-in best is the earliest of all
                 // ---- exact replay of the lane's 8 bases ----
                 int score = base, best = ev, bpos = ep;
-                unsigned long long ex_step = 0;
-                chunk8<COUNT_EXAMINED, XDROP_NONNEG>(s_tab, x, k, xdrop, score, best, bpos, ex_step);
-                const bool dropped = score < (DEAD >> 1);
-                const unsigned long long dm = __ballot(dropped);
+                uint32_t ex_step = 0;
+                chunk8_exact<COUNT_EXAMINED, XDROP_NONNEG>(s_tab, x, k, xdrop, score, best, bpos, ex_step);
+                const unsigned long long dm = __ballot(score < (DEAD >> 1));
                 if (dm) {
                     const int f = __ffsll((long long)dm) - 1;  // first lane that dropped holds the final state
-                    best_in = rfl(__shfl(best, f, 64));
-                    bpos_in = rfl(__shfl(bpos, f, 64));
+                    best_in = __builtin_amdgcn_readlane(best, f);
+                    bpos_in = __builtin_amdgcn_readlane(bpos, f);
                     if (COUNT_EXAMINED && lane <= f) examined += ex_step;  // lanes after f never happened
                     break;
                 }
                 if (COUNT_EXAMINED) examined += ex_step;
-                score_in = rfl(__shfl(score, 63, 64));
-                best_in = rfl(__shfl(best, 63, 64));
-                bpos_in = rfl(__shfl(bpos, 63, 64));
+                score_in = __builtin_amdgcn_readlane(score, 63);
+                best_in = __builtin_amdgcn_readlane(best, 63);
+                bpos_in = __builtin_amdgcn_readlane(bpos, 63);
                 k0 += 512u;
             }
-            if (!left) {  // right side done -> left side from scratch (:457-476)
-                bestR = best_in;
-                bposR = bpos_in;
-                side = PH_LEFT;
-                k0 = 1;
-                score_in = 0;
-                best_in = 0;
-                bpos_in = 0;
-            } else {
-                break;
-            }
+            if (!left) { bestR = best_in; bposR = bpos_in; }
+            else { bestL = best_in; boffL = bpos_in; }
         }
-        // ---- finalise (lane 0) ----
-        if (lane == 0) {
-            const int total = bestR + best_in, extent = bposR + bpos_in;
+        // ---- finalise: all values are wave-uniform; records are staged in LDS and flushed 64 at a time ----
+        {
+            const int total = bestR + bestL, extent = bposR + boffL;  // :414-421, :563-574
             const int cls = classify(a, total);
             if (cls) {
-                const uint32_t seg = seg_of(a, lr.hidx);
+                const uint32_t seg = seg_of(a, hidx);
                 if (cls == 1) {
-                    const uint32_t slot = atomicAdd(a.out_count, 1u);
-                    if (slot < a.out_cap) a.out[slot] = make_rec(a, ref_loc, query_loc, bpos_in, extent, total, seg);
+                    if (lane == 0) st_out[n_out] = make_rec(a, ref_loc, query_loc, boffL, extent, total, seg);  // :638 with entropy 1
+                    n_out++;
+                    __builtin_amdgcn_wave_barrier();
+                    if (n_out == 64) { stage_flush(st_out, 64, a.out, a.out_count, a.out_cap, lane); n_out = 0; __builtin_amdgcn_wave_barrier(); }
                 } else {
-                    EntRec er;
-                    er.ref_loc = ref_loc; er.query_loc = query_loc; er.bposR = bposR; er.boffL = bpos_in; er.total = total; er.seg = seg;
-                    const uint32_t slot = atomicAdd(a.ent_count, 1u);
-                    if (slot < a.ent_cap_recs) a.ent_list[slot] = er;
+                    if (lane == 0) {
+                        EntRec er;
+                        er.ref_loc = ref_loc; er.query_loc = query_loc; er.bposR = bposR; er.boffL = boffL; er.total = total; er.seg = seg;
+                        st_ent[n_ent] = er;
+                    }
+                    n_ent++;
+                    __builtin_amdgcn_wave_barrier();
+                    if (n_ent == 64) { stage_flush(st_ent, 64, a.ent_list, a.ent_count, a.ent_cap_recs, lane); n_ent = 0; __builtin_amdgcn_wave_barrier(); }
                 }
             }
         }
     }
+    stage_flush(st_out, n_out, a.out, a.out_count, a.out_cap, lane);
+    stage_flush(st_ent, n_ent, a.ent_list, a.ent_count, a.ent_cap_recs, lane);
     if (COUNT_EXAMINED) {
         unsigned long long v = examined;
 #pragma unroll
@@ -438,7 +531,7 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_long_kernel(ExtendArgs a) 
 }
 
 // =====================================================================================================================
-// 3. entropy kernel: lane per candidate (:608-647)
+// 3. entropy kernel: lane per hit (:608-647)
 // =====================================================================================================================
 __global__ __launch_bounds__(EXT_THREADS) void extend_entropy_kernel(ExtendArgs a) {
     const int lane = threadIdx.x & 63;
@@ -485,29 +578,26 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_entropy_kernel(ExtendArgs 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool C, bool X>
-static void launch_variants(const ExtendArgs& a, uint32_t main_blocks, hipStream_t s) {
-    hipLaunchKernelGGL((extend_main_kernel<C, X>), dim3(main_blocks), dim3(EXT_THREADS), 0, s, a);
-    hipLaunchKernelGGL((extend_long_kernel<C, X>), dim3(a.long_blocks), dim3(EXT_THREADS), 0, s, a);
-}
-
 void launch_extend(const ExtendArgs& a, hipStream_t s) {
     if (a.num_hits == 0) return;
     const uint64_t num_buf = (a.num_hits + 63) / 64;
-    // waves: enough to fill the chip (256 CUs x up to 32 waves); at least `bufs_per_wave` buffers per wave so the
-    // drain phase of a wave (bounded by long_cap) is amortised
+    // filter waves: a few per SIMD saturate instruction issue; at least `bufs_per_wave` buffers per wave so the drain
+    // phase of a wave (bounded by long_cap) is amortised
     uint64_t waves = num_buf / (uint64_t)(a.bufs_per_wave > 0 ? a.bufs_per_wave : 8);
-    const uint64_t max_waves = 256ull * 32ull;
+    const uint64_t max_waves = a.max_waves ? a.max_waves : 4096u;
     if (waves > max_waves) waves = max_waves;
     if (waves < 4) waves = 4;
     const uint32_t blocks = (uint32_t)((waves + 3) / 4);
     const bool nonneg = a.xdrop >= 0;
     if (a.examined) {
-        if (nonneg) launch_variants<true, true>(a, blocks, s);
-        else launch_variants<true, false>(a, blocks, s);
+        hipLaunchKernelGGL((extend_filter_kernel<true, false>), dim3(blocks), dim3(EXT_THREADS), 0, s, a);
+        if (nonneg) hipLaunchKernelGGL((extend_exact_kernel<true, true>), dim3(a.long_blocks), dim3(EXT_THREADS), 0, s, a);
+        else hipLaunchKernelGGL((extend_exact_kernel<true, false>), dim3(a.long_blocks), dim3(EXT_THREADS), 0, s, a);
     } else {
-        if (nonneg) launch_variants<false, true>(a, blocks, s);
-        else launch_variants<false, false>(a, blocks, s);
+        if (a.fast_filter) hipLaunchKernelGGL((extend_filter_kernel<false, true>), dim3(blocks), dim3(EXT_THREADS), 0, s, a);
+        else hipLaunchKernelGGL((extend_filter_kernel<false, false>), dim3(blocks), dim3(EXT_THREADS), 0, s, a);
+        if (nonneg) hipLaunchKernelGGL((extend_exact_kernel<false, true>), dim3(a.long_blocks), dim3(EXT_THREADS), 0, s, a);
+        else hipLaunchKernelGGL((extend_exact_kernel<false, false>), dim3(a.long_blocks), dim3(EXT_THREADS), 0, s, a);
     }
     hipLaunchKernelGGL(extend_entropy_kernel, dim3(a.ent_blocks), dim3(EXT_THREADS), 0, s, a);
 }

@@ -35,13 +35,9 @@ struct HspRec {               // survivor: reference segmentPair + the reference
     uint32_t seg;
 };
 
-struct LongRec {              // a hit whose current side outlived long_cap bases: state handed to the long kernel
+struct CandRec {              // a hit the X-drop filter could not reject: extended exactly by the exact kernel
     uint32_t ref_loc, query_loc;
     uint32_t hidx;            // index of the hit inside the launch (for the segment id)
-    uint32_t side;            // 0 = right side in progress, 1 = left side in progress
-    uint32_t k;               // next offset to score on that side
-    int32_t score, best, bpos;  // running state of that side
-    int32_t bestR, bposR;     // finished right side (valid when side == 1)
 };
 
 struct EntRec {               // finished hit with hspthresh <= total <= 3*hspthresh: needs the entropy factor (:608)
@@ -62,13 +58,15 @@ struct ExtendArgs {
     int noentropy;
     int fin_batch;            // finished lanes a wave accumulates before it finalises + refills them
     int bufs_per_wave;        // launch heuristic: 64-hit buffers each wave should own at least
-    uint32_t long_cap;        // bases per side a lane walks before it parks the hit for the long kernel
-    LongRec* long_list;
-    uint32_t* long_count;
-    uint32_t long_cap_recs;
+    uint32_t long_cap;        // bases per side the filter walks before it forwards the hit to the exact kernel
+    int fast_filter;          // xdrop >= 0 && 7*max(M) <= xdrop: the filter may skip the sticky select (extend.hip)
+    CandRec* cand_list;
+    uint32_t* cand_count;
+    uint32_t cand_cap_recs;
     EntRec* ent_list;
     uint32_t* ent_count;
     uint32_t ent_cap_recs;
+    uint32_t max_waves;       // wave budget of the main kernel (resident waves of the chip)
     uint32_t long_blocks, ent_blocks;  // grid sizes of the long / entropy kernels (they read their counts on device)
     const Hit* hits;
     uint64_t num_hits;

@@ -152,40 +152,48 @@ def main():
     # ---------------- roofline of the dominant kernel (rank 0's own launches) ----------------
     roof = None
     if rank == 0 and prof:
-        # E per hit from one instrumented (untimed) interval: deterministic, identical work
+        # per-hit ratios from one instrumented (untimed) interval: deterministic, identical work
         E.set_count_examined(True)
-        sample_stats = []
-        run_interval(my[0], sample_stats)
+        sample = []
+        run_interval(my[0], sample)
         E.set_count_examined(False)
-        sH = sum(s["num_hits"] for s in sample_stats)
-        sE = sum(s["num_examined"] for s in sample_stats)
-        e_per_hit = sE / max(sH, 1)
+        sH = max(sum(s["num_hits"] for s in sample), 1)
+        e_all = sum(s["num_examined"] for s in sample) / sH          # E per hit (reference algorithm)
+        e_flt = sum(s["num_examined_filter"] for s in sample) / sH   # bases per hit scored by the filter kernel
         H = sum(s["num_hits"] for s in call_stats)
         A = sum(s["num_survivors"] for s in call_stats)
         S = sum(s["num_seeds"] for s in call_stats)
-        dom = max(prof.items(), key=lambda kv: kv[1][0])
-        name, (ms, launches) = dom
+        Cn = sum(s["num_candidates"] for s in call_stats)
         kernels = {k: {"ms_total": round(v[0], 3), "launches": v[1], "avg_us": round(1e3 * v[0] / max(v[1], 1), 2)}
                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
-        # algorithmic bytes (SURVEY 8d / DESIGN.md): extension 8H + 2E + 20A ; lookup+expand 16S + 12H
-        ext_bytes = 8.0 * H + 2.0 * e_per_hit * H + 20.0 * A
+
+        def gbs(nbytes, keys):
+            ms = sum(prof[k][0] for k in keys if k in prof)
+            return (nbytes / (ms * 1e-3) / 1e9) if ms > 0 else None
+
+        # algorithmic bytes (restated per kernel in DESIGN.md):
+        #   extension as a whole (filter+exact+entropy) : 8H + 2E + 20A
+        #   X-drop filter alone                         : 8H + 2*E_filter + 12*C   (C candidates out)
+        #   lookup + expand                             : 16S + 12H
+        ext_bytes = 8.0 * H + 2.0 * e_all * H + 20.0 * A
+        flt_bytes = 8.0 * H + 2.0 * e_flt * H + 12.0 * Cn
         look_bytes = 16.0 * S + 12.0 * H
-        def gbs(nbytes, key):
-            v = prof.get(key)
-            return (nbytes / (v[0] * 1e-3) / 1e9) if v and v[0] > 0 else None
-        ext_gbs = gbs(ext_bytes, "extend_hits")
-        look_ms = sum(prof[k][0] for k in ("seed_lookup", "expand_hits") if k in prof)
-        look_gbs = look_bytes / (look_ms * 1e-3) / 1e9 if look_ms > 0 else None
-        achieved = ext_gbs if name == "extend_hits" else (look_gbs if name in ("seed_lookup", "expand_hits") else None)
+        name, (ms, launches) = max(prof.items(), key=lambda kv: kv[1][0])
+        per_kernel = {"extend_filter": flt_bytes, "seed_lookup": 16.0 * S, "expand_hits": 12.0 * H}
+        achieved = gbs(per_kernel[name], [name]) if name in per_kernel else None
+        ext_gbs = gbs(ext_bytes, ["extend_filter", "extend_exact", "extend_entropy"])
+        look_gbs = gbs(look_bytes, ["seed_lookup", "expand_hits"])
         roof = {
             "bound": "hbm", "kernel": name, "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
             "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
-            "algorithmic_bytes_per_launch": round(ext_bytes / max(prof.get("extend_hits", (0, 1))[1], 1)),
-            "per_hit": {"examined_bases": round(e_per_hit, 2), "survivor_frac": round(A / max(H, 1), 5)},
+            "algorithmic_bytes_per_launch": round(per_kernel.get(name, 0) / max(launches, 1)),
+            "per_hit": {"examined_bases_E": round(e_all, 2), "examined_by_filter": round(e_flt, 2),
+                        "candidate_frac": round(Cn / max(H, 1), 5), "survivor_frac": round(A / max(H, 1), 5)},
+            "extension_total": {"achieved": round(ext_gbs, 1) if ext_gbs else None,
+                                "frac": round(ext_gbs / HBM_PEAK_GBS, 4) if ext_gbs else None, "bytes": "8*H + 2*E + 20*A"},
             "lookup_expand": {"achieved": round(look_gbs, 1) if look_gbs else None,
-                              "frac": round(look_gbs / HBM_PEAK_GBS, 4) if look_gbs else None,
-                              "bytes": "16*S + 12*H"},
+                              "frac": round(look_gbs / HBM_PEAK_GBS, 4) if look_gbs else None, "bytes": "16*S + 12*H"},
             "kernels": kernels,
         }
 

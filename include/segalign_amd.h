@@ -127,6 +127,9 @@ typedef struct sa_call_stats {
     uint64_t num_survivors; /* A before dedup */
     uint64_t num_anchors;   /* returned HSPs */
     uint64_t num_examined;  /* E: scored positions; only filled while sa_set_count_examined(1) */
+    uint64_t num_examined_filter; /* positions scored by the filter kernel alone (same condition) */
+    uint64_t num_candidates; /* hits the X-drop filter forwarded to the exact kernel */
+    uint64_t num_entropy;   /* hits that needed the entropy factor */
     uint32_t num_iter;
     int device;
 } sa_call_stats;

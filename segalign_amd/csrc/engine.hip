@@ -143,7 +143,8 @@ struct Counters {  // device-side scalars of one slot
     uint32_t uniq;
     uint32_t uniq2;
     uint32_t pad;
-    unsigned long long examined;
+    unsigned long long examined;         // E: positions the reference algorithm scores
+    unsigned long long examined_filter;  // positions the filter kernel scored (partial walks of candidates included)
     uint32_t n_long;  // candidates the filter forwarded to the exact kernel (this batch)
     uint32_t n_ent;   // entropy candidates (this batch)
 };
@@ -337,6 +338,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
     uint64_t num_hits = 0;
     uint32_t n_final = 0;
     uint32_t survivors = 0;
+    uint64_t n_cand_total = 0, n_ent_total = 0;
 
     if (num_seeds > 0) {
         // ---- bucket lookup + prefix (find_num_hits :157-182 ; inclusive_scan :714) ----
@@ -444,10 +446,9 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     ea.cand_cap_recs = (uint32_t)std::min<size_t>(sl->cand_list.cap, 0xFFFFFFFFu);
                     ea.ent_list = sl->ent_list.p;
                     ea.ent_cap_recs = (uint32_t)std::min<size_t>(sl->ent_list.cap, 0xFFFFFFFFu);
-                    {
-                        ProfScope p(sl, "extend_hits");
-                        launch_extend(ea, st);
-                    }
+                    { ProfScope p(sl, "extend_filter");  launch_extend_filter(ea, st); }
+                    { ProfScope p(sl, "extend_exact");   launch_extend_exact(ea, st); }
+                    { ProfScope p(sl, "extend_entropy"); launch_extend_entropy(ea, st); }
                     check_launch("expand/extend");
                     check_memcpy(hipMemcpyAsync(sl->h_cnt, sl->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st), "counters");
                     check_sync(st, "extend");
@@ -464,8 +465,13 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     check_memcpy(hipMemcpy(sl->d_cnt, &before, sizeof(Counters), hipMemcpyHostToDevice), "counter reset");
                 }
                 survivors = sl->h_cnt->survivors;
+                n_cand_total += sl->h_cnt->n_long;
+                n_ent_total += sl->h_cnt->n_ent;
             }
             t_stats.num_examined = sl->h_cnt->examined;
+            t_stats.num_examined_filter = sl->h_cnt->examined_filter;
+            t_stats.num_candidates = n_cand_total;
+            t_stats.num_entropy = n_ent_total;
 
             // ---- order + de-duplicate (:776-782 ; rm :819-831) ----
             if (survivors > 0) {

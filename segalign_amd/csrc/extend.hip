@@ -236,7 +236,7 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_filter_kernel(ExtendArgs a
     uint32_t walked = 0;                    // bases walked on this side
     int score = 0, best = 0, bestR = 0;
     uint32_t ex_hit = 0;
-    unsigned long long examined = 0;
+    unsigned long long examined = 0, examined_all = 0;
 
     for (;;) {
         // ================= 1. advance every live lane by one 8-base chunk =================
@@ -312,7 +312,10 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_filter_kernel(ExtendArgs a
             bool cand = false;
             if (phase == PH_FIN && has_hit) {
                 cand = forward || classify(a, bestR + best) != 0;
-                if (COUNT_EXAMINED && !cand) examined += ex_hit;  // candidates are re-extended (and counted) by the exact kernel
+                if (COUNT_EXAMINED) {
+                    examined_all += ex_hit;             // every base the filter scored (its own algorithmic bytes)
+                    if (!cand) examined += ex_hit;      // candidates are re-extended (and counted) by the exact kernel
+                }
             }
             {
                 CandRec cr;
@@ -389,10 +392,11 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_filter_kernel(ExtendArgs a
     stage_flush(stage, n_stage, a.cand_list, a.cand_count, a.cand_cap_recs, lane);
 
     if (COUNT_EXAMINED) {
-        unsigned long long v = examined;
+        unsigned long long v = examined, w = examined_all;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        for (int off = 32; off > 0; off >>= 1) { v += __shfl_down(v, off, 64); w += __shfl_down(w, off, 64); }
         if (lane == 0 && v) atomicAdd(a.examined, v);
+        if (lane == 0 && w) atomicAdd(a.examined + 1, w);
     }
 }
 
@@ -578,27 +582,35 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_entropy_kernel(ExtendArgs 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-void launch_extend(const ExtendArgs& a, hipStream_t s) {
+void launch_extend_filter(const ExtendArgs& a, hipStream_t s) {
     if (a.num_hits == 0) return;
     const uint64_t num_buf = (a.num_hits + 63) / 64;
-    // filter waves: a few per SIMD saturate instruction issue; at least `bufs_per_wave` buffers per wave so the drain
-    // phase of a wave (bounded by long_cap) is amortised
+    // filter waves: ~4 per SIMD saturate instruction issue (more only add contention); at least `bufs_per_wave` buffers
+    // per wave so the drain phase of a wave (bounded by long_cap) is amortised
     uint64_t waves = num_buf / (uint64_t)(a.bufs_per_wave > 0 ? a.bufs_per_wave : 8);
     const uint64_t max_waves = a.max_waves ? a.max_waves : 4096u;
     if (waves > max_waves) waves = max_waves;
     if (waves < 4) waves = 4;
     const uint32_t blocks = (uint32_t)((waves + 3) / 4);
+    if (a.examined) hipLaunchKernelGGL((extend_filter_kernel<true, false>), dim3(blocks), dim3(EXT_THREADS), 0, s, a);
+    else if (a.fast_filter) hipLaunchKernelGGL((extend_filter_kernel<false, true>), dim3(blocks), dim3(EXT_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((extend_filter_kernel<false, false>), dim3(blocks), dim3(EXT_THREADS), 0, s, a);
+}
+
+void launch_extend_exact(const ExtendArgs& a, hipStream_t s) {
+    if (a.num_hits == 0) return;
     const bool nonneg = a.xdrop >= 0;
     if (a.examined) {
-        hipLaunchKernelGGL((extend_filter_kernel<true, false>), dim3(blocks), dim3(EXT_THREADS), 0, s, a);
         if (nonneg) hipLaunchKernelGGL((extend_exact_kernel<true, true>), dim3(a.long_blocks), dim3(EXT_THREADS), 0, s, a);
         else hipLaunchKernelGGL((extend_exact_kernel<true, false>), dim3(a.long_blocks), dim3(EXT_THREADS), 0, s, a);
     } else {
-        if (a.fast_filter) hipLaunchKernelGGL((extend_filter_kernel<false, true>), dim3(blocks), dim3(EXT_THREADS), 0, s, a);
-        else hipLaunchKernelGGL((extend_filter_kernel<false, false>), dim3(blocks), dim3(EXT_THREADS), 0, s, a);
         if (nonneg) hipLaunchKernelGGL((extend_exact_kernel<false, true>), dim3(a.long_blocks), dim3(EXT_THREADS), 0, s, a);
         else hipLaunchKernelGGL((extend_exact_kernel<false, false>), dim3(a.long_blocks), dim3(EXT_THREADS), 0, s, a);
     }
+}
+
+void launch_extend_entropy(const ExtendArgs& a, hipStream_t s) {
+    if (a.num_hits == 0) return;
     hipLaunchKernelGGL(extend_entropy_kernel, dim3(a.ent_blocks), dim3(EXT_THREADS), 0, s, a);
 }
 

@@ -77,7 +77,7 @@ struct ExtendArgs {
     HspRec* out;              // survivors, appended
     uint32_t out_cap;         // capacity of out[]; the counter keeps counting past it, writes are dropped
     uint32_t* out_count;      // device counter
-    unsigned long long* examined; // optional (null = do not count)
+    unsigned long long* examined; // optional (null = do not count): [0] = E of the call, [1] = bases scored by the filter
     // repeat-masker deltas (repeat_masker_src/seed_filter.cu:239-244, 305-333, 705-708)
     int rm;
     uint32_t rm_win_start, rm_win_end;
@@ -125,7 +125,9 @@ void launch_plan(const uint64_t* hit_prefix_excl, uint32_t num_seeds, uint64_t m
                  hipStream_t s);
 
 // ---- extend.hip ------------------------------------------------------------------------------------------------
-void launch_extend(const ExtendArgs& a, hipStream_t s);
+void launch_extend_filter(const ExtendArgs& a, hipStream_t s);   // hits -> candidates
+void launch_extend_exact(const ExtendArgs& a, hipStream_t s);    // candidates -> survivors + entropy records
+void launch_extend_entropy(const ExtendArgs& a, hipStream_t s);  // entropy records -> survivors
 
 // ---- dedup.hip -------------------------------------------------------------------------------------------------
 enum SortOrder { ORDER_DIAG = 0, ORDER_LASTZ = 1, ORDER_RM_FIRST = 2, ORDER_RM_DIAG = 3, ORDER_RM_FINAL = 4 };

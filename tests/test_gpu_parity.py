@@ -49,3 +49,24 @@ def test_seed_and_filter_bit_exact(small_case, rev):
         assert seg_equal(got2, want)
         total += want.size - 1
     assert total > 0
+
+
+def test_examined_counter_matches_oracle(small_case):
+    """E of SURVEY 8(d) -- positions the reference algorithm scores -- counted on the device must equal the oracle's
+    count (it feeds roofline.achieved), and counting must not change the result."""
+    c = small_case
+    (s, e) = c.chunks()[0]
+    seeds = c.host_seeds(s, e, False)
+    want, st = c.oracle_saf(seeds, False)
+    c.E.set_count_examined(True)
+    try:
+        got = c.E.SeedAndFilter(seeds, False, 0)
+        stats = c.E.last_call_stats()
+    finally:
+        c.E.set_count_examined(False)
+    assert seg_equal(got, want)
+    assert stats["num_hits"] == st["num_hits"]
+    assert stats["num_survivors"] == st["num_survivors"]
+    assert stats["num_examined"] == st["num_examined"]
+    assert stats["num_candidates"] >= stats["num_survivors"]
+    assert stats["num_examined_filter"] > 0

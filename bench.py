@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--chunk", type=int, default=250_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU baseline budget")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU-only rehearsal of the launch/shard/reduce/JSON contract (gloo, no engine, no GPU)")
     return ap.parse_args()
 
 
@@ -53,14 +55,22 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
     import torch
+    from segalign_amd import shard
     dist = None
+    dev = "cpu" if args.dry_run else "cuda"
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
+        if args.dry_run:
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # "nccl" IS RCCL on ROCm
+    elif not args.dry_run:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+
+    if args.dry_run:
+        return dry_run(args, rank, world, dist, torch, shard)
 
     from segalign_amd import engine as E
     from segalign_amd import synth
@@ -91,28 +101,22 @@ def main():
     t_query = time.time() - t0
 
     # intervals like src/main.cpp:383-393 over [0, len - seed_size)
-    end_pos = query.size - seed_size
-    intervals = [(s, min(s + args.interval, end_pos)) for s in range(0, end_pos, args.interval)]
-    q_block_len = end_pos  # q_len handed to the seeder (main.cpp:708)
+    intervals = shard.plan_intervals(query.size, seed_size, args.interval)
+    q_block_len = query.size - seed_size  # q_len handed to the seeder (main.cpp:708)
 
     def run_interval(iv, collect=None):
-        s, e = iv
-        bases = e - s
+        bases = iv[1] - iv[0]
         hsps = 0
         for rev in (False, True):
-            if rev:  # rc coordinates, seeder.cpp:33-34
-                a, b = q_block_len - e, q_block_len - s
-            else:
-                a, b = s, e
-            for c in range(a, b, args.chunk):
-                out = E.SeedAndFilterRange(c, min(c + args.chunk, b), rev, 0)
+            for (a, b) in shard.chunks_of(iv, args.chunk, q_block_len, rev):
+                out = E.SeedAndFilterRange(a, b, rev, 0)
                 if out.size:
                     hsps += out.size - 1
                 if collect is not None:
                     collect.append(E.last_call_stats())
         return bases, hsps
 
-    my = [intervals[i] for i in range(rank, len(intervals), world)] or intervals
+    my = shard.shard(intervals, rank, world) or intervals
 
     def barrier():
         if dist is not None:
@@ -142,10 +146,10 @@ def main():
 
     # max over ranks, sum of bases
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        tb = torch.tensor([bases, hsps], dtype=torch.int64, device="cuda")
+        tb = torch.tensor([bases, hsps], dtype=torch.int64, device=dev)
         dist.all_reduce(tb, op=dist.ReduceOp.SUM)
         bases, hsps = int(tb[0].item()), int(tb[1].item())
 
@@ -222,6 +226,43 @@ def main():
         print(json.dumps(line))
         sys.stdout.flush()
     E.ShutdownProcessor()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def dry_run(args, rank, world, dist, torch, shard):
+    """Everything of the bench contract that does not need a GPU: sharding, barrier, max/sum reduction, the JSON line.
+    The per-interval 'work' is a checksum of the chunk bounds, so a wrong shard or reduction changes the output."""
+    qlen = int(args.target_mbp * 1e6)
+    seed_size = len(SHAPE)
+    intervals = shard.plan_intervals(qlen, seed_size, args.interval)
+    my = shard.shard(intervals, rank, world) or intervals
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    bases, check = 0, 0
+    for k in range(args.steps):
+        iv = my[k % len(my)]
+        bases += iv[1] - iv[0]
+        for rev in (False, True):
+            for (a, b) in shard.chunks_of(iv, args.chunk, qlen - seed_size, rev):
+                check += (a * 31 + b * 17 + int(rev)) % 1000003
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        tb = torch.tensor([bases, check], dtype=torch.int64)
+        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        bases, check = int(tb[0].item()), int(tb[1].item())
+    if rank == 0:
+        print(json.dumps({"metric": "Gbp query seeded+filtered+extended per sec", "value": bases / max(elapsed, 1e-9) / 1e9,
+                          "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "int32", "data": "dry-run", "config": {"workload": "dry-run"},
+                          "bases": bases, "checksum": check}))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -187,9 +187,11 @@ def main():
         achieved = gbs(per_kernel[name], [name]) if name in per_kernel else None
         ext_gbs = gbs(ext_bytes, ["extend_filter", "extend_exact", "extend_entropy"])
         look_gbs = gbs(look_bytes, ["seed_lookup", "expand_hits"])
+        traffic, traffic_src = measured_traffic(name)
         roof = {
             "bound": "hbm", "kernel": name, "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,
+            "traffic_source": traffic_src,
             "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
             "algorithmic_bytes_per_launch": round(per_kernel.get(name, 0) / max(launches, 1)),
             "per_hit": {"examined_bases_E": round(e_all, 2), "examined_by_filter": round(e_flt, 2),
@@ -228,6 +230,23 @@ def main():
     E.ShutdownProcessor()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def measured_traffic(prof_name):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
+    separate runs, gfx950 correction: see tools/traffic_json.py).  bench.py cannot profile itself, so it quotes the
+    newest profiles/rNN/traffic.json collected with tools/profile_bench.sh on this same default workload; null if absent."""
+    import glob
+    kernel = {"extend_filter": "extend_filter_kernel", "extend_exact": "extend_exact_kernel",
+              "expand_hits": "expand_hits_kernel", "seed_lookup": "seed_lookup_kernel"}.get(prof_name)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
+    if not kernel or not files:
+        return None, None
+    try:
+        t = json.load(open(files[-1]))
+        return t[kernel]["hbm_bytes"], os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
 
 
 def dry_run(args, rank, world, dist, torch, shard):

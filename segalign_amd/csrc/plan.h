@@ -2,7 +2,7 @@
 #pragma once
 #include <stdint.h>
 namespace sa {
-constexpr uint32_t PLAN_MAX_ITER = 240;
+constexpr uint32_t PLAN_MAX_ITER = 1000;
 struct IterPlan {
     uint64_t num_hits;                 // inclusive prefix of the last seed (:716)
     uint32_t num_iter;                 // iterations to run (0 when there is nothing to do)

@@ -99,6 +99,7 @@ void launch_sort(const HspRec* in, HspRec* out, size_t n, SortOrder order, void*
 // keep[i] = i == 0 || seg differs || !pred(in[i-1], in[i]).  One workgroup walks the (small) array in tiles and
 // carries the running output offset; ballot + popcount gives the in-tile rank.
 constexpr int UNQ_THREADS = 1024;
+constexpr int UNQ_ITEMS = 8;  // consecutive records per thread per tile
 
 __global__ __launch_bounds__(UNQ_THREADS) void unique_kernel(const HspRec* __restrict__ in, HspRec* __restrict__ out,
                                                              uint32_t n, int exact, uint32_t* __restrict__ out_count) {
@@ -107,24 +108,39 @@ __global__ __launch_bounds__(UNQ_THREADS) void unique_kernel(const HspRec* __res
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < n; base += UNQ_THREADS) {
-        const uint32_t i = base + threadIdx.x;
-        bool keep = false;
-        HspRec cur;
-        if (i < n) {
-            cur = in[i];
-            if (i == 0) keep = true;
-            else {
-                const HspRec prev = in[i - 1];
-                keep = (prev.seg != cur.seg) || !(exact ? hsp_same(prev, cur) : hsp_contained(prev, cur));
+    for (uint32_t base = 0; base < n; base += UNQ_THREADS * UNQ_ITEMS) {
+        const uint32_t i0 = base + threadIdx.x * UNQ_ITEMS;
+        HspRec rec[UNQ_ITEMS];
+        uint32_t keepmask = 0;
+        HspRec prev;
+        prev.ref_start = prev.query_start = prev.len = 0; prev.score = 0; prev.seg = 0xFFFFFFFFu;
+        if (i0 > 0 && i0 < n) prev = in[i0 - 1];
+#pragma unroll
+        for (int j = 0; j < UNQ_ITEMS; j++) {
+            const uint32_t i = i0 + j;
+            if (i < n) {
+                rec[j] = in[i];
+                const bool keep = (i == 0) || (prev.seg != rec[j].seg) ||
+                                  !(exact ? hsp_same(prev, rec[j]) : hsp_contained(prev, rec[j]));
+                keepmask |= keep ? (1u << j) : 0u;
+                prev = rec[j];
             }
         }
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(m);
+        const uint32_t mine = (uint32_t)__builtin_popcount(keepmask);
+        // wave inclusive scan of the per-thread counts, then block offsets
+        uint32_t inc = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) wave_cnt[wave] = inc;
         __syncthreads();
-        uint32_t off = carry;
+        uint32_t off = carry + inc - mine;
         for (int w = 0; w < wave; w++) off += wave_cnt[w];
-        if (keep) out[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = cur;
+#pragma unroll
+        for (int j = 0; j < UNQ_ITEMS; j++)
+            if ((keepmask >> j) & 1u) out[off++] = rec[j];
         __syncthreads();
         if (threadIdx.x == 0) {
             uint32_t t = 0;

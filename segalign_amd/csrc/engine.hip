@@ -210,7 +210,7 @@ static int64_t g_max_seeds = 0;
 static int64_t g_max_hits = 0;
 static bool g_max_hits_overridden = false;
 static bool g_count_examined = false;
-static int g_fin_batch = 32;      // SEGALIGN_AMD_FIN_BATCH
+static int g_fin_batch = 48;      // SEGALIGN_AMD_FIN_BATCH
 static int g_bufs_per_wave = 8;   // SEGALIGN_AMD_BUFS_PER_WAVE
 static int g_long_cap = 128;      // SEGALIGN_AMD_LONG_CAP: bases per side before a hit goes to the long kernel
 static int g_long_blocks = 1792;  // SEGALIGN_AMD_LONG_BLOCKS: grid of the long kernel (4 waves per block)

@@ -229,9 +229,11 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_filter_kernel(ExtendArgs a
     int phase = PH_FIN;  // "finished" with nothing to emit: the first trip refills every lane
     bool has_hit = false, forward = false;
     uint32_t ref_loc = 0, query_loc = 0, hidx = 0;
-    uint32_t roff = 0, qoff = 0;            // byte offsets (from the padded bases) of the next 8-byte window
-    int dstep = 8;                          // +8 on the right side, -8 on the left
-    uint32_t sel_lo = 0x03020100u, sel_hi = 0x07060504u;  // v_perm selectors: identity (right) / byte reversal (left)
+    uint32_t roff = 0, qoff = 0;            // byte offsets (from the padded bases) of the next 16-byte window
+    int dstep = 16;                         // +16 on the right side, -16 on the left
+    uint32_t bsel = 0x03020100u;            // v_perm selector: identity (right) / byte reversal inside a dword (left)
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;  // the window: 16 matrix indices in walking order; two trips consume it
+    bool half = false;                      // false: fetch a new window and use (w0,w1); true: use the held (w2,w3)
     int remaining = 0;                      // in-range positions left on this side
     uint32_t walked = 0;                    // bases walked on this side
     int score = 0, best = 0, bestR = 0;
@@ -241,12 +243,22 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_filter_kernel(ExtendArgs a
     for (;;) {
         // ================= 1. advance every live lane by one 8-base chunk =================
         if (phase < PH_FIN) {
-            uint32_t xlo = 0, xhi = 0;
-            if (remaining > 0) {
-                const uint64_t x = load8u(R8b + roff) | load8u(Qb + qoff);  // 8 matrix indices r<<3|q
-                xlo = __builtin_amdgcn_perm((uint32_t)(x >> 32), (uint32_t)x, sel_lo);  // byte j <-> offset +j on both sides
-                xhi = __builtin_amdgcn_perm((uint32_t)(x >> 32), (uint32_t)x, sel_hi);
+            // One 16-byte window per sequence feeds two trips: the 8-byte-per-trip form made every lane load a
+            // separate L1 miss (the L1 is thrashed by 16 waves x 64 random lines), i.e. twice the L2 requests.
+            if (remaining > 0 && !half) {
+                const uint4 rw = load16u(R8b + roff), qw = load16u(Qb + qoff);
+                const uint32_t o0 = rw.x | qw.x, o1 = rw.y | qw.y, o2 = rw.z | qw.z, o3 = rw.w | qw.w;  // 16 indices r<<3|q
+                const bool left = dstep < 0;  // walking order: the left side reverses dwords and bytes
+                w0 = __builtin_amdgcn_perm(0u, left ? o3 : o0, bsel);
+                w1 = __builtin_amdgcn_perm(0u, left ? o2 : o1, bsel);
+                w2 = __builtin_amdgcn_perm(0u, left ? o1 : o2, bsel);
+                w3 = __builtin_amdgcn_perm(0u, left ? o0 : o3, bsel);
+                roff += (uint32_t)dstep;
+                qoff += (uint32_t)dstep;
             }
+            uint32_t xlo = half ? w2 : w0, xhi = half ? w3 : w1;
+            if (remaining <= 0) { xlo = 0; xhi = 0; }
+            half = !half;
             if (remaining < 8) {  // sequence edge inside this window: terminators from byte `remaining` on
                 const uint64_t t = remaining <= 0 ? TERM_ALL : (TERM_ALL << (8 * remaining));
                 xlo |= (uint32_t)t;
@@ -278,19 +290,17 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_filter_kernel(ExtendArgs a
                 if (COUNT_EXAMINED) ex_hit += ex;
                 dropped = score < (DEAD >> 1);
             }
-            roff += (uint32_t)dstep;
-            qoff += (uint32_t)dstep;
             remaining -= 8;
             walked += 8;
             if (dropped) {
                 if (phase == PH_RIGHT) {  // -> left side (:457-476): anchor-1, anchor-2, ...
                     bestR = best;
                     phase = PH_LEFT;
-                    roff = ref_loc + BIAS - 8u;   // bytes loc-8 .. loc-1 ; reversed: byte 0 <-> offset 1
-                    qoff = query_loc + BIAS - 8u;
-                    dstep = -8;
-                    sel_lo = 0x04050607u;
-                    sel_hi = 0x00010203u;
+                    roff = ref_loc + BIAS - 16u;  // bytes loc-16 .. loc-1 ; reversed: byte 0 <-> offset 1
+                    qoff = query_loc + BIAS - 16u;
+                    dstep = -16;
+                    bsel = 0x00010203u;
+                    half = false;
                     remaining = (int)min(min(ref_loc, query_loc), 0x7fffffffu);  // offsets 1..lim are in range (:482)
                     walked = 0;
                     score = 0;
@@ -373,9 +383,9 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_filter_kernel(ExtendArgs a
                         phase = PH_RIGHT;  // :299-324
                         roff = ref_loc + BIAS;
                         qoff = query_loc + BIAS;
-                        dstep = 8;
-                        sel_lo = 0x03020100u;
-                        sel_hi = 0x07060504u;
+                        dstep = 16;
+                        bsel = 0x03020100u;
+                        half = false;
                         remaining = (ref_loc < a.ref_len && query_loc < a.query_len)
                                         ? (int)min(min(a.ref_len - ref_loc, a.query_len - query_loc), 0x7fffffffu) : 0;
                         walked = 0;

@@ -13,6 +13,12 @@ __device__ __forceinline__ uint64_t load8u(const uint8_t* p) {  // unaligned 8-b
     return v;
 }
 
+__device__ __forceinline__ uint4 load16u(const uint8_t* p) {  // unaligned 16-byte load (one global_load_dwordx4)
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+
 // low 2 bits of each of the 8 bytes of w -> 16 packed bits (byte 0 -> bits 1:0)
 __device__ __forceinline__ uint32_t pack2(uint64_t w) {
     uint64_t x = w & 0x0303030303030303ull;

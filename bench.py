@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--chunk", type=int, default=250_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU baseline budget")
+    ap.add_argument("--host-threads", type=int, default=2,
+                    help="host threads issuing SeedAndFilter calls (the reference runs one TBB seeder body per core; "
+                         "the engine has 2 slots per device so one call's syncs overlap another call's kernels)")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU-only rehearsal of the launch/shard/reduce/JSON contract (gloo, no engine, no GPU)")
     return ap.parse_args()
@@ -104,17 +107,29 @@ def main():
     intervals = shard.plan_intervals(query.size, seed_size, args.interval)
     q_block_len = query.size - seed_size  # q_len handed to the seeder (main.cpp:708)
 
+    import threading
+
     def run_interval(iv, collect=None):
         bases = iv[1] - iv[0]
-        hsps = 0
-        for rev in (False, True):
-            for (a, b) in shard.chunks_of(iv, args.chunk, q_block_len, rev):
+        jobs = [(a, b, rev) for rev in (False, True) for (a, b) in shard.chunks_of(iv, args.chunk, q_block_len, rev)]
+        results = [None] * len(jobs)
+
+        def work(tid):  # ctypes releases the GIL inside the engine call
+            for j in range(tid, len(jobs), nthreads):
+                a, b, rev = jobs[j]
                 out = E.SeedAndFilterRange(a, b, rev, 0)
-                if out.size:
-                    hsps += out.size - 1
-                if collect is not None:
-                    collect.append(E.last_call_stats())
-        return bases, hsps
+                results[j] = (out.size - 1 if out.size else 0, E.last_call_stats() if collect is not None else None)
+
+        nthreads = max(1, args.host_threads)
+        if nthreads == 1:
+            work(0)
+        else:
+            ths = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+            [t.start() for t in ths]
+            [t.join() for t in ths]
+        if collect is not None:
+            collect.extend(r[1] for r in results)
+        return bases, sum(r[0] for r in results)
 
     my = shard.shard(intervals, rank, world) or intervals
 
@@ -156,6 +171,15 @@ def main():
     # ---------------- roofline of the dominant kernel (rank 0's own launches) ----------------
     roof = None
     if rank == 0 and prof:
+        # the same kernel without a second call overlapping it: one extra (untimed) interval issued by ONE host thread
+        saved_threads, args.host_threads = args.host_threads, 1
+        E.profile_reset()
+        E.profile_enable(True)
+        solo_stats = []
+        run_interval(my[0], solo_stats)
+        E.profile_enable(False)
+        solo = E.profile_entries()
+        args.host_threads = saved_threads
         # per-hit ratios from one instrumented (untimed) interval: deterministic, identical work
         E.set_count_examined(True)
         sample = []
@@ -188,10 +212,19 @@ def main():
         ext_gbs = gbs(ext_bytes, ["extend_filter", "extend_exact", "extend_entropy"])
         look_gbs = gbs(look_bytes, ["seed_lookup", "expand_hits"])
         traffic, traffic_src = measured_traffic(name)
+        single = None
+        if name == "extend_filter" and name in solo and solo[name][1]:
+            sH = sum(x["num_hits"] for x in solo_stats)
+            sC = sum(x["num_candidates"] for x in solo_stats)
+            sb = 8.0 * sH + 2.0 * e_flt * sH + 12.0 * sC
+            sg = sb / (solo[name][0] * 1e-3) / 1e9
+            single = {"avg_launch_us": round(1e3 * solo[name][0] / solo[name][1], 2), "achieved": round(sg, 1),
+                      "frac": round(sg / HBM_PEAK_GBS, 4),
+                      "note": "same kernel, one call in flight (no overlap with a second stream); untimed extra interval"}
         roof = {
             "bound": "hbm", "kernel": name, "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,
-            "traffic_source": traffic_src,
+            "traffic_source": traffic_src, "calls_in_flight": max(1, args.host_threads), "single_stream": single,
             "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
             "algorithmic_bytes_per_launch": round(per_kernel.get(name, 0) / max(launches, 1)),
             "per_hit": {"examined_bases_E": round(e_all, 2), "examined_by_filter": round(e_flt, 2),

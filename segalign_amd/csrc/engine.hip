@@ -94,7 +94,9 @@ struct SeqBuf {  // encoded sequence with SEQ_PAD guard bytes on both sides
         release(tag);
         size_t bytes = (size_t)n + 2 * SEQ_PAD + 64;  // +64: the k-mer window reads 32 bytes from any position
         alloc = (uint8_t*)dev_malloc(bytes, tag);
-        check_memcpy(hipMemsetAsync(alloc, 7 /*E*/, bytes, s), tag);
+        // guard bytes carry bit 6: OR-ed into a matrix index they select a terminator entry of the extension kernels'
+        // 128-entry table, so a window that runs over a block edge stops the walk without any bounds arithmetic
+        check_memcpy(hipMemsetAsync(alloc, 0x40, bytes, s), tag);
         codes = alloc + SEQ_PAD;
         len = n;
     }

@@ -234,7 +234,6 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_filter_kernel(ExtendArgs a
     uint32_t bsel = 0x03020100u;            // v_perm selector: identity (right) / byte reversal inside a dword (left)
     uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;  // the window: 16 matrix indices in walking order; two trips consume it
     bool half = false;                      // false: fetch a new window and use (w0,w1); true: use the held (w2,w3)
-    int remaining = 0;                      // in-range positions left on this side
     uint32_t walked = 0;                    // bases walked on this side
     int score = 0, best = 0, bestR = 0;
     uint32_t ex_hit = 0;
@@ -245,7 +244,7 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_filter_kernel(ExtendArgs a
         if (phase < PH_FIN) {
             // One 16-byte window per sequence feeds two trips: the 8-byte-per-trip form made every lane load a
             // separate L1 miss (the L1 is thrashed by 16 waves x 64 random lines), i.e. twice the L2 requests.
-            if (remaining > 0 && !half) {
+            if (!half) {
                 const uint4 rw = load16u(R8b + roff), qw = load16u(Qb + qoff);
                 const uint32_t o0 = rw.x | qw.x, o1 = rw.y | qw.y, o2 = rw.z | qw.z, o3 = rw.w | qw.w;  // 16 indices r<<3|q
                 const bool left = dstep < 0;  // walking order: the left side reverses dwords and bytes
@@ -256,14 +255,9 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_filter_kernel(ExtendArgs a
                 roff += (uint32_t)dstep;
                 qoff += (uint32_t)dstep;
             }
-            uint32_t xlo = half ? w2 : w0, xhi = half ? w3 : w1;
-            if (remaining <= 0) { xlo = 0; xhi = 0; }
+            // positions outside the block read guard bytes (0x40): their index selects a terminator entry (:332,:482)
+            const uint32_t xlo = half ? w2 : w0, xhi = half ? w3 : w1;
             half = !half;
-            if (remaining < 8) {  // sequence edge inside this window: terminators from byte `remaining` on
-                const uint64_t t = remaining <= 0 ? TERM_ALL : (TERM_ALL << (8 * remaining));
-                xlo |= (uint32_t)t;
-                xhi |= (uint32_t)(t >> 32);
-            }
             bool dropped;
             if (FAST && !COUNT_EXAMINED) {
                 int t = score, m = best, dmax = 0;
@@ -290,7 +284,6 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_filter_kernel(ExtendArgs a
                 if (COUNT_EXAMINED) ex_hit += ex;
                 dropped = score < (DEAD >> 1);
             }
-            remaining -= 8;
             walked += 8;
             if (dropped) {
                 if (phase == PH_RIGHT) {  // -> left side (:457-476): anchor-1, anchor-2, ...
@@ -301,7 +294,6 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_filter_kernel(ExtendArgs a
                     dstep = -16;
                     bsel = 0x00010203u;
                     half = false;
-                    remaining = (int)min(min(ref_loc, query_loc), 0x7fffffffu);  // offsets 1..lim are in range (:482)
                     walked = 0;
                     score = 0;
                     best = 0;
@@ -377,6 +369,9 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_filter_kernel(ExtendArgs a
                         skip = !(ref_loc >= a.rm_win_start && ref_loc <= a.rm_win_end);
                     bestR = 0;
                     best = 0;
+                    // anchors beyond the block (only possible with hand-made seed words) are outside the guard bytes'
+                    // reach: never extended (the reference would read out of bounds on the left side there)
+                    if (ref_loc > a.ref_len || query_loc > a.query_len) skip = true;
                     if (skip) {  // both loops skipped: total 0
                         phase = PH_FIN;
                     } else {
@@ -386,8 +381,6 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_filter_kernel(ExtendArgs a
                         dstep = 16;
                         bsel = 0x03020100u;
                         half = false;
-                        remaining = (ref_loc < a.ref_len && query_loc < a.query_len)
-                                        ? (int)min(min(a.ref_len - ref_loc, a.query_len - query_loc), 0x7fffffffu) : 0;
                         walked = 0;
                         score = 0;
                     }

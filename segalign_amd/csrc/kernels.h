@@ -8,7 +8,8 @@ namespace sa {
 
 // Sequences live in HBM as one code byte per base (A0 C1 G2 T3 L4 N5 X6 E7, common/parameters.h:4-13) inside
 // an allocation padded by SEQ_PAD bytes on both sides, so the 8-byte window loads of the extension kernel may
-// over-read without faulting (the over-read bytes are never scored: every position is bounds-checked).
+// over-read without faulting.  Guard bytes are 0x40: bit 6 of a matrix index selects a terminator table entry, so a
+// walk that leaves the block stops exactly at the edge (src/seed_filter.cu:332,:482) with no bounds arithmetic.
 constexpr int SEQ_PAD = 64;
 
 constexpr int MAX_CARE = 16;  // seed weight limit; reference asserts 3 < kmer_size <= 15 (seed_pos_table.cu:51-52)

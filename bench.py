@@ -224,7 +224,12 @@ def main():
         roof = {
             "bound": "hbm", "kernel": name, "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,
-            "traffic_source": traffic_src, "calls_in_flight": max(1, args.host_threads), "single_stream": single,
+            "traffic_source": traffic_src,
+            # measured fabric traffic over the single-stream launch time: how close the kernel runs to the HBM limit in
+            # bytes it really moves (every 16-byte random window costs a 128-byte line, which `achieved` does not count)
+            "traffic_gbs_single_stream": (round(traffic / (single["avg_launch_us"] * 1e-6) / 1e9, 1)
+                                          if (traffic and single) else None),
+            "calls_in_flight": max(1, args.host_threads), "single_stream": single,
             "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
             "algorithmic_bytes_per_launch": round(per_kernel.get(name, 0) / max(launches, 1)),
             "per_hit": {"examined_bases_E": round(e_all, 2), "examined_by_filter": round(e_flt, 2),

@@ -48,5 +48,22 @@ def build_lib(force=False, verbose=False):
     return LIB_PATH
 
 
+HOST_SRC = os.path.join(HERE, "host", "segalign_host.cpp")
+HOST_BIN = os.path.join(HERE, "bin", "segalign_host")
+
+
+def build_host(force=False):
+    """The C++ host harness (FASTA -> .segments) on top of the C-ABI: plain g++ + zlib, links libsegalign_hip.so."""
+    build_lib()
+    os.makedirs(os.path.dirname(HOST_BIN), exist_ok=True)
+    hdr = os.path.join(HERE, "..", "include", "segalign_amd.h")
+    if force or _newer(HOST_SRC, HOST_BIN) or _newer(hdr, HOST_BIN) or _newer(LIB_PATH, HOST_BIN):
+        subprocess.check_call(["g++", "-std=c++11", "-O2", "-pthread", "-I", os.path.join(HERE, "..", "include"), HOST_SRC,
+                               "-o", HOST_BIN, "-L", LIB_DIR, "-lsegalign_hip", "-lz", "-Wl,-rpath," + LIB_DIR,
+                               "-Wl,-rpath,/opt/rocm/lib"])
+    return HOST_BIN
+
+
 if __name__ == "__main__":
     print(build_lib(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv))

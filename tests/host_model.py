@@ -1,0 +1,125 @@
+"""Test-side restatement of the reference HOST around the engine: arena layout, block/interval planning, the seeder
+body and the segment printer -- src/main.cpp:320-549, src/seeder.cpp:12-127, src/segment_printer.cpp:11-173 --
+driven by the oracle's SeedAndFilter.  Returns {file name: text} and the lastz command lines, i.e. exactly what the
+reference binary would leave on disk / print for the same FASTA input.  Used to check segalign_amd/host/segalign_host."""
+import bisect
+
+import numpy as np
+
+
+def write_fasta(path, records, width=60):
+    with open(path, "w") as f:
+        for name, seq in records:
+            f.write(">%s some description\n" % name)
+            s = bytes(seq).decode()
+            for i in range(0, len(s), width):
+                f.write(s[i:i + width] + "\n")
+
+
+class Arena:
+    def __init__(self, records, seq_block_size, seed_size, interval, is_query):
+        self.buf = bytearray()
+        self.chr_name, self.chr_start, self.chr_len = [], [], []
+        self.block_start, self.block_len, self.block_names = [0], [], [[]]
+        self.rc = bytearray()
+        self.rc_name, self.rc_start, self.rc_len = [], [], []
+        self.intervals = []
+        block_chrs, seq_block_len, seq_block_start = [], 0, 0
+
+        def close(length):
+            nonlocal block_chrs
+            self.block_len.append(length)
+            if is_query:
+                for c in reversed(block_chrs):  # main.cpp:369-374
+                    self.rc_name.append(self.chr_name[c])
+                    self.rc_start.append(2 * seq_block_start + length - self.chr_start[c] - self.chr_len[c])
+                    self.rc_len.append(self.chr_len[c])
+                comp = bytes.maketrans(b"ACGTacgt", b"TGCAtgca")
+                blk = bytes(self.buf[seq_block_start:seq_block_start + length])
+                self.rc[seq_block_start:seq_block_start + length] = blk[::-1].translate(comp)
+                end_pos = length - seed_size
+                self.intervals.append([(s, min(end_pos, s + interval)) for s in range(0, max(end_pos, 0), interval)]
+                                      if length > seed_size else [])
+
+        for name, seq in records:
+            self.block_names[-1].append(name)
+            c = len(self.chr_name)
+            self.chr_name.append(name)
+            self.chr_start.append(len(self.buf))
+            self.chr_len.append(len(seq))
+            block_chrs.append(c)
+            self.buf += bytes(seq)
+            seq_block_len += len(seq)
+            if seq_block_len > seq_block_size:  # main.cpp:359
+                close(seq_block_len)
+                seq_block_start = len(self.buf)
+                self.block_start.append(seq_block_start)
+                self.block_names.append([])
+                seq_block_len, block_chrs = 0, []
+            else:
+                self.buf += b"&"
+                seq_block_len += 1
+        if seq_block_len > 0:
+            close(seq_block_len - 1)
+        else:
+            self.block_start.pop()
+            self.block_names.pop()
+
+
+def expected_outputs(O, target_records, query_records, shape="TTT0T00TT00T0T0TTTT", transition=True, step=1, xdrop=910,
+                     hspthresh=3000, noentropy=False, chunk=250000, interval=10000000, seq_block_size=500000000,
+                     gapped=True, data_folder="./", output_format="maf-", ydrop=9430, strand="both"):
+    seed_size = len(shape)
+    R = Arena(target_records, seq_block_size, seed_size, interval, False)
+    Q = Arena(query_records, seq_block_size, seed_size, interval, True)
+    kmer = O.generate_shape_pos(shape)
+    sub_mat = O.build_sub_mat(xdrop)
+    files, cmds = {}, []
+    for k, names in enumerate(R.block_names):
+        files["ref_block%d.name" % k] = "".join(n + "\n" for n in names)
+    for k, names in enumerate(Q.block_names):
+        files["query_block%d.name" % k] = "".join(n + "\n" for n in names)
+    for rb, (rs, rl) in enumerate(zip(R.block_start, R.block_len)):
+        tblock = bytes(R.buf[rs:rs + rl])
+        ref_codes = O.encode(tblock)
+        index, pos = O.generate_seed_pos_table(tblock, 0, rl, step, seed_size, kmer)
+        for qb, (qs, ql) in enumerate(zip(Q.block_start, Q.block_len)):
+            qblock = bytes(Q.buf[qs:qs + ql])
+            qrc_block = bytes(Q.rc[qs:qs + ql])
+            q_codes, qrc_codes = O.encode_rev_comp(qblock)
+            q_len = ql - seed_size
+            for i, (a, b) in enumerate(Q.intervals[qb]):
+                hs = {False: [], True: []}
+                for rev in (False, True):
+                    if (not rev and strand not in ("plus", "both")) or (rev and strand not in ("minus", "both")):
+                        continue
+                    s, e = (q_len - b, q_len - a) if rev else (a, b)  # seeder.cpp:33-34
+                    for c in range(s, e, chunk):
+                        seeds = O.make_seeds(qrc_block if rev else qblock, 0, c, min(c + chunk, e), seed_size, kmer, transition)
+                        if seeds.size == 0:
+                            continue  # seeder.cpp:76
+                        segs, _ = O.seed_and_filter(ref_codes, qrc_codes if rev else q_codes, index, pos, seeds, sub_mat,
+                                                    seed_size=seed_size, xdrop=xdrop, hspthresh=hspthresh, noentropy=noentropy)
+                        hs[rev].extend(segs[1:].tolist())
+                for rev in (False, True):  # segment_printer.cpp:70-168
+                    if not hs[rev]:
+                        continue
+                    base = "tmp%d.block%d.r%d.%s" % (i + 1, qb, rs, "minus" if rev else "plus")
+                    names = Q.rc_name if rev else Q.chr_name
+                    starts = Q.rc_start if rev else Q.chr_start
+                    lines = []
+                    for (r0, q0, ln, sc) in (reversed(hs[rev]) if rev else hs[rev]):
+                        seg_r, seg_q = r0 + rs, q0 + qs
+                        ri = bisect.bisect_right(R.chr_start, seg_r) - 1
+                        qi = bisect.bisect_right(starts, seg_q) - 1
+                        lines.append("%s\t%d\t%d\t%s\t%d\t%d\t%s\t%d\n" % (
+                            R.chr_name[ri], seg_r + 1 - R.chr_start[ri], seg_r + ln + 1 - R.chr_start[ri], names[qi],
+                            seg_q + 1 - starts[qi], seg_q + ln + 1 - starts[qi], "-" if rev else "+", sc))
+                    files[base + ".segments"] = "".join(lines)
+                    if gapped:
+                        cmds.append("lastz %sref.2bit[nameparse=darkspace][multiple][subset=ref_block%d.name] "
+                                    "%squery.2bit[nameparse=darkspace][subset=query_block%d.name] --format=%s --ydrop=%d "
+                                    "--gappedthresh=%d --strand=%s --segments=%s.segments --output=%s.%s 2> %s.err" % (
+                                        data_folder, rb, data_folder, qb, output_format, ydrop, hspthresh,
+                                        "minus" if rev else "plus", base, base, output_format, base))
+    return files, cmds

@@ -580,6 +580,9 @@ static size_t saf_impl(const orc_saf_params* p, const uint64_t* seeds, size_t nu
             if (iter_num_hits > 0 && iter_num_seeds > 0) {
                 orc_segment* hsp = (orc_segment*)malloc((size_t)iter_num_hits * sizeof(orc_segment));
                 /* find_hits :184-230: k-th bucket entry of seed s -> slot prefix_incl[s]-1-k-start_hit */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static, 4096) num_threads(p->num_threads > 0 ? p->num_threads : 1)
+#endif
                 for (int64_t s = start_seed_index; s <= lp; s++) {
                     uint32_t seed = (uint32_t)(seeds[s] >> 32);
                     uint32_t qloc = (uint32_t)(seeds[s] & 0xFFFFFFFFu) + p->seed_size; /* :204 */
@@ -615,7 +618,10 @@ static size_t saf_impl(const orc_saf_params* p, const uint64_t* seeds, size_t nu
                 examined += ex_local;
                 /* inclusive_scan(done) :769 + compress_output :654-680 = order-preserving compaction */
                 size_t na = 0;
-                for (uint64_t h = 0; h < iter_num_hits; h++) na += done[h];
+#ifdef _OPENMP
+#pragma omp parallel for reduction(+ : na) num_threads(p->num_threads > 0 ? p->num_threads : 1)
+#endif
+                for (int64_t h = 0; h < (int64_t)iter_num_hits; h++) na += done[h];
                 survivors += na;
                 if (na > 0) {
                     orc_segment* red = (orc_segment*)malloc(na * sizeof(orc_segment));

@@ -138,7 +138,8 @@ static int prof_id(const char* name) {
 // ------------------------------------------------------------------------------------------------------------------
 // per-device state
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int SLOTS_PER_DEVICE = 2;  // calls in flight per device (the reference allows one: token == device)
+constexpr int MAX_SLOTS_PER_DEVICE = 4;
+static int SLOTS_PER_DEVICE = 2;  // calls in flight per device (the reference allows one: token == device); SEGALIGN_AMD_SLOTS
 
 struct Counters {  // device-side scalars of one slot
     uint32_t survivors;
@@ -192,7 +193,7 @@ struct DevCtx {
     uint32_t num_index = 0;
     uint32_t nkeys = 0;
     SeqBuf query[SA_BUFFER_DEPTH], query_rc[SA_BUFFER_DEPTH];
-    Slot slots[SLOTS_PER_DEVICE];
+    Slot slots[MAX_SLOTS_PER_DEVICE];
 };
 
 static int g_ndev = 0;
@@ -668,6 +669,7 @@ int sa_initialize_interface(int num_gpu) {  // seed_filter_interface.cu:49-80
 void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_size, const int* sub_mat, int xdrop,
                              int hspthresh, int noentropy) {  // src/seed_filter.cu:830-897
     require_init("InitializeProcessor");
+    if (const char* e = getenv("SEGALIGN_AMD_SLOTS")) SLOTS_PER_DEVICE = std::max(1, std::min(MAX_SLOTS_PER_DEVICE, atoi(e)));
     if (const char* e = getenv("SEGALIGN_AMD_FIN_BATCH")) g_fin_batch = std::max(1, std::min(64, atoi(e)));
     if (const char* e = getenv("SEGALIGN_AMD_BUFS_PER_WAVE")) g_bufs_per_wave = std::max(1, atoi(e));
     if (const char* e = getenv("SEGALIGN_AMD_LONG_CAP")) g_long_cap = std::max(0, atoi(e)) & ~7;
@@ -714,7 +716,7 @@ void sa_shutdown_processor(void) {  // src/seed_filter.cu:932-940
     for (auto* dc : g_dev) {
         check_set_device(dc->dev, "ShutdownProcessor");
         hipDeviceSynchronize();
-        for (int k = 0; k < SLOTS_PER_DEVICE; k++) slot_destroy(dc->slots[k]);
+        for (int k = 0; k < MAX_SLOTS_PER_DEVICE; k++) if (dc->slots[k].stream) slot_destroy(dc->slots[k]);
         dc->ref.release("d_ref_seq");
         dc->ref8.release("d_ref_seq rows");
         dc->ref_rc.release("d_seq_rc");

@@ -625,6 +625,8 @@ void sa_select_devices(const int* ids, int n) {
     for (int i = 0; i < n; i++) g_selected.push_back(ids[i]);
 }
 
+void sa_shutdown_processor(void);
+
 int sa_initialize_interface(int num_gpu) {  // seed_filter_interface.cu:49-80
     int n = 0;
     hipError_t err = hipGetDeviceCount(&n);
@@ -648,9 +650,7 @@ int sa_initialize_interface(int num_gpu) {  // seed_filter_interface.cu:49-80
         exit(10);
     }
     fprintf(stderr, "Using %d GPU(s)\n", use);
-    for (auto* d : g_dev) delete d;
-    g_dev.clear();
-    g_tokens.clear();
+    if (!g_dev.empty()) sa_shutdown_processor();  // re-initialisation: release the previous contexts first
     g_ndev = use;
     for (int g = 0; g < use; g++) {
         const int ord = g_selected.empty() ? g : g_selected[g];

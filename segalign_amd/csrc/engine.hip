@@ -886,6 +886,7 @@ size_t sa_seed_and_filter(const uint64_t* seeds, size_t num_seeds, int rev, uint
     require_init("SeedAndFilter");
     if ((int64_t)num_seeds > g_max_seeds) {  // :688-692
         printf("MAX_SEEDS exceeded\n");
+        fflush(stdout);
         fprintf(stderr, "Assertion `num_seeds <= MAX_SEEDS' failed.\n");
         abort();
     }
@@ -967,6 +968,7 @@ size_t sa_rm_seed_and_filter(const uint64_t* seeds, size_t num_seeds, int rev, u
     require_init("SeedAndFilter");
     if ((int64_t)num_seeds > g_max_seeds) {
         printf("MAX_SEEDS exceeded\n");
+        fflush(stdout);
         fprintf(stderr, "Assertion `num_seeds <= MAX_SEEDS' failed.\n");
         abort();
     }

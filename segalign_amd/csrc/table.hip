@@ -33,17 +33,20 @@ __global__ __launch_bounds__(256) void table_fill_kernel(const uint8_t* __restri
     }
 }
 
-// Canonical order: ascending positions inside each bucket.  One lane per bucket for small buckets (the common
-// case: mean occupancy T/4^k), one wave per bucket (odd-even transposition over LDS-free registers is not
-// worth it) falls back to a simple in-place shell sort by a single lane for the rare large bucket.
+// Canonical order: ascending positions inside each bucket (the reference's order is atomic arrival order, hazard H7;
+// no consumer depends on it).  One lane sorts one bucket -- right for the typical occupancy T/4^k of a few entries.
+// Buckets above SORT_MAX (low-complexity repeats: poly-A, microsatellites) keep their arrival order: a single lane
+// would need O(n^1.3) steps on them and the order cannot influence any result.
+constexpr uint32_t SORT_MAX = 512;
+
 __global__ __launch_bounds__(256) void table_sort_buckets_kernel(const uint32_t* __restrict__ bucket_start, uint32_t nkeys,
                                                                  uint32_t* __restrict__ pos_table) {
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nkeys; k += gridDim.x * blockDim.x) {
         uint32_t b = bucket_start[k], e = bucket_start[k + 1];
         uint32_t n = e - b;
-        if (n < 2) continue;
+        if (n < 2 || n > SORT_MAX) continue;
         uint32_t* a = pos_table + b;
-        // shell sort (gaps n/2, n/4, ... 1): O(n^1.5) worst case, insertion sort for the tiny typical bucket
+        // shell sort (gaps n/2, n/4, ... 1); plain insertion sort for the tiny typical bucket
         for (uint32_t gap = n > 8 ? n / 2 : 1; gap > 0; gap /= 2) {
             for (uint32_t i = gap; i < n; i++) {
                 uint32_t v = a[i];

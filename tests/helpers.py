@@ -66,3 +66,14 @@ class Case:
 
 def seg_equal(a, b):
     return a.shape == b.shape and bool(np.all(a == b))
+
+
+def canonical_pos_table(index, pos):
+    """Positions sorted inside every bucket (the engine leaves very large buckets in arrival order; bucket order is
+    nondeterministic in the reference and cannot influence any result, hazard H7)."""
+    import numpy as np
+    index = np.asarray(index, dtype=np.int64)
+    starts = np.concatenate([[0], index[:-1]])
+    bucket_of = np.repeat(np.arange(index.size, dtype=np.int64), index - starts)
+    order = np.lexsort((np.asarray(pos, dtype=np.int64), bucket_of))
+    return np.asarray(pos)[order]

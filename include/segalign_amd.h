@@ -124,7 +124,9 @@ int sa_max_hits_for_mem(uint64_t total_global_mem);
 typedef struct sa_call_stats {
     uint64_t num_seeds;
     uint64_t num_hits;      /* H */
-    uint64_t num_survivors; /* A before dedup */
+    uint64_t num_survivors; /* records handed to the dedup stage: the reference's survivors (done = 1) minus the exact
+                               duplicates the chain shortcut never extends; equal to the reference count while
+                               sa_set_count_examined(1) is on (the shortcut is off then) */
     uint64_t num_anchors;   /* returned HSPs */
     uint64_t num_examined;  /* E: scored positions; only filled while sa_set_count_examined(1) */
     uint64_t num_examined_filter; /* positions scored by the filter kernel alone (same condition) */

@@ -150,6 +150,8 @@ struct Counters {  // device-side scalars of one slot
     unsigned long long examined_filter;  // positions the filter kernel scored (partial walks of candidates included)
     uint32_t n_long;  // candidates the filter forwarded to the exact kernel (this batch)
     uint32_t n_ent;   // entropy candidates (this batch)
+    uint32_t n_heads; // run heads of the chain shortcut (this batch)
+    uint32_t pad2;
 };
 
 struct Slot {
@@ -162,6 +164,8 @@ struct Slot {
     DevBuf<Hit> hits;
     DevBuf<HspRec> recA, recB;
     DevBuf<CandRec> cand_list;
+    DevBuf<CandRec> chain_tmp, chain_sorted;  // chain shortcut of the exact stage
+    DevBuf<uint32_t> chain_is_head, chain_heads, chain_bucket_cnt, chain_bucket_start;
     DevBuf<EntRec> ent_list;
     DevBuf<sa_segment_pair> out16;
     IterPlan* d_plan = nullptr;
@@ -219,6 +223,8 @@ static int g_long_cap = 128;      // SEGALIGN_AMD_LONG_CAP: bases per side befor
 static int g_long_blocks = 1792;  // SEGALIGN_AMD_LONG_BLOCKS: grid of the long kernel (4 waves per block)
 static int g_max_waves = 4096;    // SEGALIGN_AMD_MAX_WAVES: waves of the filter kernel (4 per SIMD saturate instruction issue)
 static int g_fast_filter = 0;     // derived in InitializeProcessor: xdrop >= 0 && 7*max(M) <= xdrop
+static int g_chain = 1;           // chain shortcut of the exact stage (SEGALIGN_AMD_NO_CHAIN=1 turns it off)
+constexpr uint32_t CHAIN_CAP = 1u << 20;  // candidates per batch the chain buffers hold; larger batches fall back
 static SeedShape g_shape = {0, 0, 0, {0}};
 static uint32_t g_query_len[SA_BUFFER_DEPTH] = {0, 0};
 
@@ -306,7 +312,9 @@ static void slot_destroy(Slot& s) {
     s.flag_prefix.release("flag_prefix"); s.prefix.release("prefix"); s.scan_temp.release("scan_temp");
     s.sort_temp.release("sort_temp"); s.hits.release("hits"); s.recA.release("recA"); s.recB.release("recB");
     s.out16.release("out16");
-    s.cand_list.release("candidate list"); s.ent_list.release("entropy list");
+    s.cand_list.release("candidate list");
+    s.chain_tmp.release("chain"); s.chain_sorted.release("chain"); s.chain_is_head.release("chain");
+    s.chain_heads.release("chain"); s.chain_bucket_cnt.release("chain"); s.chain_bucket_start.release("chain"); s.ent_list.release("entropy list");
     dev_free(s.d_plan, "plan"); dev_free(s.d_cnt, "counters");
     s.d_plan = nullptr; s.d_cnt = nullptr;
     if (s.h_plan) hipHostFree(s.h_plan);
@@ -330,6 +338,7 @@ struct CoreArgs {
     int rm;
     int rm_rev;
     uint32_t rm_win_start, rm_win_end;
+    uint32_t q_lo, q_hi;  // query positions of the seed words lie in [q_lo, q_hi) when the caller knows it (0,0 otherwise)
 };
 
 static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa_segment_pair** out) {
@@ -437,11 +446,31 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                 ea.max_waves = (uint32_t)g_max_waves;
                 ea.ent_blocks = 64;
                 sl->cand_list.ensure((size_t)std::max<uint64_t>(1u << 16, bh / 16), "candidate list");
+                // chain shortcut: valid for the plain X-drop recurrence (xdrop >= 0), not for the repeat masker's window
+                // skip, needs the 29-bit position field of its sort key, and is off while E is being counted
+                const bool chain = g_chain && !ca.rm && g_xdrop >= 0 && ca.query_len < (1u << 29) && !g_count_examined;
+                ea.chain_cap = chain ? CHAIN_CAP : 0u;
+                if (chain) {
+                    sl->chain_tmp.ensure(CHAIN_CAP, "chain candidates");
+                    sl->chain_sorted.ensure(CHAIN_CAP, "chain candidates");
+                    sl->chain_is_head.ensure(CHAIN_CAP, "chain flags");
+                    sl->chain_heads.ensure(CHAIN_CAP, "chain heads");
+                    sl->chain_bucket_cnt.ensure(chain_num_buckets(), "chain buckets");
+                    sl->chain_bucket_start.ensure(chain_num_buckets() + 1, "chain buckets");
+                    ea.chain_tmp = sl->chain_tmp.p;
+                    ea.chain_sorted = sl->chain_sorted.p;
+                    ea.chain_bucket_cnt = sl->chain_bucket_cnt.p;
+                    ea.chain_bucket_start = sl->chain_bucket_start.p;
+                    ea.chain_is_head = sl->chain_is_head.p;
+                    ea.chain_heads = sl->chain_heads.p;
+                    ea.chain_head_count = &sl->d_cnt->n_heads;
+                }
                 sl->ent_list.ensure((size_t)std::max<uint64_t>(1u << 16, bh / 32), "entropy list");
                 Counters before = *sl->h_cnt;  // counters as of the previous batch (zero for the first)
                 before.n_long = 0;
                 before.n_ent = 0;
-                check_memcpy(hipMemsetAsync(&sl->d_cnt->n_long, 0, 2 * sizeof(uint32_t), st), "counters");
+                before.n_heads = 0;
+                check_memcpy(hipMemsetAsync(&sl->d_cnt->n_long, 0, 4 * sizeof(uint32_t), st), "counters");
                 for (;;) {  // rerun the batch with larger lists if one overflowed (device writes are guarded)
                     ea.out = sl->recA.p;
                     ea.out_cap = (uint32_t)std::min<size_t>(sl->recA.cap, 0xFFFFFFFFu);
@@ -450,7 +479,13 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     ea.ent_list = sl->ent_list.p;
                     ea.ent_cap_recs = (uint32_t)std::min<size_t>(sl->ent_list.cap, 0xFFFFFFFFu);
                     { ProfScope p(sl, "extend_filter");  launch_extend_filter(ea, st); }
+                    if (ea.chain_cap) {
+                        check_memcpy(hipMemsetAsync(sl->chain_bucket_cnt.p, 0, chain_num_buckets() * sizeof(uint32_t), st), "chain buckets");
+                        { ProfScope p(sl, "chain_group"); launch_chain_group(ea, st); }
+                        { ProfScope p(sl, "chain_link");  launch_chain_link(ea, st); }
+                    }
                     { ProfScope p(sl, "extend_exact");   launch_extend_exact(ea, st); }
+                    if (ea.chain_cap) { ProfScope p(sl, "extend_exact_chain"); launch_extend_exact_chain(ea, st); }
                     { ProfScope p(sl, "extend_entropy"); launch_extend_entropy(ea, st); }
                     check_launch("expand/extend");
                     check_memcpy(hipMemcpyAsync(sl->h_cnt, sl->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st), "counters");
@@ -693,6 +728,7 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
         for (int i = 1; i < 64; i++) mx = std::max(mx, g_sub_mat[i]);
         g_fast_filter = (xdrop >= 0 && (int64_t)7 * std::max(mx, 0) <= (int64_t)xdrop) ? 1 : 0;
         if (getenv("SEGALIGN_AMD_NO_FAST_FILTER")) g_fast_filter = 0;
+        g_chain = getenv("SEGALIGN_AMD_NO_CHAIN") ? 0 : 1;
     }
     std::lock_guard<std::mutex> lk(g_mu);
     g_tokens.clear();
@@ -894,7 +930,7 @@ size_t sa_seed_and_filter(const uint64_t* seeds, size_t num_seeds, int rev, uint
     DevCtx* dc = g_dev[0];
     for (auto* d : g_dev) if (d->dev == sl->dev) dc = d;
     upload_seeds(sl, seeds, num_seeds);
-    CoreArgs ca = {rev ? dc->query_rc[buffer].codes : dc->query[buffer].codes, g_query_len[buffer], 0, 0, 0, 0};  // :762-767
+    CoreArgs ca = {rev ? dc->query_rc[buffer].codes : dc->query[buffer].codes, g_query_len[buffer], 0, 0, 0, 0, 0, 0};  // :762-767
     size_t n = saf_core(dc, sl, (uint32_t)num_seeds, ca, out);
     release_slot(sl);
     return n;
@@ -914,7 +950,7 @@ size_t sa_seed_and_filter_range(uint32_t start, uint32_t end, int rev, uint32_t 
     size_t n = 0;
     *out = nullptr;
     if (ns > 0) {  // seeder.cpp:76: the engine is only called for a non-empty seed vector
-        CoreArgs ca = {q, qlen, 0, 0, 0, 0};
+        CoreArgs ca = {q, qlen, 0, 0, 0, 0, start, end};
         n = saf_core(dc, sl, ns, ca, out);
     } else {
         prof_flush(sl);
@@ -976,7 +1012,7 @@ size_t sa_rm_seed_and_filter(const uint64_t* seeds, size_t num_seeds, int rev, u
     DevCtx* dc = g_dev[0];
     for (auto* d : g_dev) if (d->dev == sl->dev) dc = d;
     upload_seeds(sl, seeds, num_seeds);
-    CoreArgs ca = {rev ? dc->ref_rc.codes : dc->ref.codes, dc->ref.len, 1, rev ? 1 : 0, ref_start, ref_end};  // rm :805-810
+    CoreArgs ca = {rev ? dc->ref_rc.codes : dc->ref.codes, dc->ref.len, 1, rev ? 1 : 0, ref_start, ref_end, 0, 0};  // rm :805-810
     size_t n = saf_core(dc, sl, (uint32_t)num_seeds, ca, out);
     release_slot(sl);
     return n;

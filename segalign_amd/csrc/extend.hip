@@ -408,133 +408,351 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_filter_kernel(ExtendArgs a
 // =====================================================================================================================
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Exact two-sided extension of one anchor by a whole wave.  All results are wave-uniform.
 template <bool COUNT_EXAMINED, bool XDROP_NONNEG>
-__global__ __launch_bounds__(EXT_THREADS) void extend_exact_kernel(ExtendArgs a) {
-    __shared__ int s_tab[128];
-    __shared__ HspRec s_out[EXT_THREADS / 64][64];
-    __shared__ EntRec s_ent[EXT_THREADS / 64][64];
-    if (threadIdx.x < 128) s_tab[threadIdx.x] = threadIdx.x < 64 ? a.sub_mat[threadIdx.x] : NEG;
-    __syncthreads();
-    HspRec* st_out = s_out[threadIdx.x >> 6];
-    EntRec* st_ent = s_ent[threadIdx.x >> 6];
-    int n_out = 0, n_ent = 0;
-
-    const int lane = threadIdx.x & 63;
-    const uint8_t* __restrict__ R8b = a.ref8 - BIAS;
-    const uint8_t* __restrict__ Qb = a.query - BIAS;
+__device__ __forceinline__ void wave_extend_exact(const ExtendArgs& a, const int* __restrict__ s_tab,
+                                                  const uint8_t* __restrict__ R8b, const uint8_t* __restrict__ Qb, int lane,
+                                                  uint32_t ref_loc, uint32_t query_loc, int& bestR, int& bposR, int& bestL,
+                                                  int& boffL, unsigned long long& examined) {
     const int xdrop = a.xdrop;
-    const uint32_t n_cand = min(*a.cand_count, a.cand_cap_recs);
-    const uint32_t G = gridDim.x * (EXT_THREADS / 64);
+    bestR = 0; bposR = -1; bestL = 0; boffL = 0;
+    bool skip = false;
+    if (a.rm) skip = !(ref_loc >= a.rm_win_start && ref_loc <= a.rm_win_end);  // rm :239-244,:305-333
+    if (skip) bposR = 0;  // extent stays 0 (:311)
+    for (int side = skip ? 2 : 0; side < 2; side++) {
+        const bool left = side == 1;
+        const uint32_t lim = left ? min(ref_loc, query_loc)
+                                  : ((ref_loc < a.ref_len && query_loc < a.query_len)
+                                         ? min(a.ref_len - ref_loc, a.query_len - query_loc) : 0u);
+        uint32_t k0 = left ? 1u : 0u;                            // :327 / :479
+        int score_in = 0, best_in = 0, bpos_in = left ? 0 : -1;  // :308-310 / :465-467
+        for (;;) {  // 512-base windows
+            const uint32_t k = k0 + 8u * (uint32_t)lane;
+            // in-range positions from k on, clamped to [0, 8]
+            const int64_t rem64 = left ? (int64_t)lim - (int64_t)k + 1 : (int64_t)lim - (int64_t)k;
+            const int remaining = rem64 > 8 ? 8 : (rem64 < 0 ? 0 : (int)rem64);
+            uint64_t x = 0;
+            if (remaining > 0) {
+                const uint32_t roff = left ? ref_loc + BIAS - k - 7u : ref_loc + BIAS + k;
+                const uint32_t qoff = left ? query_loc + BIAS - k - 7u : query_loc + BIAS + k;
+                x = load8u(R8b + roff) | load8u(Qb + qoff);
+                if (left) x = __builtin_bswap64(x);  // byte j <-> offset k+j on both sides
+            }
+            if (remaining < 8) x |= (remaining <= 0) ? TERM_ALL : (TERM_ALL << (8 * remaining));
+            // ---- local prefix sums of the 8 scores, local maximum prefix (first position attaining it) ----
+            // (sums are formed in uint32: lanes past a sequence edge accumulate terminators and may wrap; they lie
+            //  after the first dropping lane and are discarded)
+            uint32_t run = 0;
+            int mx = INT32_MIN, amx = 0;
+            {
+                const uint32_t xlo = (uint32_t)x, xhi = (uint32_t)(x >> 32);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t w = j < 4 ? xlo : xhi;
+                    run += (uint32_t)s_tab[(w >> (8 * (j & 3))) & 0xffu];
+                    const bool up = (int)run > mx;
+                    amx = up ? j : amx;
+                    mx = up ? (int)run : mx;
+                }
+            }
+            // ---- entry score of every lane: exclusive wave sum-scan (DPP) ----
+            const uint32_t inc = wave_inclusive_sum(run);
+            const int base = (int)((uint32_t)score_in + inc - run);
+            // ---- entry best of every lane: exclusive max-scan, ties keep the EARLIER position ----
+            int mv = (int)((uint32_t)base + (uint32_t)mx), mp = (int)(k + (uint32_t)amx);
+            wave_inclusive_max(mv, mp);
+            int ev = dpp_mov<0x138>(INT32_MIN, mv);  // wave_shr:1 -> best over earlier lanes
+            int ep = dpp_mov<0x138>(0, mp);
+            if (best_in >= ev) { ev = best_in; ep = bpos_in; }  // the carried-in best is the earliest of all
+            // ---- exact replay of the lane's 8 bases ----
+            int score = base, best = ev, bpos = ep;
+            uint32_t ex_step = 0;
+            chunk8_exact<COUNT_EXAMINED, XDROP_NONNEG>(s_tab, x, k, xdrop, score, best, bpos, ex_step);
+            const unsigned long long dm = __ballot(score < (DEAD >> 1));
+            if (dm) {
+                const int f = __ffsll((long long)dm) - 1;  // first lane that dropped holds the final state
+                best_in = __builtin_amdgcn_readlane(best, f);
+                bpos_in = __builtin_amdgcn_readlane(bpos, f);
+                if (COUNT_EXAMINED && lane <= f) examined += ex_step;  // lanes after f never happened
+                break;
+            }
+            if (COUNT_EXAMINED) examined += ex_step;
+            score_in = __builtin_amdgcn_readlane(score, 63);
+            best_in = __builtin_amdgcn_readlane(best, 63);
+            bpos_in = __builtin_amdgcn_readlane(bpos, 63);
+            k0 += 512u;
+        }
+        if (!left) { bestR = best_in; bposR = bpos_in; }
+        else { bestL = best_in; boffL = bpos_in; }
+    }
+}
+
+// per-wave LDS stages of the exact kernels: survivors and entropy records, flushed 64 at a time
+struct ExactStage {
+    HspRec* st_out;
+    EntRec* st_ent;
+    int n_out, n_ent;
+};
+
+// classify + stage one finished extension (all arguments wave-uniform)
+__device__ __forceinline__ void wave_finalize(const ExtendArgs& a, ExactStage& st, int lane, uint32_t ref_loc, uint32_t query_loc,
+                                              uint32_t seg, int bestR, int bposR, int bestL, int boffL) {
+    const int total = bestR + bestL, extent = bposR + boffL;  // :414-421, :563-574
+    const int cls = classify(a, total);
+    if (!cls) return;
+    if (cls == 1) {
+        if (lane == 0) st.st_out[st.n_out] = make_rec(a, ref_loc, query_loc, boffL, extent, total, seg);  // :638 with entropy 1
+        st.n_out++;
+        __builtin_amdgcn_wave_barrier();
+        if (st.n_out == 64) { stage_flush(st.st_out, 64, a.out, a.out_count, a.out_cap, lane); st.n_out = 0; __builtin_amdgcn_wave_barrier(); }
+    } else {
+        if (lane == 0) {
+            EntRec er;
+            er.ref_loc = ref_loc; er.query_loc = query_loc; er.bposR = bposR; er.boffL = boffL; er.total = total; er.seg = seg;
+            st.st_ent[st.n_ent] = er;
+        }
+        st.n_ent++;
+        __builtin_amdgcn_wave_barrier();
+        if (st.n_ent == 64) { stage_flush(st.st_ent, 64, a.ent_list, a.ent_count, a.ent_cap_recs, lane); st.n_ent = 0; __builtin_amdgcn_wave_barrier(); }
+    }
+}
+
+#define EXACT_KERNEL_PROLOGUE()                                                                            \
+    __shared__ int s_tab[128];                                                                             \
+    __shared__ HspRec s_out[EXT_THREADS / 64][64];                                                         \
+    __shared__ EntRec s_ent[EXT_THREADS / 64][64];                                                         \
+    if (threadIdx.x < 128) s_tab[threadIdx.x] = threadIdx.x < 64 ? a.sub_mat[threadIdx.x] : NEG;           \
+    __syncthreads();                                                                                       \
+    ExactStage st = {s_out[threadIdx.x >> 6], s_ent[threadIdx.x >> 6], 0, 0};                             \
+    const int lane = threadIdx.x & 63;                                                                     \
+    const uint8_t* __restrict__ R8b = a.ref8 - BIAS;                                                       \
+    const uint8_t* __restrict__ Qb = a.query - BIAS;                                                       \
+    const uint32_t n_cand = min(*a.cand_count, a.cand_cap_recs);                                           \
+    const uint32_t G = gridDim.x * (EXT_THREADS / 64);                                                     \
     unsigned long long examined = 0;
 
+#define EXACT_KERNEL_EPILOGUE()                                                                            \
+    stage_flush(st.st_out, st.n_out, a.out, a.out_count, a.out_cap, lane);                                 \
+    stage_flush(st.st_ent, st.n_ent, a.ent_list, a.ent_count, a.ent_cap_recs, lane);                       \
+    if (COUNT_EXAMINED) {                                                                                  \
+        unsigned long long v = examined;                                                                   \
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);                               \
+        if (lane == 0 && v) atomicAdd(a.examined, v);                                                      \
+    }
+
+// every candidate extended on its own (used when the chain shortcut below is off or the candidate list overflows it)
+template <bool COUNT_EXAMINED, bool XDROP_NONNEG>
+__global__ __launch_bounds__(EXT_THREADS) void extend_exact_kernel(ExtendArgs a) {
+    EXACT_KERNEL_PROLOGUE()
+    if (a.chain_cap && n_cand <= a.chain_cap) return;  // the chain kernels handle this batch
     for (uint32_t i = blockIdx.x * (EXT_THREADS / 64) + (threadIdx.x >> 6); i < n_cand; i += G) {
         const CandRec cr = a.cand_list[i];  // same address in every lane: one broadcast load
         const uint32_t ref_loc = (uint32_t)rfl((int)cr.ref_loc), query_loc = (uint32_t)rfl((int)cr.query_loc);
         const uint32_t hidx = (uint32_t)rfl((int)cr.hidx);
-        int bestR = 0, bposR = -1, bestL = 0, boffL = 0;
+        int bestR, bposR, bestL, boffL;
+        wave_extend_exact<COUNT_EXAMINED, XDROP_NONNEG>(a, s_tab, R8b, Qb, lane, ref_loc, query_loc, bestR, bposR, bestL, boffL, examined);
+        wave_finalize(a, st, lane, ref_loc, query_loc, seg_of(a, hidx), bestR, bposR, bestL, boffL);
+    }
+    EXACT_KERNEL_EPILOGUE()
+}
 
-        bool skip = false;
-        if (a.rm) skip = !(ref_loc >= a.rm_win_start && ref_loc <= a.rm_win_end);  // rm :239-244,:305-333
-        if (skip) bposR = 0;  // extent stays 0 (:311)
+// =====================================================================================================================
+// 2b. the CHAIN shortcut: most candidates are hits inside one and the same HSP and would all extend to the very same
+//     record.  For the recurrence above (ties included) two facts hold for anchors a < b on one diagonal:
+//       (R) if b <= E_R(a) (b not beyond a's best right end) then E_R(b) = E_R(a);
+//       (L) if b's left walk reaches a STRICT new best at a position < a before it terminates, then S_L(b) = S_L(a).
+//     (Sketch: the later-starting walk has point-wise smaller drops, so it cannot stop earlier; at the earlier walk's
+//     stop both see the same running maximum, so it stops there too; the earliest arg-max is shared.)  Same interval
+//     => same score, same entropy factor, same record.  So: candidates are sorted by (iteration, diagonal, position);
+//     one lane per candidate tests (L) against its predecessor with a SHORT walk (gap + a few bases); candidates whose
+//     test fails start a run.  One wave per run extends the run head exactly and skips every member whose anchor is
+//     <= the head's right end -- the member's record would be an exact duplicate, which the dedup stage (adjacent-pair
+//     containment, :47-52,:778) would drop anyway.  A member beyond the head's right end becomes the next head.
+// =====================================================================================================================
+constexpr uint32_t CHAIN_GAP_MAX = 256;   // predecessor further away than this: no test, the candidate starts a run
+constexpr uint32_t CHAIN_WALK_EXTRA = 96; // bases walked past the predecessor's anchor looking for the new best
 
-        for (int side = skip ? 2 : 0; side < 2; side++) {
-            const bool left = side == 1;
-            const uint32_t lim = left ? min(ref_loc, query_loc)
-                                      : ((ref_loc < a.ref_len && query_loc < a.query_len)
-                                             ? min(a.ref_len - ref_loc, a.query_len - query_loc) : 0u);
-            uint32_t k0 = left ? 1u : 0u;             // :327 / :479
-            int score_in = 0, best_in = 0, bpos_in = left ? 0 : -1;  // :308-310 / :465-467
-            for (;;) {  // 512-base windows
-                const uint32_t k = k0 + 8u * (uint32_t)lane;
-                // in-range positions from k on, clamped to [0, 8]
-                const int64_t rem64 = left ? (int64_t)lim - (int64_t)k + 1 : (int64_t)lim - (int64_t)k;
-                const int remaining = rem64 > 8 ? 8 : (rem64 < 0 ? 0 : (int)rem64);
-                uint64_t x = 0;
-                if (remaining > 0) {
-                    const uint32_t roff = left ? ref_loc + BIAS - k - 7u : ref_loc + BIAS + k;
-                    const uint32_t qoff = left ? query_loc + BIAS - k - 7u : query_loc + BIAS + k;
-                    x = load8u(R8b + roff) | load8u(Qb + qoff);
-                    if (left) x = __builtin_bswap64(x);  // byte j <-> offset k+j on both sides
-                }
-                if (remaining < 8) x |= (remaining <= 0) ? TERM_ALL : (TERM_ALL << (8 * remaining));
-                // ---- local prefix sums of the 8 scores, local maximum prefix (first position attaining it) ----
-                // (sums are formed in uint32: lanes past a sequence edge accumulate terminators and may wrap; they lie
-                //  after the first dropping lane and are discarded)
-                uint32_t run = 0;
-                int mx = INT32_MIN, amx = 0;
-                {
-                    const uint32_t xlo = (uint32_t)x, xhi = (uint32_t)(x >> 32);
+// Grouping without a general sort: candidates are dealt into CHAIN_BUCKETS buckets by a hash of (iteration, diagonal)
+// (counting pass, one-block scan, scatter), then ONE WORKGROUP PER BUCKET rank-sorts its entries in LDS by
+// (iteration, diagonal, position).  A bucket holds a handful of diagonals with a few hundred candidates each, so the
+// quadratic rank sort is a few microseconds; all buckets together are the candidate list with every diagonal's
+// candidates contiguous and ordered by position -- exactly what the link test needs.  No host involvement.
+constexpr uint32_t CHAIN_BUCKETS = 2048;
+constexpr uint32_t CHAIN_SORT_MAX = 4096;  // entries a bucket may hold and still be sorted (LDS); larger: left unsorted,
+                                           // which only makes link tests fail, i.e. costs extensions, never correctness
+
+// A bucket = hash of (iteration, diagonal, 1024-position window): one diagonal can carry every candidate of a call (a
+// collinear query), so the window keeps a group at <= 1024 entries and spreads the counting atomics; chains simply
+// restart at window borders (one extra extension per kilobase of HSP).
+constexpr uint32_t CHAIN_QSHIFT = 10;
+__device__ __forceinline__ uint32_t chain_bucket_of(uint32_t seg, const CandRec& c) {
+    const uint32_t diag = c.ref_loc - c.query_loc;
+    return (((diag * 2654435761u) ^ ((c.query_loc >> CHAIN_QSHIFT) * 0x85EBCA6Bu) ^ (seg * 0x9E3779B1u)) >> 15) & (CHAIN_BUCKETS - 1u);
+}
+__device__ __forceinline__ unsigned long long chain_key(const ExtendArgs& a, const CandRec& c) {
+    // iteration (3 bits) | diagonal (32) | query position (29)
+    return ((unsigned long long)(seg_of(a, c.hidx) - a.seg_base) << 61) |
+           ((unsigned long long)(uint32_t)(c.ref_loc - c.query_loc) << 29) | (unsigned long long)(c.query_loc & 0x1FFFFFFFu);
+}
+
+__global__ __launch_bounds__(256) void chain_count_kernel(ExtendArgs a) {
+    const uint32_t n = min(*a.cand_count, a.cand_cap_recs);
+    if (n > a.chain_cap) return;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const CandRec c = a.cand_list[i];
+        atomicAdd(&a.chain_bucket_cnt[chain_bucket_of(seg_of(a, c.hidx), c)], 1u);
+    }
+}
+
+// one block: exclusive scan of the CHAIN_BUCKETS counters into chain_bucket_start[0..CHAIN_BUCKETS]; counters become cursors
+__global__ __launch_bounds__(256) void chain_scan_kernel(ExtendArgs a) {
+    __shared__ uint32_t s_part[256];
+    constexpr uint32_t PER = CHAIN_BUCKETS / 256;
+    uint32_t v[PER], sum = 0;
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const uint32_t w = j < 4 ? xlo : xhi;
-                        run += (uint32_t)s_tab[(w >> (8 * (j & 3))) & 0xffu];
-                        const bool up = (int)run > mx;
-                        amx = up ? j : amx;
-                        mx = up ? (int)run : mx;
+    for (uint32_t j = 0; j < PER; j++) { v[j] = a.chain_bucket_cnt[threadIdx.x * PER + j]; sum += v[j]; }
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t t = 0; t < threadIdx.x; t++) base += s_part[t];
+#pragma unroll
+    for (uint32_t j = 0; j < PER; j++) {
+        a.chain_bucket_start[threadIdx.x * PER + j] = base;
+        a.chain_bucket_cnt[threadIdx.x * PER + j] = 0;  // reused as the scatter cursor
+        base += v[j];
+    }
+    if (threadIdx.x == 255) a.chain_bucket_start[CHAIN_BUCKETS] = base;
+}
+
+__global__ __launch_bounds__(256) void chain_scatter_kernel(ExtendArgs a) {
+    const uint32_t n = min(*a.cand_count, a.cand_cap_recs);
+    if (n > a.chain_cap) return;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const CandRec c = a.cand_list[i];
+        const uint32_t b = chain_bucket_of(seg_of(a, c.hidx), c);
+        a.chain_tmp[a.chain_bucket_start[b] + atomicAdd(&a.chain_bucket_cnt[b], 1u)] = c;
+    }
+}
+
+// one workgroup per bucket: rank sort in LDS by (iteration, diagonal, position)
+__global__ __launch_bounds__(256) void chain_bucket_sort_kernel(ExtendArgs a) {
+    __shared__ unsigned long long s_key[CHAIN_SORT_MAX];
+    const uint32_t n = min(*a.cand_count, a.cand_cap_recs);
+    if (n > a.chain_cap) return;
+    const uint32_t b0 = a.chain_bucket_start[blockIdx.x], m = a.chain_bucket_start[blockIdx.x + 1] - b0;
+    if (m == 0) return;
+    if (m > CHAIN_SORT_MAX) {
+        for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) a.chain_sorted[b0 + i] = a.chain_tmp[b0 + i];
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) s_key[i] = chain_key(a, a.chain_tmp[b0 + i]);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+        const unsigned long long k = s_key[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < m; j++) {
+            const unsigned long long kj = s_key[j];
+            rank += (kj < k || (kj == k && j < i)) ? 1u : 0u;  // keys are unique per hit; the index breaks hand-made ties
+        }
+        a.chain_sorted[b0 + rank] = a.chain_tmp[b0 + i];
+    }
+}
+
+// one lane per sorted candidate: does it start a run?  (test (L) against the predecessor, bounded walk)
+template <bool XDROP_NONNEG>
+__global__ __launch_bounds__(256) void chain_link_kernel(ExtendArgs a) {
+    __shared__ int s_tab[128];
+    if (threadIdx.x < 128) s_tab[threadIdx.x] = threadIdx.x < 64 ? a.sub_mat[threadIdx.x] : NEG;
+    __syncthreads();
+    const uint32_t n = min(*a.cand_count, a.cand_cap_recs);
+    if (n > a.chain_cap) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    const uint8_t* __restrict__ R8b = a.ref8 - BIAS;
+    const uint8_t* __restrict__ Qb = a.query - BIAS;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t rounds = (n + stride - 1) / stride;  // wave-uniform trip count (ballot below)
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t i = r * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        bool head = false;
+        if (i < n) {
+            head = true;
+            const CandRec c = a.chain_sorted[i];
+            CandRec pc = c;
+            if (i > 0) pc = a.chain_sorted[i - 1];
+            // same iteration, same diagonal, predecessor strictly before this anchor
+            if (i > 0 && (c.ref_loc - c.query_loc) == (pc.ref_loc - pc.query_loc) && c.query_loc > pc.query_loc &&
+                seg_of(a, c.hidx) == seg_of(a, pc.hidx)) {
+                const uint32_t g = c.query_loc - pc.query_loc;  // anchor gap (> 0)
+                if (g <= CHAIN_GAP_MAX) {
+                    const uint32_t lim = min(c.ref_loc, c.query_loc);
+                    int score = 0, best = 0, bpos = 0;
+                    uint32_t ex = 0;
+                    for (uint32_t k = 1; k <= g + CHAIN_WALK_EXTRA; k += 8) {
+                        const int64_t rem64 = (int64_t)lim - (int64_t)k + 1;
+                        const int remaining = rem64 > 8 ? 8 : (rem64 < 0 ? 0 : (int)rem64);
+                        uint64_t x = 0;
+                        if (remaining > 0)
+                            x = __builtin_bswap64(load8u(R8b + (c.ref_loc + BIAS - k - 7u)) | load8u(Qb + (c.query_loc + BIAS - k - 7u)));
+                        if (remaining < 8) x |= (remaining <= 0) ? TERM_ALL : (TERM_ALL << (8 * remaining));
+                        chunk8_exact<false, XDROP_NONNEG>(s_tab, x, k, a.xdrop, score, best, bpos, ex);
+                        if ((uint32_t)bpos > g) { head = false; break; }  // strict new best at a position < predecessor's anchor: (L)
+                        if (score < (DEAD >> 1)) break;                  // walk ended first: extend this one on its own
                     }
                 }
-                // ---- entry score of every lane: exclusive wave sum-scan (DPP) ----
-                const uint32_t inc = wave_inclusive_sum(run);
-                const int base = (int)((uint32_t)score_in + inc - run);
-                // ---- entry best of every lane: exclusive max-scan, ties keep the EARLIER position ----
-                int mv = (int)((uint32_t)base + (uint32_t)mx), mp = (int)(k + (uint32_t)amx);
-                wave_inclusive_max(mv, mp);
-                int ev = dpp_mov<0x138>(INT32_MIN, mv);  // wave_shr:1 -> best over earlier lanes
-                int ep = dpp_mov<0x138>(0, mp);
-                if (best_in >= ev) { ev = best_in; ep = bpos_in; }  // the carried-in best is the earliest of all
-                // ---- exact replay of the lane's 8 bases ----
-                int score = base, best = ev, bpos = ep;
-                uint32_t ex_step = 0;
-                chunk8_exact<COUNT_EXAMINED, XDROP_NONNEG>(s_tab, x, k, xdrop, score, best, bpos, ex_step);
-                const unsigned long long dm = __ballot(score < (DEAD >> 1));
-                if (dm) {
-                    const int f = __ffsll((long long)dm) - 1;  // first lane that dropped holds the final state
-                    best_in = __builtin_amdgcn_readlane(best, f);
-                    bpos_in = __builtin_amdgcn_readlane(bpos, f);
-                    if (COUNT_EXAMINED && lane <= f) examined += ex_step;  // lanes after f never happened
-                    break;
-                }
-                if (COUNT_EXAMINED) examined += ex_step;
-                score_in = __builtin_amdgcn_readlane(score, 63);
-                best_in = __builtin_amdgcn_readlane(best, 63);
-                bpos_in = __builtin_amdgcn_readlane(bpos, 63);
-                k0 += 512u;
             }
-            if (!left) { bestR = best_in; bposR = bpos_in; }
-            else { bestL = best_in; boffL = bpos_in; }
+            a.chain_is_head[i] = head ? 1u : 0u;
         }
-        // ---- finalise: all values are wave-uniform; records are staged in LDS and flushed 64 at a time ----
-        {
-            const int total = bestR + bestL, extent = bposR + boffL;  // :414-421, :563-574
-            const int cls = classify(a, total);
-            if (cls) {
-                const uint32_t seg = seg_of(a, hidx);
-                if (cls == 1) {
-                    if (lane == 0) st_out[n_out] = make_rec(a, ref_loc, query_loc, boffL, extent, total, seg);  // :638 with entropy 1
-                    n_out++;
-                    __builtin_amdgcn_wave_barrier();
-                    if (n_out == 64) { stage_flush(st_out, 64, a.out, a.out_count, a.out_cap, lane); n_out = 0; __builtin_amdgcn_wave_barrier(); }
+        // run heads -> head list (order irrelevant)
+        const unsigned long long m = __ballot(head);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            uint32_t wbase = 0;
+            if (lane == leader) wbase = atomicAdd(a.chain_head_count, (uint32_t)__popcll(m));
+            wbase = (uint32_t)__builtin_amdgcn_readlane((int)wbase, leader);
+            if (head) a.chain_heads[wbase + (uint32_t)__popcll(m & lane_lt)] = i;
+        }
+    }
+}
+
+// one wave per run: extend the head, skip members covered by (R), promote the first member beyond the right end
+template <bool XDROP_NONNEG>
+__global__ __launch_bounds__(EXT_THREADS) void extend_exact_chain_kernel(ExtendArgs a) {
+    constexpr bool COUNT_EXAMINED = false;
+    EXACT_KERNEL_PROLOGUE()
+    if (n_cand > a.chain_cap) return;  // overflow: extend_exact_kernel handles the batch
+    const uint32_t n_heads = *a.chain_head_count;
+    for (uint32_t j = blockIdx.x * (EXT_THREADS / 64) + (threadIdx.x >> 6); j < n_heads; j += G) {
+        uint32_t cur = (uint32_t)rfl((int)a.chain_heads[j]);
+        for (;;) {
+            const CandRec cr = a.chain_sorted[cur];
+            const uint32_t ref_loc = (uint32_t)rfl((int)cr.ref_loc), query_loc = (uint32_t)rfl((int)cr.query_loc);
+            const uint32_t hidx = (uint32_t)rfl((int)cr.hidx);
+            int bestR, bposR, bestL, boffL;
+            wave_extend_exact<false, XDROP_NONNEG>(a, s_tab, R8b, Qb, lane, ref_loc, query_loc, bestR, bposR, bestL, boffL, examined);
+            wave_finalize(a, st, lane, ref_loc, query_loc, seg_of(a, hidx), bestR, bposR, bestL, boffL);
+            // members of the run follow in the sorted list until the next run head
+            const int64_t right_end = (int64_t)ref_loc + (int64_t)bposR;  // E_R(head) as a target position
+            uint32_t nxt = 0xFFFFFFFFu;
+            for (uint32_t m0 = cur + 1; m0 < n_cand; m0 += 64) {
+                const uint32_t m = m0 + (uint32_t)lane;
+                bool stop_run = false, beyond = false;
+                if (m < n_cand) {
+                    stop_run = a.chain_is_head[m] != 0u;  // (also set wherever the iteration or the diagonal changes)
+                    beyond = (int64_t)a.chain_sorted[m].ref_loc > right_end;  // (R) does not cover it
                 } else {
-                    if (lane == 0) {
-                        EntRec er;
-                        er.ref_loc = ref_loc; er.query_loc = query_loc; er.bposR = bposR; er.boffL = boffL; er.total = total; er.seg = seg;
-                        st_ent[n_ent] = er;
-                    }
-                    n_ent++;
-                    __builtin_amdgcn_wave_barrier();
-                    if (n_ent == 64) { stage_flush(st_ent, 64, a.ent_list, a.ent_count, a.ent_cap_recs, lane); n_ent = 0; __builtin_amdgcn_wave_barrier(); }
+                    stop_run = true;
                 }
+                const unsigned long long sm = __ballot(stop_run), bm = __ballot(beyond);
+                const int fs = sm ? __ffsll((long long)sm) - 1 : 64, fb = bm ? __ffsll((long long)bm) - 1 : 64;
+                if (fb < fs) { nxt = m0 + (uint32_t)fb; break; }  // a member beyond the right end: it becomes the next head
+                if (fs < 64) break;                                // run ended
             }
+            if (nxt == 0xFFFFFFFFu) break;
+            cur = nxt;
         }
     }
-    stage_flush(st_out, n_out, a.out, a.out_count, a.out_cap, lane);
-    stage_flush(st_ent, n_ent, a.ent_list, a.ent_count, a.ent_cap_recs, lane);
-    if (COUNT_EXAMINED) {
-        unsigned long long v = examined;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0 && v) atomicAdd(a.examined, v);
-    }
+    EXACT_KERNEL_EPILOGUE()
 }
 
 // =====================================================================================================================
@@ -598,6 +816,23 @@ void launch_extend_filter(const ExtendArgs& a, hipStream_t s) {
     if (a.examined) hipLaunchKernelGGL((extend_filter_kernel<true, false>), dim3(blocks), dim3(EXT_THREADS), 0, s, a);
     else if (a.fast_filter) hipLaunchKernelGGL((extend_filter_kernel<false, true>), dim3(blocks), dim3(EXT_THREADS), 0, s, a);
     else hipLaunchKernelGGL((extend_filter_kernel<false, false>), dim3(blocks), dim3(EXT_THREADS), 0, s, a);
+}
+
+void launch_chain_group(const ExtendArgs& a, hipStream_t s) {  // chain_bucket_cnt must be zero on entry
+    if (a.num_hits == 0 || !a.chain_cap) return;
+    hipLaunchKernelGGL(chain_count_kernel, dim3(256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(chain_scan_kernel, dim3(1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(chain_scatter_kernel, dim3(256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(chain_bucket_sort_kernel, dim3(CHAIN_BUCKETS), dim3(256), 0, s, a);
+}
+uint32_t chain_num_buckets() { return CHAIN_BUCKETS; }
+void launch_chain_link(const ExtendArgs& a, hipStream_t s) {
+    if (a.num_hits == 0 || !a.chain_cap) return;
+    hipLaunchKernelGGL((chain_link_kernel<true>), dim3(256), dim3(256), 0, s, a);
+}
+void launch_extend_exact_chain(const ExtendArgs& a, hipStream_t s) {
+    if (a.num_hits == 0 || !a.chain_cap) return;
+    hipLaunchKernelGGL((extend_exact_chain_kernel<true>), dim3(a.long_blocks), dim3(EXT_THREADS), 0, s, a);
 }
 
 void launch_extend_exact(const ExtendArgs& a, hipStream_t s) {

@@ -67,6 +67,15 @@ struct ExtendArgs {
     EntRec* ent_list;
     uint32_t* ent_count;
     uint32_t ent_cap_recs;
+    // chain shortcut of the exact stage (extend.hip 2b); chain_cap == 0 disables it
+    uint32_t chain_cap;                      // candidates per batch the chain buffers hold
+    uint32_t* chain_bucket_cnt;              // [buckets] counters, then scatter cursors (zero on entry)
+    uint32_t* chain_bucket_start;            // [buckets + 1]
+    CandRec* chain_tmp;                      // [chain_cap] candidates dealt into buckets
+    CandRec* chain_sorted;                   // [chain_cap] every bucket sorted by (iteration, diagonal, position)
+    uint32_t* chain_is_head;                 // [chain_cap]
+    uint32_t* chain_heads;                   // [chain_cap] indices of run heads
+    uint32_t* chain_head_count;
     uint32_t max_waves;       // wave budget of the main kernel (resident waves of the chip)
     uint32_t long_blocks, ent_blocks;  // grid sizes of the long / entropy kernels (they read their counts on device)
     const Hit* hits;
@@ -128,6 +137,11 @@ void launch_plan(const uint64_t* hit_prefix_excl, uint32_t num_seeds, uint64_t m
 // ---- extend.hip ------------------------------------------------------------------------------------------------
 void launch_extend_filter(const ExtendArgs& a, hipStream_t s);   // hits -> candidates
 void launch_extend_exact(const ExtendArgs& a, hipStream_t s);    // candidates -> survivors + entropy records
+// chain shortcut: keys -> (sort, dedup.hip) -> links/run heads -> one exact extension per run
+void launch_chain_group(const ExtendArgs& a, hipStream_t s);
+uint32_t chain_num_buckets();
+void launch_chain_link(const ExtendArgs& a, hipStream_t s);
+void launch_extend_exact_chain(const ExtendArgs& a, hipStream_t s);
 void launch_extend_entropy(const ExtendArgs& a, hipStream_t s);  // entropy records -> survivors
 
 // ---- dedup.hip -------------------------------------------------------------------------------------------------

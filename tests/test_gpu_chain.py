@@ -1,0 +1,90 @@
+"""GPU: the chain shortcut of the exact stage (extend.hip 2b) on inputs built to stress its premises -- mismatch bursts
+whose drop sits right at the X-drop threshold (HSP ends depend on the anchor), candidates crowding one diagonal,
+indels that move the diagonal every few dozen bases -- with the shortcut on (default) and off."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import Case, seg_equal
+from segalign_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def borderline_pair(seed, n=60000):
+    """Copy with bursts of 6-10 consecutive substitutions every 40-90 bases: each burst costs ~650-1250 points, i.e.
+    sometimes below and sometimes above xdrop = 910, so whether a walk crosses a burst depends on where it started."""
+    rng = np.random.default_rng(seed)
+    t = synth.random_dna(n, seed)
+    q = t.copy()
+    p = 50
+    while p < n - 20:
+        k = int(rng.integers(6, 11))
+        idx = np.searchsorted(np.frombuffer(b"ACGT", dtype=np.uint8), q[p:p + k])
+        q[p:p + k] = np.frombuffer(b"ACGT", dtype=np.uint8)[(idx + rng.integers(1, 4, size=k)) % 4]
+        p += int(rng.integers(40, 90))
+    return t, q
+
+
+def run(engine, oracle, t, q, chain, **kw):
+    if chain:
+        os.environ.pop("SEGALIGN_AMD_NO_CHAIN", None)
+    else:
+        os.environ["SEGALIGN_AMD_NO_CHAIN"] = "1"
+    c = Case(t, q, **kw).oracle_setup(oracle).engine_setup(engine)
+    try:
+        outs, surv = [], 0
+        for rev in (False, True):
+            for (s, e) in c.chunks():
+                seeds = c.host_seeds(s, e, rev)
+                if seeds.size == 0:
+                    continue
+                want, st = c.oracle_saf(seeds, rev)
+                got = c.E.SeedAndFilter(seeds, rev, 0)
+                assert seg_equal(got, want), (chain, rev, s, e)
+                surv += c.E.last_call_stats()["num_survivors"]
+                outs.append(got)
+        return outs, surv
+    finally:
+        engine.ShutdownProcessor()
+        os.environ.pop("SEGALIGN_AMD_NO_CHAIN", None)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_borderline_xdrop_bursts(oracle, engine, seed):
+    t, q = borderline_pair(100 + seed)
+    on, s_on = run(engine, oracle, t, q, True, chunk=30000)
+    off, s_off = run(engine, oracle, t, q, False, chunk=30000)
+    assert all(np.array_equal(a, b) for a, b in zip(on, off))
+    assert 0 < s_on <= s_off  # the shortcut only ever removes exact duplicates before the dedup stage
+
+
+@pytest.mark.parametrize("xdrop,hspthresh", [(300, 2000), (910, 3000), (2000, 3000)])
+def test_dense_single_diagonal_and_shifting_diagonals(oracle, engine, xdrop, hspthresh):
+    # one 40 kb collinear diagonal (3 % substitutions) ...
+    t1, q1 = synth.make_pair(40000, 7, 8, sub_rate=0.03, invert_frac=0.0)
+    on, s_on = run(engine, oracle, t1, q1, True, chunk=20000, xdrop=xdrop, hspthresh=hspthresh)
+    off, s_off = run(engine, oracle, t1, q1, False, chunk=20000, xdrop=xdrop, hspthresh=hspthresh)
+    assert all(np.array_equal(a, b) for a, b in zip(on, off)) and s_on < s_off
+    # ... and indels every ~40 bases: the diagonal moves all the time, groups are tiny
+    t2, q2 = synth.make_pair(40000, 9, 10, sub_rate=0.02, indel_every=40, invert_frac=0.3, invert_block=4000)
+    on, _ = run(engine, oracle, t2, q2, True, chunk=20000, xdrop=xdrop, hspthresh=hspthresh)
+    off, _ = run(engine, oracle, t2, q2, False, chunk=20000, xdrop=xdrop, hspthresh=hspthresh)
+    assert all(np.array_equal(a, b) for a, b in zip(on, off))
+
+
+def test_chain_with_iteration_split(oracle, engine):
+    """Candidates of different reference iterations (MAX_HITS split) must never share a chain."""
+    t, q = synth.make_pair(50000, 11, 12, sub_rate=0.04, invert_frac=0.0)
+    engine.set_max_hits(3000)
+    try:
+        c = Case(t, q, chunk=25000).oracle_setup(oracle).engine_setup(engine)
+        for (s, e) in c.chunks():
+            seeds = c.host_seeds(s, e, False)
+            want, st = c.oracle_saf(seeds, False, max_hits=3000)
+            assert st["num_iter"] > 3
+            assert seg_equal(c.E.SeedAndFilter(seeds, False, 0), want)
+    finally:
+        engine.ShutdownProcessor()
+        engine.set_max_hits(0)

@@ -577,14 +577,14 @@ constexpr uint32_t CHAIN_WALK_EXTRA = 96; // bases walked past the predecessor's
 // (iteration, diagonal, position).  A bucket holds a handful of diagonals with a few hundred candidates each, so the
 // quadratic rank sort is a few microseconds; all buckets together are the candidate list with every diagonal's
 // candidates contiguous and ordered by position -- exactly what the link test needs.  No host involvement.
-constexpr uint32_t CHAIN_BUCKETS = 2048;
+constexpr uint32_t CHAIN_BUCKETS = 4096;
 constexpr uint32_t CHAIN_SORT_MAX = 4096;  // entries a bucket may hold and still be sorted (LDS); larger: left unsorted,
                                            // which only makes link tests fail, i.e. costs extensions, never correctness
 
-// A bucket = hash of (iteration, diagonal, 1024-position window): one diagonal can carry every candidate of a call (a
-// collinear query), so the window keeps a group at <= 1024 entries and spreads the counting atomics; chains simply
-// restart at window borders (one extra extension per kilobase of HSP).
-constexpr uint32_t CHAIN_QSHIFT = 10;
+// A bucket = hash of (iteration, diagonal, 512-position window): one diagonal can carry every candidate of a call (a
+// collinear query), so the window keeps a group at <= 512 entries and spreads the counting atomics; chains simply
+// restart at window borders (one extra extension per 512 bases of HSP).
+constexpr uint32_t CHAIN_QSHIFT = 9;
 __device__ __forceinline__ uint32_t chain_bucket_of(uint32_t seg, const CandRec& c) {
     const uint32_t diag = c.ref_loc - c.query_loc;
     return (((diag * 2654435761u) ^ ((c.query_loc >> CHAIN_QSHIFT) * 0x85EBCA6Bu) ^ (seg * 0x9E3779B1u)) >> 15) & (CHAIN_BUCKETS - 1u);
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256) void chain_scatter_kernel(ExtendArgs a) {
 }
 
 // one workgroup per bucket: rank sort in LDS by (iteration, diagonal, position)
-__global__ __launch_bounds__(256) void chain_bucket_sort_kernel(ExtendArgs a) {
+__global__ __launch_bounds__(512) void chain_bucket_sort_kernel(ExtendArgs a) {
     __shared__ unsigned long long s_key[CHAIN_SORT_MAX];
     const uint32_t n = min(*a.cand_count, a.cand_cap_recs);
     if (n > a.chain_cap) return;
@@ -823,7 +823,7 @@ void launch_chain_group(const ExtendArgs& a, hipStream_t s) {  // chain_bucket_c
     hipLaunchKernelGGL(chain_count_kernel, dim3(256), dim3(256), 0, s, a);
     hipLaunchKernelGGL(chain_scan_kernel, dim3(1), dim3(256), 0, s, a);
     hipLaunchKernelGGL(chain_scatter_kernel, dim3(256), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(chain_bucket_sort_kernel, dim3(CHAIN_BUCKETS), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(chain_bucket_sort_kernel, dim3(CHAIN_BUCKETS), dim3(512), 0, s, a);
 }
 uint32_t chain_num_buckets() { return CHAIN_BUCKETS; }
 void launch_chain_link(const ExtendArgs& a, hipStream_t s) {

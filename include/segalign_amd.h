@@ -110,6 +110,33 @@ void sa_rm_clear_query(void); /* repeat_masker_src/seed_filter.cu:964-972 */
 size_t sa_rm_seed_and_filter(const uint64_t* seeds, size_t num_seeds, int rev, uint32_t ref_start, uint32_t ref_end,
                              sa_segment_pair** out);
 
+/* ---- repeat-masker post-processing on the device (additive) ---------------------------------- */
+
+/* struct Segment, repeat_masker_src/graph.h:32-35: a run of masked positions, block-relative. */
+typedef struct sa_interval {
+    uint32_t query_start;
+    uint32_t len; /* number of positions in the run; the printer writes start .. start+len+1 (segment_printer.cpp:56) */
+} sa_interval;
+
+#define SA_STRAND_PLUS 1
+#define SA_STRAND_MINUS 2
+#define SA_STRAND_BOTH 3
+
+/* Device-side form of seeder_body::operator() of the repeat masker (repeat_masker_src/seeder.cpp:28-195) for ONE
+ * interval of the resident block: for every wga_chunk of [start_pos, end_pos) and every selected strand, seed words
+ * are extracted on the device from the encoded block (seeder.cpp:84-101,123-138), SeedAndFilter runs with the target
+ * window [ref_start, ref_end] (:105,142), every returned HSP adds 1 to the coverage of positions
+ * query_start .. query_start+len-1 (uint8_t counters, :155-159) and the runs with coverage >= M become intervals
+ * (:168-186).  Neither seeds nor HSPs cross the PCIe link; only the intervals are returned.
+ * Returns the number of intervals; *out is malloc-ed (sa_free_intervals).  Optional totals: seeds, hits, HSPs
+ * (the reference's num_seeds / num_seed_hits / num_hsps statistics, seeder.cpp:104-110). */
+size_t sa_rm_mask_interval(uint32_t start_pos, uint32_t end_pos, uint32_t ref_start, uint32_t ref_end, int strands, uint32_t M,
+                           sa_interval** out, uint64_t* totals /* [3] or NULL */);
+/* The counting + run extraction alone (seeder.cpp:153-188) for a host that keeps the reference's chunk loop and
+ * hands over the HSPs it collected for one interval (headers already removed). */
+size_t sa_rm_coverage_intervals(const sa_segment_pair* hsps, size_t num_hsps, uint32_t block_len, uint32_t M, sa_interval** out);
+void sa_free_intervals(sa_interval* p);
+
 /* ---- knobs the reference derives from its GPU (hazard H4) ------------------------------------------------- */
 
 /* MAX_HITS (src/seed_filter.cu:832-841) decides how SeedAndFilter splits a call into iterations, and dedup scope

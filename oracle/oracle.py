@@ -66,6 +66,10 @@ def lib():
         L.orc_seed_and_filter_rm.argtypes = [C.POINTER(_SafParams), C.c_void_p, C.c_size_t, C.c_int, C.c_uint32,
                                              C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(_SafStats)]
         L.orc_free.argtypes = [C.c_void_p]
+        L.orc_rm_coverage_intervals.restype = C.c_size_t
+        L.orc_rm_coverage_intervals.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.orc_rm_plan.restype = C.c_size_t
+        L.orc_rm_plan.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.POINTER(C.c_void_p)]
         L.orc_max_hits_for_mem.argtypes = [C.c_uint64]
         L.orc_encode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
         L.orc_encode_rev_comp.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p]
@@ -209,6 +213,36 @@ def seed_and_filter(ref_codes, query_codes, index_table, pos_table, seeds, sub_m
     stats = dict(num_hits=st.num_hits, num_survivors=st.num_survivors, num_examined=st.num_examined,
                  num_iter=st.num_iter)
     return segs, stats
+
+
+IVL_DTYPE = np.dtype([("query_start", "<u4"), ("len", "<u4")])
+RM_TASK_DTYPE = np.dtype([("block_index", "<u4"), ("_pad", "<u4"), ("block_start", "<u8"), ("block_len", "<u4"),
+                          ("start", "<u4"), ("end", "<u4"), ("ref_start", "<u4"), ("ref_end", "<u4"), ("_pad2", "<u4")])
+
+
+def _take(n, out, dtype):
+    if n == 0:
+        lib().orc_free(out)
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * dtype.itemsize)).from_address(out.value)
+    a = np.frombuffer(buf, dtype=dtype).copy()
+    lib().orc_free(out)
+    return a
+
+
+def rm_coverage_intervals(hsps, block_len, M=1):
+    """repeat_masker_src/seeder.cpp:153-188 (uint8_t counters, runs with count >= M)."""
+    h = np.ascontiguousarray(hsps, dtype=SEG_DTYPE)
+    out = C.c_void_p()
+    n = lib().orc_rm_coverage_intervals(h.ctypes.data if h.size else None, h.size, block_len, M, C.byref(out))
+    return _take(n, out, IVL_DTYPE)
+
+
+def rm_plan(seq_len, seq_block_size=1000000000, lastz_interval_size=10000000, prop_neigh_interval=0.2, seed_size=19):
+    """repeat_masker_src/main.cpp:316-436: one record per (block, interval) task."""
+    out = C.c_void_p()
+    n = lib().orc_rm_plan(seq_len, seq_block_size, lastz_interval_size, prop_neigh_interval, seed_size, C.byref(out))
+    return _take(n, out, RM_TASK_DTYPE)
 
 
 def max_hits_for_mem(total_global_mem):

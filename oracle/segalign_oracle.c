@@ -696,3 +696,100 @@ size_t orc_seed_and_filter_rm(const orc_saf_params* p, const uint64_t* seeds, si
                               uint32_t ref_start, uint32_t ref_end, orc_segment** out_vec, orc_saf_stats* stats) {
     return saf_impl(p, seeds, num_seeds, 1, rev, ref_start, ref_end, out_vec, stats);
 }
+
+/* ---- repeat masker: coverage counting and run extraction (repeat_masker_src/seeder.cpp:57-58,153-188) ------------- */
+size_t orc_rm_coverage_intervals(const orc_segment* hsps, size_t num_hsps, uint32_t block_len, uint32_t M, orc_interval** out) {
+    uint8_t* int_count = (uint8_t*)calloc(block_len ? block_len : 1, 1); /* :57-58 */
+    for (size_t h = 0; h < num_hsps; h++) {                               /* :155-159 (the sort at :154 cannot matter) */
+        uint64_t b = hsps[h].query_start, e = (uint64_t)hsps[h].query_start + hsps[h].len;
+        for (uint64_t j = b; j < e && j < block_len; j++) int_count[j]++;
+    }
+    size_t cap = 16, n = 0;
+    orc_interval* res = (orc_interval*)malloc(cap * sizeof(orc_interval));
+    int run = 0;
+    uint32_t query_start = 0, len = 0;
+    for (uint32_t i = 0; i < block_len; i++) { /* :168-186 */
+        if (int_count[i] >= M) {
+            if (run == 0) {
+                run = 1;
+                query_start = i;
+            }
+            len++;
+        } else {
+            if (run == 1) {
+                run = 0;
+                if (n == cap) {
+                    cap *= 2;
+                    res = (orc_interval*)realloc(res, cap * sizeof(orc_interval));
+                }
+                res[n].query_start = query_start;
+                res[n].len = len;
+                n++;
+            }
+            query_start = 0;
+            len = 0;
+        }
+    }
+    free(int_count);
+    *out = res;
+    return n;
+}
+
+/* ---- repeat masker: block / interval plan (repeat_masker_src/main.cpp:316-436) ----------------------------------- */
+size_t orc_rm_plan(uint64_t seq_len, uint32_t seq_block_size, uint32_t lastz_interval_size, float prop_neigh_interval,
+                   uint32_t seed_size, orc_rm_task** out) {
+    if (seq_block_size == 1000000000u) seq_block_size -= seq_block_size % lastz_interval_size; /* :255-258 */
+    uint32_t total_query_intervals = (uint32_t)ceil((float)seq_len / lastz_interval_size);  /* :316 */
+    uint32_t num_neigh_interval = (uint32_t)ceil((float)prop_neigh_interval * total_query_intervals);
+    uint32_t left_intervals = (uint32_t)ceil((float)(num_neigh_interval - 1) / 2); /* :319 */
+    uint32_t right_intervals = num_neigh_interval - 1 - left_intervals;
+    uint32_t left_overlap = left_intervals * lastz_interval_size;
+    uint32_t right_overlap = right_intervals * lastz_interval_size;
+    uint32_t max_interval_seq_len = left_overlap + lastz_interval_size + right_overlap;
+    size_t cap = 64, n = 0;
+    orc_rm_task* res = (orc_rm_task*)malloc(cap * sizeof(orc_rm_task));
+    uint32_t block_index = 0;
+    for (uint64_t l = 0; l < seq_len; l += seq_block_size) { /* :341 */
+        uint64_t seq_block_start = (l < left_overlap) ? l : l - left_overlap;
+        uint32_t seq_block_len;
+        if (l + seq_block_size + right_overlap > seq_len)
+            seq_block_len = (uint32_t)(seq_len - seq_block_start);
+        else
+            seq_block_len = (uint32_t)(l - seq_block_start + seq_block_size) + right_overlap;
+        uint32_t start_pos = (uint32_t)(l - seq_block_start), end_pos;
+        if (seq_block_len < seq_block_size)
+            end_pos = start_pos + seq_block_len - (uint32_t)(l - seq_block_start) - seed_size;
+        else
+            end_pos = start_pos + seq_block_size - seed_size;
+        while (start_pos < end_pos) { /* :367 */
+            orc_rm_task t;
+            t.block_index = block_index;
+            t.block_start = seq_block_start;
+            t.block_len = seq_block_len;
+            t.start = start_pos;
+            t.end = end_pos < start_pos + lastz_interval_size ? end_pos : start_pos + lastz_interval_size;
+            int left_limit = t.start < left_overlap;
+            int right_limit = (t.end + right_overlap) > seq_block_len;
+            if (left_limit) {
+                t.ref_start = 0;
+                if (right_limit) t.ref_end = seq_block_len;
+                else t.ref_end = max_interval_seq_len > seq_block_len ? seq_block_len : max_interval_seq_len;
+            } else if (right_limit) {
+                t.ref_end = seq_block_len;
+                t.ref_start = seq_block_len < max_interval_seq_len ? 0 : seq_block_len - max_interval_seq_len;
+            } else {
+                t.ref_start = t.start - left_overlap;
+                t.ref_end = t.end + right_overlap;
+            }
+            if (n == cap) {
+                cap *= 2;
+                res = (orc_rm_task*)realloc(res, cap * sizeof(orc_rm_task));
+            }
+            res[n++] = t;
+            start_pos += lastz_interval_size;
+        }
+        block_index++;
+    }
+    *out = res;
+    return n;
+}

@@ -119,6 +119,18 @@ size_t orc_seed_and_filter(const orc_saf_params* p, const uint64_t* seeds, size_
 size_t orc_seed_and_filter_rm(const orc_saf_params* p, const uint64_t* seeds, size_t num_seeds, int rev,
                               uint32_t ref_start, uint32_t ref_end, orc_segment** out_vec, orc_saf_stats* stats);
 
+/* repeat-masker post-processing, repeat_masker_src/seeder.cpp:153-188: per-position uint8_t coverage counters
+ * incremented over query_start .. query_start+len-1 of every HSP, then runs with count >= M (a run still open at the
+ * end of the block is not written, :168-186).  Returns the number of {query_start,len} pairs stored in *out. */
+typedef struct { uint32_t query_start, len; } orc_interval;
+size_t orc_rm_coverage_intervals(const orc_segment* hsps, size_t num_hsps, uint32_t block_len, uint32_t M, orc_interval** out);
+
+/* repeat-masker interval plan, repeat_masker_src/main.cpp:316-436: blocks with neighbour overlap and, per
+ * lastz_interval of each block, the seed range [start,end) and the target window [ref_start, ref_end]. */
+typedef struct { uint32_t block_index; uint64_t block_start; uint32_t block_len, start, end, ref_start, ref_end; } orc_rm_task;
+size_t orc_rm_plan(uint64_t seq_len, uint32_t seq_block_size, uint32_t lastz_interval_size, float prop_neigh_interval,
+                   uint32_t seed_size, orc_rm_task** out);
+
 void orc_free(void* p);
 
 /* MAX_HITS exactly as computed at src/seed_filter.cu:832-841 from a device's totalGlobalMem. */

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libsegalign_hip.so")
-SOURCES = ["encode.hip", "scan.hip", "table.hip", "seeds.hip", "extend.hip", "dedup.hip", "engine.hip"]
+SOURCES = ["encode.hip", "scan.hip", "table.hip", "seeds.hip", "extend.hip", "dedup.hip", "coverage.hip", "engine.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 
@@ -50,6 +50,9 @@ def build_lib(force=False, verbose=False):
 
 HOST_SRC = os.path.join(HERE, "host", "segalign_host.cpp")
 HOST_BIN = os.path.join(HERE, "bin", "segalign_host")
+RM_HOST_SRC = os.path.join(HERE, "host", "segalign_rm_host.cpp")
+RM_HOST_BIN = os.path.join(HERE, "bin", "segalign_rm_host")
+HOST_COMMON = os.path.join(HERE, "host", "host_common.hpp")
 
 
 def build_host(force=False):
@@ -57,10 +60,11 @@ def build_host(force=False):
     build_lib()
     os.makedirs(os.path.dirname(HOST_BIN), exist_ok=True)
     hdr = os.path.join(HERE, "..", "include", "segalign_amd.h")
-    if force or _newer(HOST_SRC, HOST_BIN) or _newer(hdr, HOST_BIN) or _newer(LIB_PATH, HOST_BIN):
-        subprocess.check_call(["g++", "-std=c++11", "-O2", "-pthread", "-I", os.path.join(HERE, "..", "include"), HOST_SRC,
-                               "-o", HOST_BIN, "-L", LIB_DIR, "-lsegalign_hip", "-lz", "-Wl,-rpath," + LIB_DIR,
-                               "-Wl,-rpath,/opt/rocm/lib"])
+    for src, dst in ((HOST_SRC, HOST_BIN), (RM_HOST_SRC, RM_HOST_BIN)):
+        if force or _newer(src, dst) or _newer(hdr, dst) or _newer(HOST_COMMON, dst) or _newer(LIB_PATH, dst):
+            subprocess.check_call(["g++", "-std=c++11", "-O2", "-pthread", "-Wall", "-I", os.path.join(HERE, "..", "include"), src,
+                                   "-o", dst, "-L", LIB_DIR, "-lsegalign_hip", "-lz", "-Wl,-rpath," + LIB_DIR,
+                                   "-Wl,-rpath,/opt/rocm/lib"])
     return HOST_BIN
 
 

@@ -168,6 +168,10 @@ struct Slot {
     DevBuf<uint32_t> chain_is_head, chain_heads, chain_bucket_cnt, chain_bucket_start;
     DevBuf<EntRec> ent_list;
     DevBuf<sa_segment_pair> out16;
+    // repeat-masker coverage (coverage.hip): difference array over the block + scan/compaction scratch
+    DevBuf<uint32_t> cov_diff, cov_pre, cov_is_start, cov_is_end, cov_sidx, cov_eidx, cov_pairs;
+    uint32_t* d_cov_range = nullptr;  // {min query_start, max query_start+len} touched since the last reset
+    uint32_t* h_cov = nullptr;        // pinned: range + per-tile totals
     IterPlan* d_plan = nullptr;
     Counters* d_cnt = nullptr;
     // pinned host staging
@@ -301,7 +305,9 @@ static void slot_init(Slot& s, int dev) {
     hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
     s.d_plan = (IterPlan*)dev_malloc(sizeof(IterPlan), "plan");
     s.d_cnt = (Counters*)dev_malloc(sizeof(Counters), "counters");
-    if (hipHostMalloc((void**)&s.h_plan, sizeof(IterPlan)) != hipSuccess ||
+    s.d_cov_range = (uint32_t*)dev_malloc(2 * sizeof(uint32_t), "coverage range");
+    if (hipHostMalloc((void**)&s.h_cov, 8 * sizeof(uint32_t)) != hipSuccess ||
+        hipHostMalloc((void**)&s.h_plan, sizeof(IterPlan)) != hipSuccess ||
         hipHostMalloc((void**)&s.h_cnt, sizeof(Counters)) != hipSuccess) {
         fprintf(stderr, "Error: hipHostMalloc for slot staging failed\n");
         exit(12);
@@ -315,8 +321,12 @@ static void slot_destroy(Slot& s) {
     s.cand_list.release("candidate list");
     s.chain_tmp.release("chain"); s.chain_sorted.release("chain"); s.chain_is_head.release("chain");
     s.chain_heads.release("chain"); s.chain_bucket_cnt.release("chain"); s.chain_bucket_start.release("chain"); s.ent_list.release("entropy list");
-    dev_free(s.d_plan, "plan"); dev_free(s.d_cnt, "counters");
-    s.d_plan = nullptr; s.d_cnt = nullptr;
+    s.cov_diff.release("coverage"); s.cov_pre.release("coverage"); s.cov_is_start.release("coverage");
+    s.cov_is_end.release("coverage"); s.cov_sidx.release("coverage"); s.cov_eidx.release("coverage"); s.cov_pairs.release("coverage");
+    dev_free(s.d_plan, "plan"); dev_free(s.d_cnt, "counters"); dev_free(s.d_cov_range, "coverage range");
+    s.d_plan = nullptr; s.d_cnt = nullptr; s.d_cov_range = nullptr;
+    if (s.h_cov) hipHostFree(s.h_cov);
+    s.h_cov = nullptr;
     if (s.h_plan) hipHostFree(s.h_plan);
     if (s.h_cnt) hipHostFree(s.h_cnt);
     if (s.h_seeds) hipHostFree(s.h_seeds);
@@ -339,6 +349,10 @@ struct CoreArgs {
     int rm_rev;
     uint32_t rm_win_start, rm_win_end;
     uint32_t q_lo, q_hi;  // query positions of the seed words lie in [q_lo, q_hi) when the caller knows it (0,0 otherwise)
+    // repeat-masker coverage accumulation (sa_rm_mask_interval): the final HSPs of the call are counted into this
+    // difference array on the device instead of being returned
+    uint32_t* cov_diff;
+    uint32_t cov_diff_len;
 };
 
 static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa_segment_pair** out) {
@@ -539,10 +553,16 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     check_memcpy(hipMemcpyAsync(sl->h_cnt, sl->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st), "counters");
                     check_sync(st, "unique 2");
                     n_final = sl->h_cnt->uniq2;
-                    { ProfScope p(sl, "sort_rm_final"); launch_sort(sl->recA.p, sl->recB.p, n_final, ORDER_RM_FINAL, sl->sort_temp.p, sl->sort_temp.cap, st); }
-                    fin = sl->recB.p;
+                    if (ca.cov_diff) {  // coverage is order-independent: the final sort (rm :831) and the D2H are not needed
+                        ProfScope p(sl, "coverage_add");
+                        launch_coverage_add_hsprec(sl->recA.p, n_final, ca.cov_diff, ca.cov_diff_len, sl->d_cov_range, st);
+                        check_launch("coverage add");
+                    } else {
+                        { ProfScope p(sl, "sort_rm_final"); launch_sort(sl->recA.p, sl->recB.p, n_final, ORDER_RM_FINAL, sl->sort_temp.p, sl->sort_temp.cap, st); }
+                        fin = sl->recB.p;
+                    }
                 }
-                if (n_final > 0) {
+                if (n_final > 0 && fin) {
                     sl->out16.ensure(n_final, "out16");
                     if (sl->h_out_cap < n_final) {
                         if (sl->h_out) hipHostFree(sl->h_out);
@@ -563,6 +583,11 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
     }
     prof_flush(sl);
 
+    t_stats.num_hits = num_hits;
+    t_stats.num_survivors = survivors;
+    t_stats.num_anchors = n_final;
+    if (out == nullptr) return (size_t)n_final + 1;  // coverage mode: nothing is returned to the host
+
     // ---- return vector: header + HSPs (:804-827 ; rm :857-861) ----
     sa_segment_pair* res = (sa_segment_pair*)malloc(((size_t)n_final + 1) * sizeof(sa_segment_pair));
     memset(&res[0], 0, sizeof(sa_segment_pair));
@@ -577,9 +602,6 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
         res[0].score = (int32_t)(ta >> 32);
     }
     if (n_final) memcpy(res + 1, sl->h_out, (size_t)n_final * sizeof(sa_segment_pair));
-    t_stats.num_hits = num_hits;
-    t_stats.num_survivors = survivors;
-    t_stats.num_anchors = n_final;
     *out = res;
     return (size_t)n_final + 1;
 }
@@ -930,7 +952,7 @@ size_t sa_seed_and_filter(const uint64_t* seeds, size_t num_seeds, int rev, uint
     DevCtx* dc = g_dev[0];
     for (auto* d : g_dev) if (d->dev == sl->dev) dc = d;
     upload_seeds(sl, seeds, num_seeds);
-    CoreArgs ca = {rev ? dc->query_rc[buffer].codes : dc->query[buffer].codes, g_query_len[buffer], 0, 0, 0, 0, 0, 0};  // :762-767
+    CoreArgs ca = {rev ? dc->query_rc[buffer].codes : dc->query[buffer].codes, g_query_len[buffer], 0, 0, 0, 0, 0, 0, nullptr, 0};  // :762-767
     size_t n = saf_core(dc, sl, (uint32_t)num_seeds, ca, out);
     release_slot(sl);
     return n;
@@ -950,7 +972,7 @@ size_t sa_seed_and_filter_range(uint32_t start, uint32_t end, int rev, uint32_t 
     size_t n = 0;
     *out = nullptr;
     if (ns > 0) {  // seeder.cpp:76: the engine is only called for a non-empty seed vector
-        CoreArgs ca = {q, qlen, 0, 0, 0, 0, start, end};
+        CoreArgs ca = {q, qlen, 0, 0, 0, 0, start, end, nullptr, 0};
         n = saf_core(dc, sl, ns, ca, out);
     } else {
         prof_flush(sl);
@@ -1012,11 +1034,164 @@ size_t sa_rm_seed_and_filter(const uint64_t* seeds, size_t num_seeds, int rev, u
     DevCtx* dc = g_dev[0];
     for (auto* d : g_dev) if (d->dev == sl->dev) dc = d;
     upload_seeds(sl, seeds, num_seeds);
-    CoreArgs ca = {rev ? dc->ref_rc.codes : dc->ref.codes, dc->ref.len, 1, rev ? 1 : 0, ref_start, ref_end, 0, 0};  // rm :805-810
+    CoreArgs ca = {rev ? dc->ref_rc.codes : dc->ref.codes, dc->ref.len, 1, rev ? 1 : 0, ref_start, ref_end, 0, 0, nullptr, 0};  // rm :805-810
     size_t n = saf_core(dc, sl, (uint32_t)num_seeds, ca, out);
     release_slot(sl);
     return n;
 }
+
+// ---- repeat-masker post-processing on the device (8f-4) -------------------------------------------------------------
+namespace sa {
+
+constexpr uint32_t COV_TILE = 1u << 26;  // positions per scan tile (bounds the scratch at 5 x 256 MiB)
+
+// make the slot's difference array cover `block_len` positions, all zero, and reset the touched range
+static void coverage_begin(Slot* sl, uint32_t block_len) {
+    hipStream_t st = sl->stream;
+    const size_t need = (size_t)block_len + 1;
+    if (sl->cov_diff.cap < need) {  // a fresh allocation is cleared once; afterwards only the touched range is re-cleared
+        sl->cov_diff.ensure(need, "coverage diff");
+        check_memcpy(hipMemsetAsync(sl->cov_diff.p, 0, sl->cov_diff.cap * sizeof(uint32_t), st), "coverage diff");
+    }
+    launch_coverage_range_reset(sl->d_cov_range, st);
+    check_launch("coverage begin");
+}
+
+// runs with (depth mod 256) >= M over the touched range -> malloc-ed sa_interval list; leaves the array zeroed again
+static size_t coverage_finish(Slot* sl, uint32_t block_len, uint32_t M, uint64_t num_hsps, sa_interval** out) {
+    hipStream_t st = sl->stream;
+    *out = nullptr;
+    check_memcpy(hipMemcpyAsync(sl->h_cov, sl->d_cov_range, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st), "coverage range");
+    check_sync(st, "coverage range");
+    const uint32_t lo = sl->h_cov[0], hi = sl->h_cov[1];
+    if (lo == 0xFFFFFFFFu) return 0;  // nothing was counted: depth 0 everywhere (M == 0: one unterminated run, see below)
+    size_t n_out = 0;
+    // M == 0 makes every position of the block "covered": one run that reaches the end of the block and is therefore
+    // never written (seeder.cpp:168-186 has no flush after the loop)
+    if (M > 0 && M <= 255) {
+        // every run boundary sits on a position with a non-zero difference, so there are at most 2 per HSP
+        const uint64_t cap64 = std::min<uint64_t>(2 * num_hsps + 2, (uint64_t)block_len + 1);
+        const uint32_t cap = (uint32_t)std::min<uint64_t>(cap64, 0x7FFFFFFFull);
+        sl->cov_pairs.ensure((size_t)cap * 2, "coverage intervals");
+        const uint32_t span = hi - lo + 1;  // depth is 0 before lo and from hi on
+        const uint32_t tile_cap = std::min(span, COV_TILE);
+        sl->cov_pre.ensure((size_t)tile_cap + 1, "coverage scan");
+        sl->cov_is_start.ensure(tile_cap, "coverage scan");
+        sl->cov_is_end.ensure(tile_cap, "coverage scan");
+        sl->cov_sidx.ensure((size_t)tile_cap + 1, "coverage scan");
+        sl->cov_eidx.ensure((size_t)tile_cap + 1, "coverage scan");
+        sl->scan_temp.ensure(scan_temp_bytes(tile_cap), "scan temp");
+        uint32_t depth = 0, nstart = 0, nend = 0;
+        for (uint64_t off = 0; off < span; off += COV_TILE) {
+            const uint32_t n = (uint32_t)std::min<uint64_t>(COV_TILE, span - off);
+            const uint32_t pos0 = lo + (uint32_t)off;
+            const uint32_t* d = sl->cov_diff.p + pos0;
+            ProfScope p(sl, "coverage_runs");
+            launch_exclusive_scan_u32(d, sl->cov_pre.p, n, sl->scan_temp.p, st);
+            launch_coverage_flags(d, sl->cov_pre.p, n, depth, M, sl->cov_is_start.p, sl->cov_is_end.p, st);
+            launch_exclusive_scan_u32(sl->cov_is_start.p, sl->cov_sidx.p, n, sl->scan_temp.p, st);
+            launch_exclusive_scan_u32(sl->cov_is_end.p, sl->cov_eidx.p, n, sl->scan_temp.p, st);
+            launch_coverage_emit(sl->cov_is_start.p, sl->cov_is_end.p, sl->cov_sidx.p, sl->cov_eidx.p, n, pos0, nstart, nend, cap,
+                                 sl->cov_pairs.p, st);
+            check_launch("coverage runs");
+            check_memcpy(hipMemcpyAsync(&sl->h_cov[2], sl->cov_pre.p + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st), "coverage totals");
+            check_memcpy(hipMemcpyAsync(&sl->h_cov[3], sl->cov_sidx.p + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st), "coverage totals");
+            check_memcpy(hipMemcpyAsync(&sl->h_cov[4], sl->cov_eidx.p + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st), "coverage totals");
+            check_sync(st, "coverage totals");
+            depth += sl->h_cov[2];
+            nstart += sl->h_cov[3];
+            nend += sl->h_cov[4];
+        }
+        // the depth returns to 0 at `hi`, so every run that started has ended (nstart == nend)
+        n_out = std::min(nend, cap);
+        if (n_out > 0) {
+            launch_coverage_finish(sl->cov_pairs.p, (uint32_t)n_out, st);
+            check_launch("coverage finish");
+            sa_interval* res = (sa_interval*)malloc(n_out * sizeof(sa_interval));
+            if (!res) {
+                fprintf(stderr, "Error: malloc for the interval list failed\n");
+                exit(12);
+            }
+            check_memcpy(hipMemcpyAsync(res, sl->cov_pairs.p, n_out * sizeof(sa_interval), hipMemcpyDeviceToHost, st), "intervals");
+            check_sync(st, "intervals");
+            *out = res;
+        }
+    }
+    // leave the difference array zeroed for the next interval
+    check_memcpy(hipMemsetAsync(sl->cov_diff.p + lo, 0, ((size_t)hi - lo + 1) * sizeof(uint32_t), st), "coverage clear");
+    check_sync(st, "coverage clear");
+    return n_out;
+}
+
+}  // namespace sa
+
+size_t sa_rm_mask_interval(uint32_t start_pos, uint32_t end_pos, uint32_t ref_start, uint32_t ref_end, int strands, uint32_t M,
+                           sa_interval** out, uint64_t* totals) {  // repeat_masker_src/seeder.cpp:28-195
+    require_init("MaskInterval");
+    Slot* sl = acquire_slot();
+    DevCtx* dc = g_dev[0];
+    for (auto* d : g_dev) if (d->dev == sl->dev) dc = d;
+    const uint32_t block_len = dc->ref.len;
+    if (!dc->ref_rc.codes && (strands & SA_STRAND_MINUS)) {
+        fprintf(stderr, "Error: MaskInterval on the minus strand before SendQueryWriteRequest\n");
+        exit(1);
+    }
+    coverage_begin(sl, block_len);
+    // a seed window must lie inside the block (the reference reads its host arena past the block end for the last
+    // positions of the minus strand of a block's first interval: undefined there, no seed here)
+    const uint32_t lim = block_len >= g_seed_size ? block_len - g_seed_size + 1 : 0;
+    const uint32_t end_pos_rc = block_len - 1 - start_pos;  // seeder.cpp:46-47
+    uint64_t tot_seeds = 0, tot_hits = 0, tot_hsps = 0;
+    for (uint64_t i = start_pos; i < end_pos; i += g_wga_chunk) {  // :73
+        const uint32_t start = (uint32_t)i;
+        const uint32_t end = (uint32_t)std::min<uint64_t>(i + g_wga_chunk, end_pos);  // :76-77
+        for (int rev = 0; rev < 2; rev++) {
+            if (!(strands & (rev ? SA_STRAND_MINUS : SA_STRAND_PLUS))) continue;
+            uint32_t s0 = start, s1 = end;
+            if (rev) {  // :118-119: the minus-strand chunk is derived from the plus-strand chunk END
+                s0 = block_len - 1 - end;
+                s1 = (uint32_t)std::min<uint64_t>((uint64_t)s0 + g_wga_chunk, end_pos_rc);
+            }
+            if (s1 > lim) s1 = lim;
+            const uint8_t* q = rev ? dc->ref_rc.codes : dc->ref.codes;
+            const uint32_t ns = device_seeds(sl, q, s0, s1);
+            if (ns == 0) continue;  // :103,140
+            CoreArgs ca = {q, block_len, 1, rev, ref_start, ref_end, s0, s1, sl->cov_diff.p, block_len + 1};
+            saf_core(dc, sl, ns, ca, nullptr);
+            tot_seeds += ns;
+            tot_hits += t_stats.num_hits;
+            tot_hsps += t_stats.num_anchors;
+        }
+    }
+    const size_t n = coverage_finish(sl, block_len, M, tot_hsps, out);
+    prof_flush(sl);
+    release_slot(sl);
+    if (totals) { totals[0] = tot_seeds; totals[1] = tot_hits; totals[2] = tot_hsps; }
+    return n;
+}
+
+size_t sa_rm_coverage_intervals(const sa_segment_pair* hsps, size_t num_hsps, uint32_t block_len, uint32_t M, sa_interval** out) {
+    require_init("CoverageIntervals");  // repeat_masker_src/seeder.cpp:153-188
+    Slot* sl = acquire_slot();
+    hipStream_t st = sl->stream;
+    coverage_begin(sl, block_len);
+    const size_t BATCH = 1u << 24;
+    for (size_t off = 0; off < num_hsps; off += BATCH) {
+        const size_t n = std::min(BATCH, num_hsps - off);
+        sl->out16.ensure(n, "out16");
+        check_memcpy(hipMemcpyAsync(sl->out16.p, hsps + off, n * sizeof(sa_segment_pair), hipMemcpyHostToDevice, st), "hsps h2d");
+        launch_coverage_add_pairs(reinterpret_cast<const SegPair16*>(sl->out16.p), (uint32_t)n, sl->cov_diff.p, block_len + 1,
+                                  sl->d_cov_range, st);
+        check_launch("coverage add");
+        check_sync(st, "coverage add");
+    }
+    const size_t n = coverage_finish(sl, block_len, M, num_hsps, out);
+    prof_flush(sl);
+    release_slot(sl);
+    return n;
+}
+
+void sa_free_intervals(sa_interval* p) { free(p); }
 
 // ---- knobs ----------------------------------------------------------------------------------------------------------
 void sa_set_max_hits(int64_t max_hits) {

@@ -153,4 +153,16 @@ void launch_sort(const HspRec* in, HspRec* out, size_t n, SortOrder order, void*
 void launch_unique(const HspRec* in, HspRec* out, uint32_t n, int exact, uint32_t* out_count, hipStream_t s);
 void launch_strip(const HspRec* in, uint32_t n, void* out_segment_pairs, hipStream_t s);
 
+// ---- coverage.hip (repeat-masker post-processing, repeat_masker_src/seeder.cpp:153-188) ------------------------
+struct SegPair16 { uint32_t ref_start, query_start, len; int32_t score; };  // layout of sa_segment_pair / segmentPair
+void launch_coverage_range_reset(uint32_t* range /*{min start, max end}*/, hipStream_t s);
+void launch_coverage_add_hsprec(const HspRec* hsps, uint32_t n, uint32_t* diff, uint32_t diff_len, uint32_t* range, hipStream_t s);
+void launch_coverage_add_pairs(const SegPair16* hsps, uint32_t n, uint32_t* diff, uint32_t diff_len, uint32_t* range, hipStream_t s);
+void launch_coverage_flags(const uint32_t* diff, const uint32_t* pre, uint32_t n, uint32_t carry_depth, uint32_t M,
+                           uint32_t* is_start, uint32_t* is_end, hipStream_t s);
+void launch_coverage_emit(const uint32_t* is_start, const uint32_t* is_end, const uint32_t* start_idx, const uint32_t* end_idx,
+                          uint32_t n, uint32_t pos0, uint32_t start_base, uint32_t end_base, uint32_t cap, uint32_t* out_pairs,
+                          hipStream_t s);
+void launch_coverage_finish(uint32_t* pairs, uint32_t n, hipStream_t s);
+
 }  // namespace sa

@@ -34,7 +34,10 @@ C_ABI_SYMBOLS = [
     "sa_profile_enable", "sa_profile_reset", "sa_profile_num_entries", "sa_profile_get", "sa_get_ref_len",
     "sa_get_num_index", "sa_get_index_table_size", "sa_copy_ref_codes", "sa_copy_index_table", "sa_copy_pos_table",
     "sa_copy_query_codes", "sa_get_query_len", "sa_device_make_seeds", "sa_version",
+    "sa_rm_mask_interval", "sa_rm_coverage_intervals", "sa_free_intervals",
 ]
+IVL_DTYPE = np.dtype([("query_start", "<u4"), ("len", "<u4")])  # struct Segment, repeat_masker_src/graph.h:32-35
+STRAND_PLUS, STRAND_MINUS, STRAND_BOTH = 1, 2, 3
 
 
 class CallStats(C.Structure):
@@ -74,6 +77,12 @@ def lib():
     L.sa_free_segments.argtypes = [C.c_void_p]
     L.sa_rm_seed_and_filter.restype = C.c_size_t
     L.sa_rm_seed_and_filter.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.sa_rm_mask_interval.restype = C.c_size_t
+    L.sa_rm_mask_interval.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_void_p),
+                                      C.c_void_p]
+    L.sa_rm_coverage_intervals.restype = C.c_size_t
+    L.sa_rm_coverage_intervals.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.sa_free_intervals.argtypes = [C.c_void_p]
     L.sa_set_max_hits.argtypes = [C.c_int64]
     L.sa_get_max_hits.restype = C.c_int64
     L.sa_max_hits_for_mem.restype = C.c_int
@@ -195,6 +204,32 @@ def RmSeedAndFilter(seed_offset_vector, rev, ref_start, ref_end):
     out = C.c_void_p()
     n = lib().sa_rm_seed_and_filter(s.ctypes.data, s.size, int(bool(rev)), ref_start, ref_end, C.byref(out))
     return _take(n, out)
+
+
+def _take_intervals(n, out):
+    if n == 0 or not out.value:
+        return np.zeros(0, dtype=IVL_DTYPE)
+    buf = (C.c_char * (n * IVL_DTYPE.itemsize)).from_address(out.value)
+    iv = np.frombuffer(buf, dtype=IVL_DTYPE).copy()
+    lib().sa_free_intervals(out)
+    return iv
+
+
+def RmMaskInterval(start_pos, end_pos, ref_start, ref_end, strands=STRAND_BOTH, M=1):
+    """Device-side seeder_body::operator() of the repeat masker (repeat_masker_src/seeder.cpp:28-195) for one interval.
+    Returns (intervals, dict(num_seeds, num_hits, num_hsps))."""
+    out = C.c_void_p()
+    tot = (C.c_uint64 * 3)()
+    n = lib().sa_rm_mask_interval(start_pos, end_pos, ref_start, ref_end, strands, M, C.byref(out), tot)
+    return _take_intervals(n, out), dict(num_seeds=tot[0], num_hits=tot[1], num_hsps=tot[2])
+
+
+def RmCoverageIntervals(hsps, block_len, M=1):
+    """repeat_masker_src/seeder.cpp:153-188 on the device for HSPs the host collected (headers removed)."""
+    h = np.ascontiguousarray(hsps, dtype=SEG_DTYPE)
+    out = C.c_void_p()
+    n = lib().sa_rm_coverage_intervals(h.ctypes.data if h.size else None, h.size, block_len, M, C.byref(out))
+    return _take_intervals(n, out)
 
 
 # ---- knobs / introspection ---------------------------------------------------------------------------------------

@@ -123,3 +123,83 @@ def expected_outputs(O, target_records, query_records, shape="TTT0T00TT00T0T0TTT
                                         data_folder, rb, data_folder, qb, output_format, ydrop, hspthresh,
                                         "minus" if rev else "plus", base, base, output_format, base))
     return files, cmds
+
+
+# ---- repeat masker host (repeat_masker_src/main.cpp:283-436, seeder.cpp:28-195, segment_printer.cpp:8-65) -------------
+def rm_mask_interval(O, blk, ctx, start_pos, end_pos, ref_start, ref_end, strands, M, chunk, seed_size, kmer_size, transition,
+                     saf_kwargs):
+    """seeder_body::operator() of the repeat masker for one interval of block `blk` (ASCII bytes); ctx caches the
+    oracle-side encoded block, its reverse complement and its seed table."""
+    L = len(blk)
+    if "ref" not in ctx:
+        ctx["ref"] = O.encode(blk)
+        ctx["rc_ascii"] = O.rev_comp_ascii(blk, 0, L)
+        ctx["rc"] = O.rev_comp_codes(ctx["ref"])
+        ctx["index"], ctx["pos"] = O.generate_seed_pos_table(blk, 0, L, saf_kwargs.get("step", 1), seed_size, kmer_size)
+    kw = {k: v for k, v in saf_kwargs.items() if k != "step"}
+    end_pos_rc = L - 1 - start_pos
+    hsps = []
+    tot = dict(num_seeds=0, num_hits=0, num_hsps=0)
+    for i in range(start_pos, end_pos, chunk):
+        start, end = i, min(i + chunk, end_pos)
+        for rev in (False, True):
+            if not (strands & (2 if rev else 1)):
+                continue
+            s0, s1 = start, end
+            if rev:  # seeder.cpp:118-119: derived from the plus-strand chunk END
+                s0 = L - 1 - end
+                s1 = min(s0 + chunk, end_pos_rc)
+            s1 = min(s1, L - seed_size + 1)
+            seeds = O.make_seeds(ctx["rc_ascii"] if rev else blk, 0, s0, s1, seed_size, kmer_size, transition)
+            if seeds.size == 0:
+                continue
+            segs, st = O.seed_and_filter(ctx["ref"], ctx["rc"] if rev else ctx["ref"], ctx["index"], ctx["pos"], seeds,
+                                         seed_size=seed_size, rm=(rev, ref_start, ref_end), **kw)
+            tot["num_seeds"] += int(seeds.size)
+            tot["num_hits"] += int(st["num_hits"])
+            tot["num_hsps"] += int(segs.size - 1)
+            hsps.append(segs[1:])
+    allh = np.concatenate(hsps) if hsps else np.zeros(0, dtype=O.SEG_DTYPE)
+    return O.rm_coverage_intervals(allh, L, M), tot
+
+
+def rm_expected_outputs(O, records, shape="TTT0T00TT00T0T0TTTT", transition=True, step=1, xdrop=910, hspthresh=3000,
+                        noentropy=False, chunk=250000, interval=10000000, seq_block_size=1000000000, prop=0.2, M=1,
+                        strand="both", markend=False):
+    """{file name: text} the reference repeat masker would write for this FASTA content."""
+    kmer_size = O.generate_shape_pos(shape)
+    seed_size = len(shape)
+    sub_mat = O.build_sub_mat(xdrop)
+    buf = bytearray()
+    chr_name, chr_start, chr_len = [], [], []
+    for name, seq in records:  # main.cpp:283-305
+        chr_name.append(name)
+        chr_start.append(len(buf))
+        chr_len.append(len(seq))
+        buf += bytes(seq) + b"&"
+    buf = bytes(buf[:-1])
+    strands = {"plus": 1, "minus": 2, "both": 3}[strand]
+    tasks = O.rm_plan(len(buf), seq_block_size, interval, prop, seed_size)
+    files = {}
+    ctxs = {}
+    counters = {}
+    for t in tasks:
+        b = int(t["block_index"])
+        counters[b] = counters.get(b, 0) + 1
+        bs, bl = int(t["block_start"]), int(t["block_len"])
+        blk = buf[bs:bs + bl]
+        ctx = ctxs.setdefault(b, {})
+        ivs, _ = rm_mask_interval(O, blk, ctx, int(t["start"]), int(t["end"]), int(t["ref_start"]), int(t["ref_end"]), strands, M,
+                                  chunk, seed_size, kmer_size, transition,
+                                  dict(sub_mat=sub_mat, xdrop=xdrop, hspthresh=hspthresh, noentropy=noentropy, step=step))
+        if ivs.size == 0:
+            continue
+        lines = []
+        for iv in ivs:  # segment_printer.cpp:43-57
+            q = bs + int(iv["query_start"])
+            c = bisect.bisect_right(chr_start, q) - 1
+            lines.append("%s\t%d\t%d\n" % (chr_name[c], q - chr_start[c], q + int(iv["len"]) + 1 - chr_start[c]))
+        if markend:
+            lines.append("# segalign_repeat_masker end-of-file\n")
+        files["tmp%d.block%d.intervals" % (counters[b], b)] = "".join(lines)
+    return files

@@ -90,13 +90,15 @@ struct SeqBuf {  // encoded sequence with SEQ_PAD guard bytes on both sides
     uint8_t* alloc = nullptr;
     uint8_t* codes = nullptr;
     uint32_t len = 0;
-    void create(uint32_t n, const char* tag, hipStream_t s) {
+    void create(uint32_t n, const char* tag, hipStream_t s, bool row_coded = false) {
         release(tag);
         size_t bytes = (size_t)n + 2 * SEQ_PAD + 64;  // +64: the k-mer window reads 32 bytes from any position
         alloc = (uint8_t*)dev_malloc(bytes, tag);
         // guard bytes carry bit 6: OR-ed into a matrix index they select a terminator entry of the extension kernels'
-        // 128-entry table, so a window that runs over a block edge stops the walk without any bounds arithmetic
-        check_memcpy(hipMemsetAsync(alloc, 0x40, bytes, s), tag);
+        // 128-entry table, so a window that runs over a block edge stops the walk without any bounds arithmetic.
+        // Below the guard bit they hold the code 7 ('E', the record separator) in the buffer's own coding -- the
+        // pair-table filter masks the guard bit off and lets the matrix's E row / column end the walk
+        check_memcpy(hipMemsetAsync(alloc, row_coded ? 0x78 : 0x47, bytes, s), tag);
         codes = alloc + SEQ_PAD;
         len = n;
     }
@@ -431,6 +433,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     launch_expand_hits(sl->seeds.p, sl->start.p, sl->count.p, sl->prefix.p, (uint32_t)b_seed_lo,
                                        (uint32_t)b_seed_hi, b_hit_lo, dc->pos_table, g_seed_size, sl->hits.p, st);
                 }
+                ea.hits = sl->hits.p;
                 ea.ref8 = dc->ref8.codes;
                 ea.fin_batch = g_fin_batch;
                 ea.bufs_per_wave = g_bufs_per_wave;
@@ -441,7 +444,6 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                 ea.xdrop = g_xdrop;
                 ea.hspthresh = g_hspthresh;
                 ea.noentropy = g_noentropy;
-                ea.hits = sl->hits.p;
                 ea.num_hits = bh;
                 ea.hit_base = b_hit_lo;
                 ea.num_segs = nseg;
@@ -749,6 +751,15 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
         int mx = g_sub_mat[0];
         for (int i = 1; i < 64; i++) mx = std::max(mx, g_sub_mat[i]);
         g_fast_filter = (xdrop >= 0 && (int64_t)7 * std::max(mx, 0) <= (int64_t)xdrop) ? 1 : 0;
+        // pair-table filter (extend.hip 1b): int16 scores, drop test per 16-base window, E row/column as terminator
+        {
+            const int64_t m0 = std::max(mx, 0);
+            const int64_t need = (int64_t)xdrop + 15 * m0 + 1;  // fall that forces the drop test at the window end
+            bool ok = xdrop >= 0 && m0 * ((int64_t)g_long_cap + 16) <= 32767 && need <= 16383;
+            for (int i = 0; i < 8 && ok; i++)
+                if (g_sub_mat[7 * 8 + i] > -need || g_sub_mat[i * 8 + 7] > -need) ok = false;
+            if (ok && !getenv("SEGALIGN_AMD_NO_PAIR_FILTER")) g_fast_filter = 2;
+        }
         if (getenv("SEGALIGN_AMD_NO_FAST_FILTER")) g_fast_filter = 0;
         g_chain = getenv("SEGALIGN_AMD_NO_CHAIN") ? 0 : 1;
     }
@@ -805,7 +816,7 @@ void sa_send_ref_write_request(const char* seq, size_t addr, uint32_t len) {  //
         check_memcpy(hipMemcpyAsync(tmp, seq + addr, len, hipMemcpyHostToDevice, dc->admin), "ref_seq");
         dc->ref.create(len, "ref_seq", dc->admin);
         launch_encode(tmp, dc->ref.codes, len, dc->admin);
-        dc->ref8.create(len, "ref_seq rows", dc->admin);
+        dc->ref8.create(len, "ref_seq rows", dc->admin, true);
         launch_row_code(dc->ref.codes, dc->ref8.codes, len, dc->admin);
         check_launch("compress_string");
         check_sync(dc->admin, "SendRefWriteRequest");

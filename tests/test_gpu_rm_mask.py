@@ -126,10 +126,12 @@ def test_mask_interval_matches_reference_loop(oracle, rm_case, strands):
     c, E, O = rm_case, rm_case.E, oracle
     L = c.target.size
     for (s, e, ws, we, M) in ((0, L - 19, 0, L, 1), (40000, 130000, 20000, 150000, 1), (0, L - 19, 0, L, 2),
-                              (100000, 100001, 0, L, 1), (50000, 50000, 0, L, 1)):
+                              (100000, 100001, 0, L, 1), (50000, 50000, 0, L, 1),
+                              (100000, 160000, 0, 90000, 1), (0, 70000, 120000, L, 1), (100000, 160000, 0, 90000, 2)):
         want, wt = model_mask_interval(c, O, s, e, ws, we, strands, M)
         got, gt = E.RmMaskInterval(s, e, ws, we, strands, M)
         assert as_list(got) == as_list(want), (s, e, ws, we, M, as_list(got)[:4], as_list(want)[:4])
         assert gt == wt
-    want, _ = model_mask_interval(c, O, 0, L - 19, 0, L, 3, 1)
-    assert want.size > 20  # the planted family is found
+    # a window that excludes the interval itself leaves only the planted family (no trivial self-alignment)
+    want, _ = model_mask_interval(c, O, 100000, 160000, 0, 90000, 3, 1)
+    assert want.size > 10

@@ -80,6 +80,36 @@ __global__ __launch_bounds__(256) void row_code_kernel(const uint8_t* __restrict
         for (uint32_t i = nvec * 16 + threadIdx.x; i < len; i += blockDim.x) out[i] = (uint8_t)(codes[i] << 3);
 }
 
+// ---- packed copies for the packed X-drop filter (extend.hip 1c) ---------------------------------------------------
+// 2 bits per base, codes >= 4 stored as 0; PHASE copy k holds bases [4j+k, 4j+k+4) in byte j, so that a window that
+// starts (or ends) at ANY base position is byte aligned in the copy k = position & 3.
+__global__ __launch_bounds__(256) void pack2_phase_kernel(const uint8_t* __restrict__ codes, uint32_t len,
+                                                          uint8_t* __restrict__ out, size_t copy_stride, uint32_t nbytes) {
+    const uint64_t total = (uint64_t)nbytes * 4;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t k = (uint32_t)(i / nbytes), j = (uint32_t)(i % nbytes);
+        uint32_t v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const uint64_t pos = (uint64_t)j * 4 + k + b;
+            const uint32_t c = pos < len ? codes[pos] : 0u;
+            v |= (c < 4u ? c : 0u) << (2 * b);
+        }
+        out[k * copy_stride + j] = (uint8_t)v;
+    }
+}
+// 4 bits per base (code & 7), phase copy k holds bases [2j+k, 2j+k+2) in byte j, first base in the low nibble
+__global__ __launch_bounds__(256) void pack4_phase_kernel(const uint8_t* __restrict__ codes, uint32_t len,
+                                                          uint8_t* __restrict__ out, size_t copy_stride, uint32_t nbytes) {
+    const uint64_t total = (uint64_t)nbytes * 2;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t k = (uint32_t)(i / nbytes), j = (uint32_t)(i % nbytes);
+        const uint64_t p0 = (uint64_t)j * 2 + k, p1 = p0 + 1;
+        const uint32_t c0 = p0 < len ? (codes[p0] & 7u) : 7u, c1 = p1 < len ? (codes[p1] & 7u) : 7u;
+        out[k * copy_stride + j] = (uint8_t)(c0 | (c1 << 4));
+    }
+}
+
 static inline int grid_for(uint64_t work_items, int block, int max_blocks = 256 * 8) {
     uint64_t g = (work_items + block - 1) / block;
     if (g < 1) g = 1;
@@ -98,6 +128,12 @@ void launch_rev_comp_codes(const uint8_t* codes, uint8_t* codes_rc, uint32_t len
 void launch_row_code(const uint8_t* codes, uint8_t* out, uint32_t len, hipStream_t s) {
     if (len == 0) return;
     hipLaunchKernelGGL(row_code_kernel, dim3(grid_for(len / 16 + 1, 256)), dim3(256), 0, s, codes, out, len);
+}
+void launch_pack2_phases(const uint8_t* codes, uint32_t len, uint8_t* out, size_t copy_stride, uint32_t nbytes, hipStream_t s) {
+    hipLaunchKernelGGL(pack2_phase_kernel, dim3(grid_for((uint64_t)nbytes * 4, 256)), dim3(256), 0, s, codes, len, out, copy_stride, nbytes);
+}
+void launch_pack4_phases(const uint8_t* codes, uint32_t len, uint8_t* out, size_t copy_stride, uint32_t nbytes, hipStream_t s) {
+    hipLaunchKernelGGL(pack4_phase_kernel, dim3(grid_for((uint64_t)nbytes * 2, 256)), dim3(256), 0, s, codes, len, out, copy_stride, nbytes);
 }
 void launch_encode_rev_comp(const uint8_t* ascii, uint8_t* codes, uint8_t* codes_rc, uint32_t len, hipStream_t s) {
     // two streaming passes: the second reads the freshly written codes (L2 / Infinity Cache resident)

@@ -109,6 +109,30 @@ struct SeqBuf {  // encoded sequence with SEQ_PAD guard bytes on both sides
     }
 };
 
+struct PackedBuf {  // phase copies of a packed sequence (packed X-drop filter): copy k at base + k*stride
+    uint8_t* alloc = nullptr;
+    uint8_t* base = nullptr;
+    size_t stride = 0;
+    void create(const uint8_t* codes, uint32_t len, int bits, const char* tag, hipStream_t s) {
+        release(tag);
+        const int copies = bits == 2 ? 4 : 2;
+        const uint32_t nbytes = len / (bits == 2 ? 4 : 2) + 1;
+        stride = ((size_t)nbytes + 2 * PACK_PAD + 127) & ~(size_t)127;
+        alloc = (uint8_t*)dev_malloc(stride * copies, tag);
+        // pads: 2-bit copies read as code 0, 4-bit copies as code 7 in both nibbles (any content keeps the filter's
+        // scores upper bounds; these make a walk that leaves the block die quickly under the default matrices)
+        check_memcpy(hipMemsetAsync(alloc, bits == 2 ? 0x00 : 0x77, stride * copies, s), tag);
+        base = alloc + PACK_PAD;
+        if (bits == 2) launch_pack2_phases(codes, len, base, stride, nbytes, s);
+        else launch_pack4_phases(codes, len, base, stride, nbytes, s);
+    }
+    void release(const char* tag) {
+        dev_free(alloc, tag);
+        alloc = base = nullptr;
+        stride = 0;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------------------------
 // profiling: HIP events on the engine's own streams
 // ------------------------------------------------------------------------------------------------------------------
@@ -197,6 +221,8 @@ struct DevCtx {
     SeqBuf ref;
     SeqBuf ref8;                         // row-coded copy (code << 3) read by the extension kernel
     const char* ref_host_ptr = nullptr;  // identity of the block last sent (to skip a second upload for the table)
+    PackedBuf ref2;                      // 2-bit phase copies of the target (packed filter)
+    PackedBuf query4[SA_BUFFER_DEPTH], query4_rc[SA_BUFFER_DEPTH];  // 4-bit phase copies of the query strands
     SeqBuf ref_rc;                       // repeat masker
     uint32_t* bucket_start = nullptr;    // 4^k + 1
     uint32_t* pos_table = nullptr;
@@ -227,8 +253,10 @@ static int g_fin_batch = 48;      // SEGALIGN_AMD_FIN_BATCH
 static int g_bufs_per_wave = 8;   // SEGALIGN_AMD_BUFS_PER_WAVE
 static int g_long_cap = 128;      // SEGALIGN_AMD_LONG_CAP: bases per side before a hit goes to the long kernel
 static int g_long_blocks = 1792;  // SEGALIGN_AMD_LONG_BLOCKS: grid of the long kernel (4 waves per block)
+static int g_packed_waves = 6144; // SEGALIGN_AMD_PACKED_WAVES: waves of the packed filter (3 workgroups of 8 waves per CU measured best)
 static int g_max_waves = 4096;    // SEGALIGN_AMD_MAX_WAVES: waves of the filter kernel (4 per SIMD saturate instruction issue)
 static int g_fast_filter = 0;     // derived in InitializeProcessor: xdrop >= 0 && 7*max(M) <= xdrop
+static int g_packed_filter = 0;   // derived in InitializeProcessor: the packed upper-bound filter may be used
 static int g_chain = 1;           // chain shortcut of the exact stage (SEGALIGN_AMD_NO_CHAIN=1 turns it off)
 constexpr uint32_t CHAIN_CAP = 1u << 20;  // candidates per batch the chain buffers hold; larger batches fall back
 static SeedShape g_shape = {0, 0, 0, {0}};
@@ -355,6 +383,7 @@ struct CoreArgs {
     // difference array on the device instead of being returned
     uint32_t* cov_diff;
     uint32_t cov_diff_len;
+    const PackedBuf* query4;  // 4-bit phase copies of `query` (nullptr: the packed filter is not used for this call)
 };
 
 static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa_segment_pair** out) {
@@ -457,9 +486,16 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                 ea.long_cap = (uint32_t)g_long_cap;
                 ea.cand_count = &sl->d_cnt->n_long;
                 ea.fast_filter = g_fast_filter;
+                if (g_packed_filter && ca.query4 && ca.query4->base && dc->ref2.base && !g_count_examined) {
+                    ea.fast_filter = 3;  // packed upper-bound filter (extend.hip 1c)
+                    ea.ref2 = dc->ref2.base;
+                    ea.ref2_stride = dc->ref2.stride;
+                    ea.query4 = ca.query4->base;
+                    ea.query4_stride = ca.query4->stride;
+                }
                 ea.ent_count = &sl->d_cnt->n_ent;
                 ea.long_blocks = (uint32_t)g_long_blocks;
-                ea.max_waves = (uint32_t)g_max_waves;
+                ea.max_waves = (uint32_t)(ea.fast_filter == 3 ? g_packed_waves : g_max_waves);
                 ea.ent_blocks = 64;
                 sl->cand_list.ensure((size_t)std::max<uint64_t>(1u << 16, bh / 16), "candidate list");
                 // chain shortcut: valid for the plain X-drop recurrence (xdrop >= 0), not for the repeat masker's window
@@ -734,6 +770,7 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
     if (const char* e = getenv("SEGALIGN_AMD_LONG_CAP")) g_long_cap = std::max(0, atoi(e)) & ~7;
     if (const char* e = getenv("SEGALIGN_AMD_LONG_BLOCKS")) g_long_blocks = std::max(1, atoi(e));
     if (const char* e = getenv("SEGALIGN_AMD_MAX_WAVES")) g_max_waves = std::max(4, atoi(e));
+    if (const char* e = getenv("SEGALIGN_AMD_PACKED_WAVES")) g_packed_waves = std::max(8, atoi(e));
     if (xdrop >= (1 << 25) || xdrop <= -(1 << 25)) {
         fprintf(stderr, "Error: |xdrop| must be below 2^25\n");
         exit(1);
@@ -760,7 +797,9 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
                 if (g_sub_mat[7 * 8 + i] > -need || g_sub_mat[i * 8 + 7] > -need) ok = false;
             if (ok && !getenv("SEGALIGN_AMD_NO_PAIR_FILTER")) g_fast_filter = 2;
         }
-        if (getenv("SEGALIGN_AMD_NO_FAST_FILTER")) g_fast_filter = 0;
+        g_packed_filter = (xdrop >= 0 && (int64_t)std::max(mx, 0) * ((int64_t)g_long_cap + 16) <= 32767 &&
+                           !getenv("SEGALIGN_AMD_NO_PACKED_FILTER")) ? 1 : 0;
+        if (getenv("SEGALIGN_AMD_NO_FAST_FILTER")) { g_fast_filter = 0; g_packed_filter = 0; }
         g_chain = getenv("SEGALIGN_AMD_NO_CHAIN") ? 0 : 1;
     }
     std::lock_guard<std::mutex> lk(g_mu);
@@ -788,6 +827,7 @@ void sa_shutdown_processor(void) {  // src/seed_filter.cu:932-940
         for (int k = 0; k < MAX_SLOTS_PER_DEVICE; k++) if (dc->slots[k].stream) slot_destroy(dc->slots[k]);
         dc->ref.release("d_ref_seq");
         dc->ref8.release("d_ref_seq rows");
+        dc->ref2.release("d_ref_seq 2-bit");
         dc->ref_rc.release("d_seq_rc");
         dev_free(dc->bucket_start, "d_index_table");
         dev_free(dc->pos_table, "d_pos_table");
@@ -795,6 +835,8 @@ void sa_shutdown_processor(void) {  // src/seed_filter.cu:932-940
         for (int b = 0; b < SA_BUFFER_DEPTH; b++) {
             dc->query[b].release("d_query_seq");
             dc->query_rc[b].release("d_query_rc_seq");
+            dc->query4[b].release("d_query_seq 4-bit");
+            dc->query4_rc[b].release("d_query_rc_seq 4-bit");
         }
         dev_free(dc->d_sub_mat, "sub_mat");
         dc->d_sub_mat = nullptr;
@@ -818,6 +860,7 @@ void sa_send_ref_write_request(const char* seq, size_t addr, uint32_t len) {  //
         launch_encode(tmp, dc->ref.codes, len, dc->admin);
         dc->ref8.create(len, "ref_seq rows", dc->admin, true);
         launch_row_code(dc->ref.codes, dc->ref8.codes, len, dc->admin);
+        dc->ref2.create(dc->ref.codes, len, 2, "ref_seq 2-bit", dc->admin);
         check_launch("compress_string");
         check_sync(dc->admin, "SendRefWriteRequest");
         dev_free(tmp, "d_ref_seq_tmp");
@@ -830,6 +873,7 @@ void sa_clear_ref(void) {  // seed_filter_interface.cu:103-113
         check_set_device(dc->dev, "ClearRef");
         dc->ref.release("d_ref_seq");
         dc->ref8.release("d_ref_seq rows");
+        dc->ref2.release("d_ref_seq 2-bit");
         dc->ref_host_ptr = nullptr;
         dev_free(dc->bucket_start, "d_index_table");
         dev_free(dc->pos_table, "d_pos_table");
@@ -935,6 +979,8 @@ void sa_send_query_write_request(const char* query_buffer, size_t addr, uint32_t
         dc->query[buffer].create(len, "query_seq", st);
         dc->query_rc[buffer].create(len, "query_rc_seq", st);
         launch_encode_rev_comp(tmp, dc->query[buffer].codes, dc->query_rc[buffer].codes, len, st);
+        dc->query4[buffer].create(dc->query[buffer].codes, len, 4, "query_seq 4-bit", st);
+        dc->query4_rc[buffer].create(dc->query_rc[buffer].codes, len, 4, "query_rc_seq 4-bit", st);
         check_launch("compress_string_rev_comp");
         check_sync(st, "SendQueryWriteRequest");
         dev_free(tmp, "d_query_seq_tmp");
@@ -947,6 +993,8 @@ void sa_clear_query(uint32_t buffer) {  // :921-930
         check_set_device(dc->dev, "ClearQuery");
         dc->query[buffer].release("d_query_seq");
         dc->query_rc[buffer].release("d_query_rc_seq");
+        dc->query4[buffer].release("d_query_seq 4-bit");
+        dc->query4_rc[buffer].release("d_query_rc_seq 4-bit");
     }
 }
 
@@ -963,7 +1011,8 @@ size_t sa_seed_and_filter(const uint64_t* seeds, size_t num_seeds, int rev, uint
     DevCtx* dc = g_dev[0];
     for (auto* d : g_dev) if (d->dev == sl->dev) dc = d;
     upload_seeds(sl, seeds, num_seeds);
-    CoreArgs ca = {rev ? dc->query_rc[buffer].codes : dc->query[buffer].codes, g_query_len[buffer], 0, 0, 0, 0, 0, 0, nullptr, 0};  // :762-767
+    CoreArgs ca = {rev ? dc->query_rc[buffer].codes : dc->query[buffer].codes, g_query_len[buffer], 0, 0, 0, 0, 0, 0, nullptr, 0,
+                   rev ? &dc->query4_rc[buffer] : &dc->query4[buffer]};  // :762-767
     size_t n = saf_core(dc, sl, (uint32_t)num_seeds, ca, out);
     release_slot(sl);
     return n;
@@ -983,7 +1032,7 @@ size_t sa_seed_and_filter_range(uint32_t start, uint32_t end, int rev, uint32_t 
     size_t n = 0;
     *out = nullptr;
     if (ns > 0) {  // seeder.cpp:76: the engine is only called for a non-empty seed vector
-        CoreArgs ca = {q, qlen, 0, 0, 0, 0, start, end, nullptr, 0};
+        CoreArgs ca = {q, qlen, 0, 0, 0, 0, start, end, nullptr, 0, rev ? &dc->query4_rc[buffer] : &dc->query4[buffer]};
         n = saf_core(dc, sl, ns, ca, out);
     } else {
         prof_flush(sl);
@@ -1045,7 +1094,7 @@ size_t sa_rm_seed_and_filter(const uint64_t* seeds, size_t num_seeds, int rev, u
     DevCtx* dc = g_dev[0];
     for (auto* d : g_dev) if (d->dev == sl->dev) dc = d;
     upload_seeds(sl, seeds, num_seeds);
-    CoreArgs ca = {rev ? dc->ref_rc.codes : dc->ref.codes, dc->ref.len, 1, rev ? 1 : 0, ref_start, ref_end, 0, 0, nullptr, 0};  // rm :805-810
+    CoreArgs ca = {rev ? dc->ref_rc.codes : dc->ref.codes, dc->ref.len, 1, rev ? 1 : 0, ref_start, ref_end, 0, 0, nullptr, 0, nullptr};  // rm :805-810
     size_t n = saf_core(dc, sl, (uint32_t)num_seeds, ca, out);
     release_slot(sl);
     return n;
@@ -1167,7 +1216,7 @@ size_t sa_rm_mask_interval(uint32_t start_pos, uint32_t end_pos, uint32_t ref_st
             const uint8_t* q = rev ? dc->ref_rc.codes : dc->ref.codes;
             const uint32_t ns = device_seeds(sl, q, s0, s1);
             if (ns == 0) continue;  // :103,140
-            CoreArgs ca = {q, block_len, 1, rev, ref_start, ref_end, s0, s1, sl->cov_diff.p, block_len + 1};
+            CoreArgs ca = {q, block_len, 1, rev, ref_start, ref_end, s0, s1, sl->cov_diff.p, block_len + 1, nullptr};
             saf_core(dc, sl, ns, ca, nullptr);
             tot_seeds += ns;
             tot_hits += t_stats.num_hits;

@@ -49,6 +49,10 @@ struct EntRec {               // finished hit with hspthresh <= total <= 3*hspth
 };
 
 struct ExtendArgs {
+    const uint8_t* ref2;      // packed filter: 2-bit target, phase copy k at ref2 + k*ref2_stride (byte 0 = bases k..k+3)
+    size_t ref2_stride;
+    const uint8_t* query4;    // packed filter: 4-bit query of this call's strand, phase copy k at query4 + k*query4_stride
+    size_t query4_stride;
     const uint8_t* ref8;      // ROW-CODED target: byte = code << 3 (points past the front pad)
     const uint8_t* query;     // encoded query, fwd or rc
     uint32_t ref_len;
@@ -101,6 +105,10 @@ void launch_encode_rev_comp(const uint8_t* ascii, uint8_t* codes, uint8_t* codes
 void launch_rev_comp_codes(const uint8_t* codes, uint8_t* codes_rc, uint32_t len, hipStream_t s);
 // row-coded copy of the target for the extension kernel: out[i] = codes[i] << 3
 void launch_row_code(const uint8_t* codes, uint8_t* out, uint32_t len, hipStream_t s);
+// phase copies for the packed filter: out + k*copy_stride is copy k (4 copies at 2 bit/base, 2 copies at 4 bit/base)
+constexpr int PACK_PAD = 64;  // pad bytes in front of / behind every packed copy
+void launch_pack2_phases(const uint8_t* codes, uint32_t len, uint8_t* out, size_t copy_stride, uint32_t nbytes, hipStream_t s);
+void launch_pack4_phases(const uint8_t* codes, uint32_t len, uint8_t* out, size_t copy_stride, uint32_t nbytes, hipStream_t s);
 
 // ---- scan.hip --------------------------------------------------------------------------------------------------
 // exclusive prefix of n u32 values; out_excl[n] receives the total.  OutT = uint32_t or uint64_t.

@@ -253,7 +253,7 @@ static int g_fin_batch = 48;      // SEGALIGN_AMD_FIN_BATCH
 static int g_bufs_per_wave = 8;   // SEGALIGN_AMD_BUFS_PER_WAVE
 static int g_long_cap = 128;      // SEGALIGN_AMD_LONG_CAP: bases per side before a hit goes to the long kernel
 static int g_long_blocks = 1792;  // SEGALIGN_AMD_LONG_BLOCKS: grid of the long kernel (4 waves per block)
-static int g_packed_waves = 6144; // SEGALIGN_AMD_PACKED_WAVES: waves of the packed filter (3 workgroups of 8 waves per CU measured best)
+static int g_packed_waves = 4096; // SEGALIGN_AMD_PACKED_WAVES: waves of the packed filter (2 workgroups of 8 waves per CU measured best: 3072 +16 %, 6144 +20 %, 8192 +14 %)
 static int g_max_waves = 4096;    // SEGALIGN_AMD_MAX_WAVES: waves of the filter kernel (4 per SIMD saturate instruction issue)
 static int g_fast_filter = 0;     // derived in InitializeProcessor: xdrop >= 0 && 7*max(M) <= xdrop
 static int g_packed_filter = 0;   // derived in InitializeProcessor: the packed upper-bound filter may be used

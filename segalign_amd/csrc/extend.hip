@@ -598,213 +598,6 @@ __global__ __launch_bounds__(PAIR_THREADS) void extend_filter_pair_kernel(Extend
     stage_flush(stage, n_stage, a.cand_list, a.cand_count, a.cand_cap_recs, lane);
 }
 
-// One combined window of 16 matrix indices in WALKING order (byte 0 = first base walked).
-struct Win16 { uint32_t d0, d1, d2, d3; };
-__device__ __forceinline__ Win16 win_fwd(const uint4& rw, const uint4& qw) {
-    const uint32_t K = 0x3F3F3F3Fu;  // strips the guard bit of pad bytes: they then read as code 7
-    return Win16{(rw.x | qw.x) & K, (rw.y | qw.y) & K, (rw.z | qw.z) & K, (rw.w | qw.w) & K};
-}
-__device__ __forceinline__ Win16 win_rev(const uint4& rw, const uint4& qw) {  // left side: last byte first
-    const uint32_t K = 0x3F3F3F3Fu, R = 0x00010203u;
-    return Win16{__builtin_amdgcn_perm(0u, (rw.w | qw.w) & K, R), __builtin_amdgcn_perm(0u, (rw.z | qw.z) & K, R),
-                 __builtin_amdgcn_perm(0u, (rw.y | qw.y) & K, R), __builtin_amdgcn_perm(0u, (rw.x | qw.x) & K, R)};
-}
-__device__ __forceinline__ Win16 win_sel(bool c, const Win16& a, const Win16& b) {
-    return Win16{c ? a.d0 : b.d0, c ? a.d1 : b.d1, c ? a.d2 : b.d2, c ? a.d3 : b.d3};
-}
-
-// Memory behaviour (measured, tools/micro): the memory system delivers ~57 G random 128-byte lines per second and a
-// divergent 16-byte load costs the L1 ~140 clocks per wave, so the kernel is priced in LINES and LOAD INSTRUCTIONS
-// per hit, not in bytes.  A new hit therefore fetches its whole typical neighbourhood [loc-48, loc+32) at once --
-// five windows per sequence, 1 + 79/128 = 1.6 lines -- instead of one window per trip (the same lines were re-fetched
-// after eviction: 2.2 per hit); only the ~25 % longer walks load further windows, and those loads are issued together
-// with the refill loads so that a loop iteration waits for memory once.
-__global__ __launch_bounds__(PAIR_THREADS) void extend_filter_pair_pre_kernel(ExtendArgs a) {
-    extern __shared__ uint32_t s_dyn[];
-    uint32_t* s_pair = s_dyn;
-    CandRec* s_cand = reinterpret_cast<CandRec*>(s_dyn + PAIR_TAB);
-    for (int i = threadIdx.x; i < PAIR_TAB; i += PAIR_THREADS) {
-        const int b0 = i & 0x3f, b1 = (i >> 8) & 0x3f;
-        const int s0 = max(a.sub_mat[b0], -16383), s1 = max(a.sub_mat[b1], -16383);
-        s_pair[i] = ((uint32_t)s0 & 0xffffu) | ((uint32_t)(s0 + s1) << 16);
-    }
-    __syncthreads();
-    CandRec* stage = s_cand + (threadIdx.x >> 6) * STAGE_CAP;
-    int n_stage = 0;
-
-    const int lane = threadIdx.x & 63;
-    const unsigned long long lane_lt = (1ull << lane) - 1ull;
-    const uint8_t* __restrict__ R8b = a.ref8 - BIAS;  // row-coded target: byte = r << 3 (pads: 0x78)
-    const uint8_t* __restrict__ Qb = a.query - BIAS;  // plain codes (pads: 0x47)
-    const int xdrop = a.xdrop;
-    const int fin_batch = a.fin_batch;
-    const uint32_t long_cap = a.long_cap;
-
-    // ---- the wave's queue: 64-hit buffers, round-robin over all waves of the grid ----
-    const uint64_t num_buf = (a.num_hits + 63) >> 6;
-    const uint64_t G = (uint64_t)gridDim.x * (PAIR_THREADS / 64);
-    uint64_t cur_buf = (uint64_t)blockIdx.x * (PAIR_THREADS / 64) + (threadIdx.x >> 6);
-    uint64_t nxt_buf = cur_buf + G;
-    auto buf_count = [&](uint64_t b) -> int {
-        if (b >= num_buf) return 0;
-        uint64_t rem = a.num_hits - (b << 6);
-        return rem >= 64 ? 64 : (int)rem;
-    };
-    int buf_cnt = buf_count(cur_buf), nxt_cnt = buf_count(nxt_buf), consumed = 0;
-    Hit buf = {0u, 0u}, nxt = {0u, 0u};
-    if (lane < buf_cnt) buf = a.hits[(cur_buf << 6) + lane];
-    if (lane < nxt_cnt) nxt = a.hits[(nxt_buf << 6) + lane];
-
-    // ---- per-lane state ----
-    int phase = PH_FIN;  // "finished" with nothing to emit: the first trip refills every lane
-    bool has_hit = false, forward = false;
-    uint32_t ref_loc = 0, query_loc = 0, hidx = 0;
-    uint32_t walked = 0;           // bases walked on this side (multiple of 16)
-    s16x2 T = {0, 0}, M = {0, 0};  // T.y = running score ; max(M.x, M.y) = running best
-    int bestR = 0, best = 0;
-    const Win16 Z = {0u, 0u, 0u, 0u};
-    Win16 pR0 = Z, pR1 = Z, pL0 = Z, pL1 = Z, pL2 = Z;  // preloaded windows of the current hit
-    Win16 gw = Z;                                         // the next window of a walk that outran them
-
-    for (;;) {
-        // ================= 1. advance every live lane by one 16-base window =================
-        if (phase < PH_FIN) {
-            const bool left = phase == PH_LEFT;
-            const uint32_t k = walked >> 4;
-            Win16 w = left ? pL0 : pR0;
-            w = win_sel(k == 1u, left ? pL1 : pR1, w);
-            w = win_sel(left ? k == 2u : false, pL2, w);
-            w = win_sel(left ? k >= 3u : k >= 2u, gw, w);
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint32_t x = j < 2 ? w.d0 : j < 4 ? w.d1 : j < 6 ? w.d2 : w.d3;
-                uint32_t addr;  // byte address of the entry: (16-bit half of x) << 2 in one SDWA shift
-                if (j & 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(addr) : "v"(2), "v"(x));
-                else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(addr) : "v"(2), "v"(x));
-                const s16x2 e = __builtin_bit_cast(s16x2, *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_pair) + addr));
-                const s16x2 Tb = T.yy;
-                T = __builtin_elementwise_add_sat(Tb, e);  // {t + s0, t + s0 + s1}
-                M = __builtin_elementwise_max(M, T);
-            }
-            const int m = max((int)M.x, (int)M.y), t = (int)T.y;
-            const bool dropped = (m - t) > xdrop;
-            walked += 16;
-            if (dropped) {
-                if (!left) {  // -> left side (:457-476): anchor-1, anchor-2, ...
-                    bestR = m;
-                    phase = PH_LEFT;
-                    walked = 0;
-                    T = (s16x2){0, 0};
-                    M = (s16x2){0, 0};
-                } else {
-                    best = m;
-                    phase = PH_FIN;
-                }
-            } else if (walked >= long_cap) {  // still alive after long_cap bases: real homology -> exact kernel
-                forward = true;
-                phase = PH_FIN;
-            }
-        }
-
-        // ================= 2. finalise + refill in batches =================
-        const unsigned long long fin = __ballot(phase == PH_FIN);
-        const unsigned long long live = __ballot(phase < PH_FIN);
-        bool fresh = false;  // this lane starts a new hit: its five windows are loaded below
-        if (fin != 0ull && (__popcll(fin) >= fin_batch || live == 0ull)) {
-            bool cand = false;
-            if (phase == PH_FIN && has_hit) cand = forward || classify(a, bestR + best) != 0;
-            {
-                CandRec cr;
-                cr.ref_loc = ref_loc; cr.query_loc = query_loc; cr.hidx = hidx;
-                stage_append(stage, n_stage, cand, cr, a.cand_list, a.cand_count, a.cand_cap_recs, lane, lane_lt);
-            }
-            unsigned long long need = fin;
-            bool got = false;
-            Hit mine = {0u, 0u};
-            uint32_t mine_idx = 0;
-            while (need != 0ull) {
-                const int avail = buf_cnt - consumed;
-                if (avail <= 0) {
-                    if (nxt_cnt == 0) break;  // queue exhausted
-                    buf = nxt;
-                    buf_cnt = nxt_cnt;
-                    cur_buf = nxt_buf;
-                    consumed = 0;
-                    nxt_buf += G;
-                    nxt_cnt = buf_count(nxt_buf);
-                    if (lane < nxt_cnt) nxt = a.hits[(nxt_buf << 6) + lane];
-                    continue;
-                }
-                const int rank = __popcll(need & lane_lt);
-                const bool take = ((need >> lane) & 1ull) && rank < avail;
-                const int src = (consumed + rank) & 63;
-                const uint32_t hr = (uint32_t)__shfl((int)buf.ref_loc, src, 64);
-                const uint32_t hq = (uint32_t)__shfl((int)buf.query_loc, src, 64);
-                if (take) {
-                    mine.ref_loc = hr;
-                    mine.query_loc = hq;
-                    mine_idx = (uint32_t)(cur_buf << 6) + (uint32_t)src;
-                    got = true;
-                }
-                consumed += min(__popcll(need), avail);
-                need &= ~__ballot(take);
-            }
-            if (phase == PH_FIN) {
-                forward = false;
-                if (got) {
-                    has_hit = true;
-                    ref_loc = mine.ref_loc;
-                    query_loc = mine.query_loc;
-                    hidx = mine_idx;
-                    bool skip = false;
-                    if (a.rm) skip = !(ref_loc >= a.rm_win_start && ref_loc <= a.rm_win_end);  // rm :239-244,:305-333
-                    bestR = 0;
-                    best = 0;
-                    if (ref_loc > a.ref_len || query_loc > a.query_len) skip = true;  // see extend_filter_kernel
-                    if (skip) {
-                        phase = PH_FIN;
-                    } else {
-                        phase = PH_RIGHT;  // :299-324
-                        walked = 0;
-                        T = (s16x2){0, 0};
-                        M = (s16x2){0, 0};
-                        fresh = true;
-                    }
-                } else {
-                    has_hit = false;
-                    phase = PH_IDLE;
-                }
-            }
-        }
-        if (__ballot(phase != PH_IDLE) == 0ull) break;
-
-        // ================= 3. one round of loads: new hits' neighbourhoods + the next window of long walks =================
-        const bool left_now = phase == PH_LEFT;
-        const bool more = !fresh && phase < PH_FIN && (left_now ? walked >= 48u : walked >= 32u);
-        uint4 r0, r1, r2, r3, r4, q0, q1, q2, q3, q4, rg, qg;
-        if (fresh) {  // bytes [loc-48, loc+32) of both sequences (pads cover the block edges)
-            const uint8_t* rp = R8b + (ref_loc + BIAS - 48u);
-            const uint8_t* qp = Qb + (query_loc + BIAS - 48u);
-            r0 = load16u(rp); r1 = load16u(rp + 16); r2 = load16u(rp + 32); r3 = load16u(rp + 48); r4 = load16u(rp + 64);
-            q0 = load16u(qp); q1 = load16u(qp + 16); q2 = load16u(qp + 32); q3 = load16u(qp + 48); q4 = load16u(qp + 64);
-        }
-        if (more) {  // right: [loc+walked, +16) ; left: [loc-walked-16, loc-walked)
-            const uint32_t d = left_now ? 0u - walked - 16u : walked;
-            rg = load16u(R8b + (ref_loc + BIAS + d));
-            qg = load16u(Qb + (query_loc + BIAS + d));
-        }
-        if (fresh) {
-            pL2 = win_rev(r0, q0);
-            pL1 = win_rev(r1, q1);
-            pL0 = win_rev(r2, q2);
-            pR0 = win_fwd(r3, q3);
-            pR1 = win_fwd(r4, q4);
-        }
-        if (more) gw = left_now ? win_rev(rg, qg) : win_fwd(rg, qg);
-    }
-    stage_flush(stage, n_stage, a.cand_list, a.cand_count, a.cand_cap_recs, lane);
-}
-
 // =====================================================================================================================
 // 1c. the X-drop filter, PACKED form: 2-bit target, 4-bit query, an upper bound priced in lines and load instructions
 // =====================================================================================================================
@@ -880,64 +673,68 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
     int phase = PH_FIN;
     bool has_hit = false, forward = false;
     uint32_t ref_loc = 0, query_loc = 0, hidx = 0;
-    uint32_t walked = 0;  // bases walked on this side (multiple of 16)
-    uint32_t tw0 = 0, tw1 = 0, tw2 = 0, tw3 = 0;  // held target window: 4 x 16 bases in walking order
-    uint32_t qw0 = 0, qw1 = 0, qw2 = 0, qw3 = 0, qw4 = 0, qw5 = 0, qw6 = 0, qw7 = 0;  // held query window: 4 x 16 bases
+    uint32_t walked = 0;  // bases walked on this side (multiple of 64)
     s16x2 T = {0, 0}, M = {0, 0};
     int bestR = 0, best = 0;
 
     for (;;) {
-        // ================= 1. advance every live lane by one 16-base window =================
+        // ================= 1. advance every live lane by one 64-base window of its current side =================
+        // Every lane enters with a fresh window, so the four 16-base steps below read fixed registers (no per-lane
+        // selection of the held dwords) and a lane that drops simply sits out the remaining steps.
         if (phase < PH_FIN) {
             const bool left = phase == PH_LEFT;
-            const uint32_t k = walked >> 4;
-            if ((k & 3u) == 0u) {  // every 64 bases: 16 bytes of the 2-bit target and 32 bytes of the 4-bit query
-                // signed positions: a long left walk near the block start may reach below 0 (pad bytes)
-                const int32_t qpos = left ? (int32_t)query_loc - (int32_t)walked : (int32_t)(query_loc + walked);
-                const int32_t qbyte = left ? (qpos >> 1) - 32 : (qpos >> 1);
-                const uint8_t* qp = a.query4 + (size_t)(qpos & 1) * a.query4_stride + qbyte;
-                const uint4 qlo = load16u(qp), qhi = load16u(qp + 16);
-                const int32_t tpos = left ? (int32_t)ref_loc - (int32_t)walked : (int32_t)(ref_loc + walked);
-                const int32_t tbyte = left ? (tpos >> 2) - 16 : (tpos >> 2);
-                const uint4 tw = load16u(a.ref2 + (size_t)(tpos & 3) * a.ref2_stride + tbyte);
-                if (left) {
-                    const uint32_t R = 0x00010203u, D = 0x88888888u;
-                    qw0 = __builtin_amdgcn_perm(0u, qhi.w, R) | D; qw1 = __builtin_amdgcn_perm(0u, qhi.z, R) | D;
-                    qw2 = __builtin_amdgcn_perm(0u, qhi.y, R) | D; qw3 = __builtin_amdgcn_perm(0u, qhi.x, R) | D;
-                    qw4 = __builtin_amdgcn_perm(0u, qlo.w, R) | D; qw5 = __builtin_amdgcn_perm(0u, qlo.z, R) | D;
-                    qw6 = __builtin_amdgcn_perm(0u, qlo.y, R) | D; qw7 = __builtin_amdgcn_perm(0u, qlo.x, R) | D;
-                    tw0 = __builtin_bitreverse32(tw.w); tw1 = __builtin_bitreverse32(tw.z);
-                    tw2 = __builtin_bitreverse32(tw.y); tw3 = __builtin_bitreverse32(tw.x);
-                } else {
-                    qw0 = qlo.x; qw1 = qlo.y; qw2 = qlo.z; qw3 = qlo.w; qw4 = qhi.x; qw5 = qhi.y; qw6 = qhi.z; qw7 = qhi.w;
-                    tw0 = tw.x; tw1 = tw.y; tw2 = tw.z; tw3 = tw.w;
-                }
+            // signed positions: a long left walk near the block start may reach below 0 (pad bytes)
+            const int32_t qpos = left ? (int32_t)query_loc - (int32_t)walked : (int32_t)(query_loc + walked);
+            const int32_t qbyte = left ? (qpos >> 1) - 32 : (qpos >> 1);
+            const uint8_t* qp = a.query4 + (size_t)(qpos & 1) * a.query4_stride + qbyte;
+            const uint4 qlo = load16u(qp), qhi = load16u(qp + 16);
+            const int32_t tpos = left ? (int32_t)ref_loc - (int32_t)walked : (int32_t)(ref_loc + walked);
+            const int32_t tbyte = left ? (tpos >> 2) - 16 : (tpos >> 2);
+            const uint4 tw = load16u(a.ref2 + (size_t)(tpos & 3) * a.ref2_stride + tbyte);
+            uint32_t tw0, tw1, tw2, tw3, qw0, qw1, qw2, qw3, qw4, qw5, qw6, qw7;  // 4 x 16 bases in walking order
+            if (left) {
+                const uint32_t R = 0x00010203u, D = 0x88888888u;
+                qw0 = __builtin_amdgcn_perm(0u, qhi.w, R) | D; qw1 = __builtin_amdgcn_perm(0u, qhi.z, R) | D;
+                qw2 = __builtin_amdgcn_perm(0u, qhi.y, R) | D; qw3 = __builtin_amdgcn_perm(0u, qhi.x, R) | D;
+                qw4 = __builtin_amdgcn_perm(0u, qlo.w, R) | D; qw5 = __builtin_amdgcn_perm(0u, qlo.z, R) | D;
+                qw6 = __builtin_amdgcn_perm(0u, qlo.y, R) | D; qw7 = __builtin_amdgcn_perm(0u, qlo.x, R) | D;
+                tw0 = __builtin_bitreverse32(tw.w); tw1 = __builtin_bitreverse32(tw.z);
+                tw2 = __builtin_bitreverse32(tw.y); tw3 = __builtin_bitreverse32(tw.x);
+            } else {
+                qw0 = qlo.x; qw1 = qlo.y; qw2 = qlo.z; qw3 = qlo.w; qw4 = qhi.x; qw5 = qhi.y; qw6 = qhi.z; qw7 = qhi.w;
+                tw0 = tw.x; tw1 = tw.y; tw2 = tw.z; tw3 = tw.w;
             }
-            const uint32_t k3 = k & 3u;
-            const uint32_t td = k3 == 0u ? tw0 : k3 == 1u ? tw1 : k3 == 2u ? tw2 : tw3;
-            const uint32_t q0 = k3 == 0u ? qw0 : k3 == 1u ? qw2 : k3 == 2u ? qw4 : qw6;
-            const uint32_t q1 = k3 == 0u ? qw1 : k3 == 1u ? qw3 : k3 == 2u ? qw5 : qw7;
+            bool alive = true;
+            int m = 0;
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint32_t qd = j < 4 ? q0 : q1;
-                uint32_t qaddr;  // (query byte j) << 6 in one SDWA shift
-                switch (j & 3) {
-                    case 0: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(qaddr) : "v"(6), "v"(qd)); break;
-                    case 1: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(qaddr) : "v"(6), "v"(qd)); break;
-                    case 2: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(qaddr) : "v"(6), "v"(qd)); break;
-                    default: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(qaddr) : "v"(6), "v"(qd)); break;
+            for (int st = 0; st < 4; st++) {
+                if (alive) {
+                    const uint32_t td = st == 0 ? tw0 : st == 1 ? tw1 : st == 2 ? tw2 : tw3;
+                    const uint32_t q0 = st == 0 ? qw0 : st == 1 ? qw2 : st == 2 ? qw4 : qw6;
+                    const uint32_t q1 = st == 0 ? qw1 : st == 1 ? qw3 : st == 2 ? qw5 : qw7;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const uint32_t qd = j < 4 ? q0 : q1;
+                        uint32_t qaddr;  // (query byte j) << 6 in one SDWA shift
+                        switch (j & 3) {
+                            case 0: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(qaddr) : "v"(6), "v"(qd)); break;
+                            case 1: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(qaddr) : "v"(6), "v"(qd)); break;
+                            case 2: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(qaddr) : "v"(6), "v"(qd)); break;
+                            default: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(qaddr) : "v"(6), "v"(qd)); break;
+                        }
+                        const uint32_t rp = (td >> (4 * j)) & 15u;
+                        const uint32_t addr = (rp << 2) | qaddr;  // byte address of entry rp | qbyte << 4
+                        const s16x2 e = __builtin_bit_cast(s16x2, *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_pk) + addr));
+                        const s16x2 Tb = T.yy;
+                        T = __builtin_elementwise_add_sat(Tb, e);  // {t + s0, t + s0 + s1}
+                        M = __builtin_elementwise_max(M, T);
+                    }
+                    m = max((int)M.x, (int)M.y);
+                    alive = (m - (int)T.y) <= xdrop;  // :374 / :523, looked at once per 16 bases
                 }
-                const uint32_t rp = (td >> (4 * j)) & 15u;          // v_bfe_u32
-                const uint32_t addr = (rp << 2) | qaddr;            // byte address of entry rp | qbyte << 4
-                const s16x2 e = __builtin_bit_cast(s16x2, *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_pk) + addr));
-                const s16x2 Tb = T.yy;
-                T = __builtin_elementwise_add_sat(Tb, e);  // {t + s0, t + s0 + s1}
-                M = __builtin_elementwise_max(M, T);
             }
-            const int m = max((int)M.x, (int)M.y), t = (int)T.y;
-            const bool dropped = (m - t) > xdrop;
-            walked += 16;
-            if (dropped) {
+            walked += 64;
+            if (!alive) {
                 if (!left) {  // -> left side (:457-476): anchor-1, anchor-2, ...
                     bestR = m;
                     phase = PH_LEFT;
@@ -1448,14 +1245,7 @@ void launch_extend_filter(const ExtendArgs& a, hipStream_t s) {
             attr_set = true;
         }
         const uint32_t pblocks = (uint32_t)((waves + PAIR_THREADS / 64 - 1) / (PAIR_THREADS / 64));
-        const bool pre = getenv("SEGALIGN_AMD_PAIR_PRELOAD") != nullptr;  // EXPERIMENT
-        if (pre) {
-            static bool attr2 = false;
-            if (!attr2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(extend_filter_pair_pre_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr2 = true; }
-            hipLaunchKernelGGL(extend_filter_pair_pre_kernel, dim3(pblocks), dim3(PAIR_THREADS), lds, s, a);
-        } else {
-            hipLaunchKernelGGL(extend_filter_pair_kernel, dim3(pblocks), dim3(PAIR_THREADS), lds, s, a);
-        }
+        hipLaunchKernelGGL(extend_filter_pair_kernel, dim3(pblocks), dim3(PAIR_THREADS), lds, s, a);
         return;
     }
     if (a.examined) hipLaunchKernelGGL((extend_filter_kernel<true, false>), dim3(blocks), dim3(EXT_THREADS), 0, s, a);

@@ -257,6 +257,7 @@ static int g_packed_waves = 4096; // SEGALIGN_AMD_PACKED_WAVES: waves of the pac
 static int g_max_waves = 4096;    // SEGALIGN_AMD_MAX_WAVES: waves of the filter kernel (4 per SIMD saturate instruction issue)
 static int g_fast_filter = 0;     // derived in InitializeProcessor: xdrop >= 0 && 7*max(M) <= xdrop
 static int g_packed_filter = 0;   // derived in InitializeProcessor: the packed upper-bound filter may be used
+static int g_no_small_dedup = 0;  // SEGALIGN_AMD_NO_SMALL_DEDUP=1: always use the library sorts
 static int g_chain = 1;           // chain shortcut of the exact stage (SEGALIGN_AMD_NO_CHAIN=1 turns it off)
 constexpr uint32_t CHAIN_CAP = 1u << 20;  // candidates per batch the chain buffers hold; larger batches fall back
 static SeedShape g_shape = {0, 0, 0, {0}};
@@ -564,12 +565,32 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
             t_stats.num_entropy = n_ent_total;
 
             // ---- order + de-duplicate (:776-782 ; rm :819-831) ----
+            auto ensure_host_out = [&](size_t n) {
+                if (sl->h_out_cap >= n) return;
+                if (sl->h_out) hipHostFree(sl->h_out);
+                sl->h_out_cap = std::max<size_t>(n, 1u << 16);
+                if (hipHostMalloc((void**)&sl->h_out, sl->h_out_cap * sizeof(sa_segment_pair)) != hipSuccess) {
+                    fprintf(stderr, "Error: hipHostMalloc for hsp_output failed\n");
+                    exit(12);
+                }
+            };
             if (survivors > 0) {
                 sl->recB.ensure(std::max<size_t>(survivors, sl->recA.cap), "survivors B");
                 size_t tb = sort_temp_bytes(survivors);
                 sl->sort_temp.ensure(tb, "sort temp");
                 HspRec* fin = nullptr;
-                if (!ca.rm) {
+                const bool small = !ca.rm && survivors <= dedup_small_max() && !g_no_small_dedup;
+                if (small) {  // the whole chain in one workgroup, one D2H of count + records
+                    sl->out16.ensure(survivors, "out16");
+                    ensure_host_out(survivors);
+                    { ProfScope p(sl, "dedup_small"); launch_dedup_small(sl->recA.p, survivors, sl->out16.p, &sl->d_cnt->uniq, st); }
+                    check_launch("dedup small");
+                    check_memcpy(hipMemcpyAsync(sl->h_cnt, sl->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st), "counters");
+                    check_memcpy(hipMemcpyAsync(sl->h_out, sl->out16.p, (size_t)survivors * sizeof(sa_segment_pair),
+                                                hipMemcpyDeviceToHost, st), "hsp_output");  // :788
+                    check_sync(st, "hsp_output");
+                    n_final = sl->h_cnt->uniq;
+                } else if (!ca.rm) {
                     { ProfScope p(sl, "sort_diag");  launch_sort(sl->recA.p, sl->recB.p, survivors, ORDER_DIAG, sl->sort_temp.p, sl->sort_temp.cap, st); }
                     { ProfScope p(sl, "unique");     launch_unique(sl->recB.p, sl->recA.p, survivors, 0, &sl->d_cnt->uniq, st); }
                     check_launch("sort/unique");
@@ -602,14 +623,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                 }
                 if (n_final > 0 && fin) {
                     sl->out16.ensure(n_final, "out16");
-                    if (sl->h_out_cap < n_final) {
-                        if (sl->h_out) hipHostFree(sl->h_out);
-                        sl->h_out_cap = std::max<size_t>(n_final, 1u << 16);
-                        if (hipHostMalloc((void**)&sl->h_out, sl->h_out_cap * sizeof(sa_segment_pair)) != hipSuccess) {
-                            fprintf(stderr, "Error: hipHostMalloc for hsp_output failed\n");
-                            exit(12);
-                        }
-                    }
+                    ensure_host_out(n_final);
                     { ProfScope p(sl, "strip"); launch_strip(fin, n_final, sl->out16.p, st); }
                     check_launch("final sort/strip");
                     check_memcpy(hipMemcpyAsync(sl->h_out, sl->out16.p, (size_t)n_final * sizeof(sa_segment_pair),
@@ -801,6 +815,7 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
                            !getenv("SEGALIGN_AMD_NO_PACKED_FILTER")) ? 1 : 0;
         if (getenv("SEGALIGN_AMD_NO_FAST_FILTER")) { g_fast_filter = 0; g_packed_filter = 0; }
         g_chain = getenv("SEGALIGN_AMD_NO_CHAIN") ? 0 : 1;
+        g_no_small_dedup = getenv("SEGALIGN_AMD_NO_SMALL_DEDUP") ? 1 : 0;
     }
     std::lock_guard<std::mutex> lk(g_mu);
     g_tokens.clear();

@@ -211,7 +211,7 @@ def main():
         achieved = gbs(per_kernel[name], [name]) if name in per_kernel else None
         ext_gbs = gbs(ext_bytes, ["extend_filter", "extend_exact", "extend_entropy"])
         look_gbs = gbs(look_bytes, ["seed_lookup", "expand_hits"])
-        traffic, traffic_src = measured_traffic(name)
+        traffic, traffic_src = measured_traffic(name, E.filter_mode())
         single = None
         if name == "extend_filter" and name in solo and solo[name][1]:
             sH = sum(x["num_hits"] for x in solo_stats)
@@ -229,6 +229,12 @@ def main():
             # bytes it really moves (every 16-byte random window costs a 128-byte line, which `achieved` does not count)
             "traffic_gbs_single_stream": (round(traffic / (single["avg_launch_us"] * 1e-6) / 1e9, 1)
                                           if (traffic and single) else None),
+            # the same traffic counted in 128-byte lines against the measured random-gather ceiling of the chip
+            # (tools/micro/gather_bw.hip: 57 G lines/s for a 100 MB working set) -- the bound that actually applies
+            "random_line_roofline": ({"lines_per_launch": int(traffic // 128), "peak_lines_per_s": RANDOM_LINES_PER_S,
+                                      "frac_single_stream": round(traffic / 128 / (single["avg_launch_us"] * 1e-6) / RANDOM_LINES_PER_S, 4)}
+                                     if (traffic and single) else None),
+            "kernel_symbol": FILTER_KERNELS.get(E.filter_mode()) if name == "extend_filter" else None,
             "calls_in_flight": max(1, args.host_threads), "single_stream": single,
             "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
             "algorithmic_bytes_per_launch": round(per_kernel.get(name, 0) / max(launches, 1)),
@@ -270,12 +276,17 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_traffic(prof_name):
+RANDOM_LINES_PER_S = 57e9  # measured on MI355X: random 128-byte line gathers per second (tools/micro/gather_bw.hip)
+FILTER_KERNELS = {0: "extend_filter_kernel", 1: "extend_filter_kernel", 2: "extend_filter_pair_kernel",
+                  3: "extend_filter_packed_kernel"}  # sa_get_filter_mode() -> kernel behind the "extend_filter" scope
+
+
+def measured_traffic(prof_name, filter_mode=3):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
     separate runs, gfx950 correction: see tools/traffic_json.py).  bench.py cannot profile itself, so it quotes the
     newest profiles/rNN/traffic.json collected with tools/profile_bench.sh on this same default workload; null if absent."""
     import glob
-    kernel = {"extend_filter": "extend_filter_kernel", "extend_exact": "extend_exact_kernel",
+    kernel = {"extend_filter": FILTER_KERNELS.get(filter_mode), "extend_exact": "extend_exact_kernel",
               "expand_hits": "expand_hits_kernel", "seed_lookup": "seed_lookup_kernel"}.get(prof_name)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
     if not kernel or not files:

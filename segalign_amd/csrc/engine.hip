@@ -1284,6 +1284,10 @@ int sa_max_hits_for_mem(uint64_t total_global_mem) { return max_hits_for_mem(tot
 // ---- introspection --------------------------------------------------------------------------------------------------
 void sa_get_last_call_stats(sa_call_stats* o) { *o = t_stats; }
 void sa_set_count_examined(int on) { g_count_examined = on != 0; }
+int sa_get_filter_mode(void) {  // which X-drop filter kernel the next plain (non repeat-masker) call uses
+    if (g_count_examined) return g_fast_filter ? 1 : 0;
+    return g_packed_filter ? 3 : g_fast_filter;
+}
 void sa_profile_enable(int on) { g_prof_on = on != 0; }
 void sa_profile_reset(void) {
     std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -34,7 +34,7 @@ C_ABI_SYMBOLS = [
     "sa_profile_enable", "sa_profile_reset", "sa_profile_num_entries", "sa_profile_get", "sa_get_ref_len",
     "sa_get_num_index", "sa_get_index_table_size", "sa_copy_ref_codes", "sa_copy_index_table", "sa_copy_pos_table",
     "sa_copy_query_codes", "sa_get_query_len", "sa_device_make_seeds", "sa_version",
-    "sa_rm_mask_interval", "sa_rm_coverage_intervals", "sa_free_intervals",
+    "sa_rm_mask_interval", "sa_rm_coverage_intervals", "sa_free_intervals", "sa_get_filter_mode",
 ]
 IVL_DTYPE = np.dtype([("query_start", "<u4"), ("len", "<u4")])  # struct Segment, repeat_masker_src/graph.h:32-35
 STRAND_PLUS, STRAND_MINUS, STRAND_BOTH = 1, 2, 3
@@ -249,6 +249,10 @@ def last_call_stats():
     st = CallStats()
     lib().sa_get_last_call_stats(C.byref(st))
     return {k: getattr(st, k) for k, _ in CallStats._fields_}
+
+
+def filter_mode():
+    return int(lib().sa_get_filter_mode())
 
 
 def set_count_examined(on):

@@ -243,7 +243,11 @@ def main():
             "extension_total": {"achieved": round(ext_gbs, 1) if ext_gbs else None,
                                 "frac": round(ext_gbs / HBM_PEAK_GBS, 4) if ext_gbs else None, "bytes": "8*H + 2*E + 20*A"},
             "lookup_expand": {"achieved": round(look_gbs, 1) if look_gbs else None,
-                              "frac": round(look_gbs / HBM_PEAK_GBS, 4) if look_gbs else None, "bytes": "16*S + 12*H"},
+                              "frac": round(look_gbs / HBM_PEAK_GBS, 4) if look_gbs else None, "bytes": "16*S + 12*H",
+                              # the same two kernels by the HBM traffic rocprofv3 measured (profiles/), over their
+                              # single-stream launch time: every 8-byte bucket gather moves a 128-byte line, so the
+                              # kernels sit near the roofline in bytes MOVED while `achieved` counts bytes NEEDED
+                              "measured_traffic": measured_pair(solo)},
             "kernels": kernels,
         }
 
@@ -296,6 +300,18 @@ def measured_traffic(prof_name, filter_mode=3):
         return t[kernel]["hbm_bytes"], os.path.relpath(files[-1], ROOT)
     except Exception:
         return None, None
+
+
+def measured_pair(solo):
+    out = {}
+    for name in ("seed_lookup", "expand_hits"):
+        t, _ = measured_traffic(name)
+        if t and name in solo and solo[name][1]:
+            us = 1e3 * solo[name][0] / solo[name][1]
+            out[name] = {"hbm_bytes_per_launch": int(t), "single_stream_us": round(us, 2),
+                         "gbs": round(t / (us * 1e-6) / 1e9, 1), "frac": round(t / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                         "line_frac": round(t / 128 / (us * 1e-6) / RANDOM_LINES_PER_S, 4)}
+    return out or None
 
 
 def dry_run(args, rank, world, dist, torch, shard):

@@ -674,6 +674,7 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
     bool has_hit = false, forward = false;
     uint32_t ref_loc = 0, query_loc = 0, hidx = 0;
     uint32_t walked = 0;  // bases walked on this side (multiple of 64)
+    uint4 h_tw = {0u, 0u, 0u, 0u}, h_qlo = {0u, 0u, 0u, 0u}, h_qhi = {0u, 0u, 0u, 0u};  // first LEFT window, fetched with the hit
     s16x2 T = {0, 0}, M = {0, 0};
     int bestR = 0, best = 0;
 
@@ -683,14 +684,29 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
         // selection of the held dwords) and a lane that drops simply sits out the remaining steps.
         if (phase < PH_FIN) {
             const bool left = phase == PH_LEFT;
-            // signed positions: a long left walk near the block start may reach below 0 (pad bytes)
-            const int32_t qpos = left ? (int32_t)query_loc - (int32_t)walked : (int32_t)(query_loc + walked);
-            const int32_t qbyte = left ? (qpos >> 1) - 32 : (qpos >> 1);
-            const uint8_t* qp = a.query4 + (size_t)(qpos & 1) * a.query4_stride + qbyte;
-            const uint4 qlo = load16u(qp), qhi = load16u(qp + 16);
-            const int32_t tpos = left ? (int32_t)ref_loc - (int32_t)walked : (int32_t)(ref_loc + walked);
-            const int32_t tbyte = left ? (tpos >> 2) - 16 : (tpos >> 2);
-            const uint4 tw = load16u(a.ref2 + (size_t)(tpos & 3) * a.ref2_stride + tbyte);
+            // A new hit (right side, nothing walked) also fetches the first window of its LEFT side: both lie in the
+            // same 32 bytes of the 2-bit copy, usually one line, which would otherwise be fetched again after the L2
+            // has turned over (a few microseconds at this miss rate): 1.41 -> 1.30 lines per hit, one wait fewer.
+            uint4 qlo, qhi, tw;
+            if (left && walked == 0u) {
+                qlo = h_qlo; qhi = h_qhi; tw = h_tw;
+            } else {
+                // signed positions: a long left walk near the block start may reach below 0 (pad bytes)
+                const int32_t qpos = left ? (int32_t)query_loc - (int32_t)walked : (int32_t)(query_loc + walked);
+                const int32_t qbyte = left ? (qpos >> 1) - 32 : (qpos >> 1);
+                const uint8_t* qp = a.query4 + (size_t)(qpos & 1) * a.query4_stride + qbyte;
+                qlo = load16u(qp);
+                qhi = load16u(qp + 16);
+                const int32_t tpos = left ? (int32_t)ref_loc - (int32_t)walked : (int32_t)(ref_loc + walked);
+                const int32_t tbyte = left ? (tpos >> 2) - 16 : (tpos >> 2);
+                const uint8_t* tp = a.ref2 + (size_t)(tpos & 3) * a.ref2_stride + tbyte;
+                tw = load16u(tp);
+                if (!left && walked == 0u) {  // same phase copies (qpos, tpos are the anchor itself)
+                    h_tw = load16u(tp - 16);
+                    h_qlo = load16u(qp - 32);
+                    h_qhi = load16u(qp - 16);
+                }
+            }
             uint32_t tw0, tw1, tw2, tw3, qw0, qw1, qw2, qw3, qw4, qw5, qw6, qw7;  // 4 x 16 bases in walking order
             if (left) {
                 const uint32_t R = 0x00010203u, D = 0x88888888u;

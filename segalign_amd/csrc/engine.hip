@@ -257,9 +257,10 @@ static int g_packed_waves = 4096; // SEGALIGN_AMD_PACKED_WAVES: waves of the pac
 static int g_max_waves = 4096;    // SEGALIGN_AMD_MAX_WAVES: waves of the filter kernel (4 per SIMD saturate instruction issue)
 static int g_fast_filter = 0;     // derived in InitializeProcessor: xdrop >= 0 && 7*max(M) <= xdrop
 static int g_packed_filter = 0;   // derived in InitializeProcessor: the packed upper-bound filter may be used
+static int g_chain_sort_threads = 512;  // SEGALIGN_AMD_CHAIN_SORT_THREADS
 static int g_no_small_dedup = 0;  // SEGALIGN_AMD_NO_SMALL_DEDUP=1: always use the library sorts
 static int g_chain = 1;           // chain shortcut of the exact stage (SEGALIGN_AMD_NO_CHAIN=1 turns it off)
-constexpr uint32_t CHAIN_CAP = 1u << 20;  // candidates per batch the chain buffers hold; larger batches fall back
+static uint32_t CHAIN_CAP = 1u << 20;  // candidates per batch the chain buffers hold (SEGALIGN_AMD_CHAIN_CAP); larger batches fall back
 static SeedShape g_shape = {0, 0, 0, {0}};
 static uint32_t g_query_len[SA_BUFFER_DEPTH] = {0, 0};
 
@@ -503,6 +504,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                 // skip, needs the 29-bit position field of its sort key, and is off while E is being counted
                 const bool chain = g_chain && !ca.rm && g_xdrop >= 0 && ca.query_len < (1u << 29) && !g_count_examined;
                 ea.chain_cap = chain ? CHAIN_CAP : 0u;
+                ea.chain_sort_threads = (uint32_t)g_chain_sort_threads;
                 if (chain) {
                     sl->chain_tmp.ensure(CHAIN_CAP, "chain candidates");
                     sl->chain_sorted.ensure(CHAIN_CAP, "chain candidates");
@@ -537,12 +539,23 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                         { ProfScope p(sl, "chain_group"); launch_chain_group(ea, st); }
                         { ProfScope p(sl, "chain_link");  launch_chain_link(ea, st); }
                     }
-                    { ProfScope p(sl, "extend_exact");   launch_extend_exact(ea, st); }
                     if (ea.chain_cap) { ProfScope p(sl, "extend_exact_chain"); launch_extend_exact_chain(ea, st); }
+                    else              { ProfScope p(sl, "extend_exact");       launch_extend_exact(ea, st); }
                     { ProfScope p(sl, "extend_entropy"); launch_extend_entropy(ea, st); }
                     check_launch("expand/extend");
                     check_memcpy(hipMemcpyAsync(sl->h_cnt, sl->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st), "counters");
                     check_sync(st, "extend");
+                    if (ea.chain_cap && sl->h_cnt->n_long > ea.chain_cap && sl->h_cnt->n_long <= ea.cand_cap_recs) {
+                        // more candidates than the chain buffers hold: the chain kernels left the batch alone (device-side
+                        // test on the same counter); extend every candidate on its own
+                        ExtendArgs eb = ea;
+                        eb.chain_cap = 0;
+                        { ProfScope p(sl, "extend_exact");   launch_extend_exact(eb, st); }
+                        { ProfScope p(sl, "extend_entropy"); launch_extend_entropy(eb, st); }
+                        check_launch("extend (no chain)");
+                        check_memcpy(hipMemcpyAsync(sl->h_cnt, sl->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st), "counters");
+                        check_sync(st, "extend (no chain)");
+                    }
                     const Counters& c = *sl->h_cnt;
                     if (c.survivors <= ea.out_cap && c.n_long <= ea.cand_cap_recs && c.n_ent <= ea.ent_cap_recs) break;
                     // an overflowing long list also truncates what the later kernels saw: size everything from the
@@ -815,6 +828,10 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
                            !getenv("SEGALIGN_AMD_NO_PACKED_FILTER")) ? 1 : 0;
         if (getenv("SEGALIGN_AMD_NO_FAST_FILTER")) { g_fast_filter = 0; g_packed_filter = 0; }
         g_chain = getenv("SEGALIGN_AMD_NO_CHAIN") ? 0 : 1;
+        g_chain_sort_threads = 512;
+        if (const char* e = getenv("SEGALIGN_AMD_CHAIN_SORT_THREADS")) g_chain_sort_threads = std::max(64, std::min(512, atoi(e) & ~63));
+        if (const char* e = getenv("SEGALIGN_AMD_CHAIN_CAP")) CHAIN_CAP = (uint32_t)std::max(1, atoi(e));
+        else CHAIN_CAP = 1u << 20;
         g_no_small_dedup = getenv("SEGALIGN_AMD_NO_SMALL_DEDUP") ? 1 : 0;
     }
     std::lock_guard<std::mutex> lk(g_mu);

@@ -1274,7 +1274,7 @@ void launch_chain_group(const ExtendArgs& a, hipStream_t s) {  // chain_bucket_c
     hipLaunchKernelGGL(chain_count_kernel, dim3(256), dim3(256), 0, s, a);
     hipLaunchKernelGGL(chain_scan_kernel, dim3(1), dim3(256), 0, s, a);
     hipLaunchKernelGGL(chain_scatter_kernel, dim3(256), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(chain_bucket_sort_kernel, dim3(CHAIN_BUCKETS), dim3(512), 0, s, a);
+    hipLaunchKernelGGL(chain_bucket_sort_kernel, dim3(CHAIN_BUCKETS), dim3(a.chain_sort_threads ? a.chain_sort_threads : 512), 0, s, a);
 }
 uint32_t chain_num_buckets() { return CHAIN_BUCKETS; }
 void launch_chain_link(const ExtendArgs& a, hipStream_t s) {

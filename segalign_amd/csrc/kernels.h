@@ -64,6 +64,7 @@ struct ExtendArgs {
     int fin_batch;            // finished lanes a wave accumulates before it finalises + refills them
     int bufs_per_wave;        // launch heuristic: 64-hit buffers each wave should own at least
     uint32_t long_cap;        // bases per side the filter walks before it forwards the hit to the exact kernel
+    uint32_t chain_sort_threads;  // workgroup size of the chain bucket sort (0: 512)
     int fast_filter;          // 1: xdrop >= 0 && 7*max(M) <= xdrop: the filter may skip the sticky select (extend.hip)
                               // 2: additionally eligible for the pair-table upper-bound filter (extend.hip 1b)
     CandRec* cand_list;

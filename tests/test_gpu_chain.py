@@ -88,3 +88,16 @@ def test_chain_with_iteration_split(oracle, engine):
     finally:
         engine.ShutdownProcessor()
         engine.set_max_hits(0)
+
+
+def test_candidate_list_larger_than_the_chain_buffers(oracle, engine):
+    """more candidates than SEGALIGN_AMD_CHAIN_CAP: the chain kernels leave the batch alone and every candidate is
+    extended on its own by a second launch (engine.hip), same output"""
+    t = synth.random_dna(50000, 31)
+    q = synth.mutate(t, 32, 0.03)
+    os.environ["SEGALIGN_AMD_CHAIN_CAP"] = "500"
+    try:
+        outs, surv = run(engine, oracle, t, q, True)
+    finally:
+        os.environ.pop("SEGALIGN_AMD_CHAIN_CAP", None)
+    assert surv > 500  # without the shortcut every candidate survives on its own

@@ -223,6 +223,7 @@ struct DevCtx {
     const char* ref_host_ptr = nullptr;  // identity of the block last sent (to skip a second upload for the table)
     PackedBuf ref2;                      // 2-bit phase copies of the target (packed filter)
     PackedBuf query4[SA_BUFFER_DEPTH], query4_rc[SA_BUFFER_DEPTH];  // 4-bit phase copies of the query strands
+    PackedBuf ref4, ref4_rc;             // repeat masker: the query IS the target
     SeqBuf ref_rc;                       // repeat masker
     uint32_t* bucket_start = nullptr;    // 4^k + 1
     uint32_t* pos_table = nullptr;
@@ -861,6 +862,8 @@ void sa_shutdown_processor(void) {  // src/seed_filter.cu:932-940
         dc->ref8.release("d_ref_seq rows");
         dc->ref2.release("d_ref_seq 2-bit");
         dc->ref_rc.release("d_seq_rc");
+        dc->ref4.release("d_seq 4-bit");
+        dc->ref4_rc.release("d_seq_rc 4-bit");
         dev_free(dc->bucket_start, "d_index_table");
         dev_free(dc->pos_table, "d_pos_table");
         dc->bucket_start = dc->pos_table = nullptr;
@@ -1103,6 +1106,8 @@ void sa_rm_send_query_write_request(void) {  // rm :951-961
         check_set_device(dc->dev, "SendQueryWriteRequest");
         dc->ref_rc.create(dc->ref.len, "seq_rc", dc->admin);
         launch_rev_comp_codes(dc->ref.codes, dc->ref_rc.codes, dc->ref.len, dc->admin);
+        dc->ref4.create(dc->ref.codes, dc->ref.len, 4, "seq 4-bit", dc->admin);
+        dc->ref4_rc.create(dc->ref_rc.codes, dc->ref.len, 4, "seq_rc 4-bit", dc->admin);
         check_launch("rev_comp_string");
         check_sync(dc->admin, "SendQueryWriteRequest");
     }
@@ -1111,6 +1116,8 @@ void sa_rm_clear_query(void) {  // rm :964-972
     for (auto* dc : g_dev) {
         check_set_device(dc->dev, "ClearQuery");
         dc->ref_rc.release("d_seq_rc");
+        dc->ref4.release("d_seq 4-bit");
+        dc->ref4_rc.release("d_seq_rc 4-bit");
     }
 }
 size_t sa_rm_seed_and_filter(const uint64_t* seeds, size_t num_seeds, int rev, uint32_t ref_start, uint32_t ref_end,
@@ -1126,7 +1133,8 @@ size_t sa_rm_seed_and_filter(const uint64_t* seeds, size_t num_seeds, int rev, u
     DevCtx* dc = g_dev[0];
     for (auto* d : g_dev) if (d->dev == sl->dev) dc = d;
     upload_seeds(sl, seeds, num_seeds);
-    CoreArgs ca = {rev ? dc->ref_rc.codes : dc->ref.codes, dc->ref.len, 1, rev ? 1 : 0, ref_start, ref_end, 0, 0, nullptr, 0, nullptr};  // rm :805-810
+    CoreArgs ca = {rev ? dc->ref_rc.codes : dc->ref.codes, dc->ref.len, 1, rev ? 1 : 0, ref_start, ref_end, 0, 0, nullptr, 0,
+                   rev ? &dc->ref4_rc : &dc->ref4};  // rm :805-810
     size_t n = saf_core(dc, sl, (uint32_t)num_seeds, ca, out);
     release_slot(sl);
     return n;
@@ -1248,7 +1256,7 @@ size_t sa_rm_mask_interval(uint32_t start_pos, uint32_t end_pos, uint32_t ref_st
             const uint8_t* q = rev ? dc->ref_rc.codes : dc->ref.codes;
             const uint32_t ns = device_seeds(sl, q, s0, s1);
             if (ns == 0) continue;  // :103,140
-            CoreArgs ca = {q, block_len, 1, rev, ref_start, ref_end, s0, s1, sl->cov_diff.p, block_len + 1, nullptr};
+            CoreArgs ca = {q, block_len, 1, rev, ref_start, ref_end, s0, s1, sl->cov_diff.p, block_len + 1, rev ? &dc->ref4_rc : &dc->ref4};
             saf_core(dc, sl, ns, ca, nullptr);
             tot_seeds += ns;
             tot_hits += t_stats.num_hits;

@@ -818,8 +818,10 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
                     hidx = mine_idx;
                     bestR = 0;
                     best = 0;
+                    bool skip = false;
+                    if (a.rm) skip = !(ref_loc >= a.rm_win_start && ref_loc <= a.rm_win_end);  // rm :239-244,:305-333
                     // anchors beyond the block (hand-made seed words only) are never extended, see extend_filter_kernel
-                    if (ref_loc > a.ref_len || query_loc > a.query_len) {
+                    if (skip || ref_loc > a.ref_len || query_loc > a.query_len) {
                         phase = PH_FIN;
                     } else {
                         phase = PH_RIGHT;  // :299-324

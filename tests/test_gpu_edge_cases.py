@@ -19,8 +19,12 @@ def run_all_chunks(c, rev_list=(False, True), max_hits=None, check_range=True):
             if seeds.size == 0:
                 continue
             want, st = c.oracle_saf(seeds, rev, **({"max_hits": max_hits} if max_hits else {}))
-            got = c.E.SeedAndFilter(seeds, rev, 0)
-            assert seg_equal(got, want), (rev, s, e, got[:3], want[:3])
+            # the reference asserts num_seeds <= MAX_SEEDS = 13 * chunk (seed_filter.cu:688-692,836-839), which a
+            # 14of22 seed with transitions (15 words per position) exceeds on a chunk without masked positions; the
+            # drop-in entry keeps that behaviour, the device seeder has no such limit
+            if seeds.size <= (13 if c.transition else 1) * c.chunk:
+                got = c.E.SeedAndFilter(seeds, rev, 0)
+                assert seg_equal(got, want), (rev, s, e, got[:3], want[:3])
             if check_range:
                 assert seg_equal(c.E.SeedAndFilterRange(s, e, rev, 0), want)
             n += want.size - 1
@@ -83,11 +87,10 @@ def test_max_hits_iteration_split(oracle, engine_clean, max_hits):
     (SHAPE_12OF19, 2, True), (SHAPE_12OF19, 3, False), (SHAPE_12OF19, 4, True),
     ("T0T0TT00T0TTT", 1, True),              # custom pattern, weight 8 (main.cpp:168-178)
     ("TTTTT11TTTT", 1, True),                # '1' care positions are not transition-enabled (ntcoding.cpp:21-37)
-    ("TTT0T0TT00TT00T0T0TTTT", 1, False),    # 14of22 span with transitions off
+    ("TTT0T0TT00TT00T0T0TTTT", 1, False),    # 14of22 (main.cpp:164-167): 4^14 buckets, transitions off
+    ("TTT0T0TT00TT00T0T0TTTT", 1, True),     # 14of22 as the reference runs it: 15 seed words per position
 ])
 def test_shapes_steps_and_transitions(oracle, engine_clean, shape, step, transition):
-    if shape.count("T") + shape.count("1") > 12:
-        pytest.skip("4^14-entry oracle table is too large for a quick test")
     t, q = synth.make_pair(90000, 7, 8, sub_rate=0.08, mask_frac=0.1, records=3, n_runs=2)
     c = Case(t, q, shape=shape, step=step, transition=transition, chunk=45000).oracle_setup(oracle).engine_setup(engine_clean)
     assert np.array_equal(c.E.copy_index_table(), c.o_index)

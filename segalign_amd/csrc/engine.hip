@@ -825,7 +825,9 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
                 if (g_sub_mat[7 * 8 + i] > -need || g_sub_mat[i * 8 + 7] > -need) ok = false;
             if (ok && !getenv("SEGALIGN_AMD_NO_PAIR_FILTER")) g_fast_filter = 2;
         }
-        g_packed_filter = (xdrop >= 0 && (int64_t)std::max(mx, 0) * ((int64_t)g_long_cap + 16) <= 32767 &&
+        // int16 score arithmetic: the best of a side (<= max(M) * long_cap rounded up to whole 64-base windows) and xdrop itself must stay well inside
+        // the saturation range, or a walk could never satisfy the drop test and every hit would become a candidate
+        g_packed_filter = (xdrop >= 0 && xdrop <= 16383 && (int64_t)std::max(mx, 0) * (((int64_t)g_long_cap + 63) / 64 * 64) <= 16383 &&
                            !getenv("SEGALIGN_AMD_NO_PACKED_FILTER")) ? 1 : 0;
         if (getenv("SEGALIGN_AMD_NO_FAST_FILTER")) { g_fast_filter = 0; g_packed_filter = 0; }
         g_chain = getenv("SEGALIGN_AMD_NO_CHAIN") ? 0 : 1;

@@ -612,6 +612,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void extend_filter_pair_kernel(Extend
 //   * the drop test is evaluated once per 16 bases; adds saturate; entries below -16383 are raised to -16383;
 //   * beyond a block edge the walk reads pad codes: arbitrary scores, but the reference has already stopped there, and a
 //     best over a longer walk is >= the best over its prefix.
+// Eligibility (engine.hip): 0 <= xdrop <= 16383 and max(M) * long_cap <= 16383 (int16 scores with room for the drop test).
 // Phase copies (encode.hip) make every window byte aligned: copy k = position & 3 (target) / & 1 (query).
 // Left walks: the 128-bit target window is bit-reversed (v_bfrev_b32 + dword order), which also swaps the two bits of
 // every code; the query bytes are byte-reversed and get bit 3 of both nibbles set; table entries with those bits set

@@ -281,8 +281,7 @@ def main():
 
 
 RANDOM_LINES_PER_S = 57e9  # measured on MI355X: random 128-byte line gathers per second (tools/micro/gather_bw.hip)
-FILTER_KERNELS = {0: "extend_filter_kernel", 1: "extend_filter_kernel", 2: "extend_filter_pair_kernel",
-                  3: "extend_filter_packed_kernel"}  # sa_get_filter_mode() -> kernel behind the "extend_filter" scope
+FILTER_KERNELS = {0: "extend_filter_kernel", 1: "extend_filter_kernel", 3: "extend_filter_packed_kernel"}  # sa_get_filter_mode() -> kernel behind the "extend_filter" scope
 
 
 def measured_traffic(prof_name, filter_mode=3):

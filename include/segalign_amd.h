@@ -165,7 +165,7 @@ typedef struct sa_call_stats {
 void sa_get_last_call_stats(sa_call_stats* out); /* stats of the calling thread's most recent hot call */
 void sa_set_count_examined(int on);
 /* X-drop filter kernel selected by InitializeProcessor for plain calls: 0 = exact per-base walk, 1 = fast per-base
- * (7*max(M) <= xdrop), 2 = pair table on byte codes, 3 = packed 2-bit/4-bit upper-bound filter. */
+ * (7*max(M) <= xdrop), 3 = packed 2-bit/4-bit upper-bound filter. */
 int sa_get_filter_mode(void);
 
 /* Per-kernel HIP-event timing on the engine's own streams (bench.py's roofline leg). */

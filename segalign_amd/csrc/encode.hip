@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void row_code_kernel(const uint8_t* __restrict
         for (uint32_t i = nvec * 16 + threadIdx.x; i < len; i += blockDim.x) out[i] = (uint8_t)(codes[i] << 3);
 }
 
-// ---- packed copies for the packed X-drop filter (extend.hip 1c) ---------------------------------------------------
+// ---- packed copies for the packed X-drop filter (extend.hip 1b) ---------------------------------------------------
 // 2 bits per base, codes >= 4 stored as 0; PHASE copy k holds bases [4j+k, 4j+k+4) in byte j, so that a window that
 // starts (or ends) at ANY base position is byte aligned in the copy k = position & 3.
 __global__ __launch_bounds__(256) void pack2_phase_kernel(const uint8_t* __restrict__ codes, uint32_t len,

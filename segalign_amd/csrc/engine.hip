@@ -96,8 +96,8 @@ struct SeqBuf {  // encoded sequence with SEQ_PAD guard bytes on both sides
         alloc = (uint8_t*)dev_malloc(bytes, tag);
         // guard bytes carry bit 6: OR-ed into a matrix index they select a terminator entry of the extension kernels'
         // 128-entry table, so a window that runs over a block edge stops the walk without any bounds arithmetic.
-        // Below the guard bit they hold the code 7 ('E', the record separator) in the buffer's own coding -- the
-        // pair-table filter masks the guard bit off and lets the matrix's E row / column end the walk
+        // Below the guard bit they hold the code 7 ('E', the record separator) in the buffer's own coding, so a reader
+        // that ignores the guard bit still sees a separator there
         check_memcpy(hipMemsetAsync(alloc, row_coded ? 0x78 : 0x47, bytes, s), tag);
         codes = alloc + SEQ_PAD;
         len = n;
@@ -490,7 +490,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                 ea.cand_count = &sl->d_cnt->n_long;
                 ea.fast_filter = g_fast_filter;
                 if (g_packed_filter && ca.query4 && ca.query4->base && dc->ref2.base && !g_count_examined) {
-                    ea.fast_filter = 3;  // packed upper-bound filter (extend.hip 1c)
+                    ea.fast_filter = 3;  // packed upper-bound filter (extend.hip 1b)
                     ea.ref2 = dc->ref2.base;
                     ea.ref2_stride = dc->ref2.stride;
                     ea.query4 = ca.query4->base;
@@ -816,15 +816,6 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
         int mx = g_sub_mat[0];
         for (int i = 1; i < 64; i++) mx = std::max(mx, g_sub_mat[i]);
         g_fast_filter = (xdrop >= 0 && (int64_t)7 * std::max(mx, 0) <= (int64_t)xdrop) ? 1 : 0;
-        // pair-table filter (extend.hip 1b): int16 scores, drop test per 16-base window, E row/column as terminator
-        {
-            const int64_t m0 = std::max(mx, 0);
-            const int64_t need = (int64_t)xdrop + 15 * m0 + 1;  // fall that forces the drop test at the window end
-            bool ok = xdrop >= 0 && m0 * ((int64_t)g_long_cap + 16) <= 32767 && need <= 16383;
-            for (int i = 0; i < 8 && ok; i++)
-                if (g_sub_mat[7 * 8 + i] > -need || g_sub_mat[i * 8 + 7] > -need) ok = false;
-            if (ok && !getenv("SEGALIGN_AMD_NO_PAIR_FILTER")) g_fast_filter = 2;
-        }
         // int16 score arithmetic: the best of a side (<= max(M) * long_cap rounded up to whole 64-base windows) and xdrop itself must stay well inside
         // the saturation range, or a walk could never satisfy the drop test and every hit would become a candidate
         g_packed_filter = (xdrop >= 0 && xdrop <= 16383 && (int64_t)std::max(mx, 0) * (((int64_t)g_long_cap + 63) / 64 * 64) <= 16383 &&

@@ -406,212 +406,26 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_filter_kernel(ExtendArgs a
 }
 
 // =====================================================================================================================
-// 1b. the X-drop filter, PAIR-TABLE form: an UPPER BOUND of the side scores at 16 bases per trip
-// =====================================================================================================================
-// The filter only has to be conservative: every hit it forwards is re-extended exactly by the exact kernels, so it may
-// over-estimate a side's best score but must never under-estimate it.  That freedom buys the cheap inner loop:
-//   * the drop test (:374/:523) is evaluated once per 16-base window instead of per base.  A walk therefore never stops
-//     before the reference's walk does (at the reference's stopping position k the test is either not looked at, or it
-//     is looked at a window end >= k), and the best over a longer walk is >= the best over its prefix;
-//   * two bases are scored per LDS access: a 16-bit index pair (r0<<3|q0) | (r1<<3|q1)<<8 selects an entry holding
-//     {s0, s0+s1} as two int16; with the running score broadcast to both halves, ONE v_pk_add_i16 yields the scores
-//     after base 0 and after base 1 and ONE v_pk_max_i16 folds both into the running maxima: 3 VALU per 2 bases;
-//   * the adds saturate (clamp) and matrix entries below -16383 are raised to -16383: both only raise scores;
-//   * sequence edges: pad bytes carry the code 7 ('E', row and column of the separator character) next to their guard
-//     bit, and the engine only selects this kernel when the E row/column of the matrix is negative enough
-//     (<= -(xdrop + 15*max(M) + 1)) to force the drop test of the window in which an edge or a separator is met --
-//     after which the score only falls, so the best is the reference's (:332,:482).
-// Eligibility (engine.hip): xdrop >= 0, max(M)*(long_cap+16) <= 32767, xdrop + 15*max(M) + 1 <= 16383, E terminates.
-constexpr int PAIR_THREADS = 512;
-constexpr int PAIR_TAB = 16192;  // (63<<8|63)+1 entries of 4 bytes, index = two 6-bit matrix indices in two bytes
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-
-__global__ __launch_bounds__(PAIR_THREADS) void extend_filter_pair_kernel(ExtendArgs a) {
-    extern __shared__ uint32_t s_dyn[];
-    uint32_t* s_pair = s_dyn;
-    CandRec* s_cand = reinterpret_cast<CandRec*>(s_dyn + PAIR_TAB);
-    for (int i = threadIdx.x; i < PAIR_TAB; i += PAIR_THREADS) {
-        const int b0 = i & 0x3f, b1 = (i >> 8) & 0x3f;
-        const int s0 = max(a.sub_mat[b0], -16383), s1 = max(a.sub_mat[b1], -16383);
-        s_pair[i] = ((uint32_t)s0 & 0xffffu) | ((uint32_t)(s0 + s1) << 16);
-    }
-    __syncthreads();
-    CandRec* stage = s_cand + (threadIdx.x >> 6) * STAGE_CAP;
-    int n_stage = 0;
-
-    const int lane = threadIdx.x & 63;
-    const unsigned long long lane_lt = (1ull << lane) - 1ull;
-    const uint8_t* __restrict__ R8b = a.ref8 - BIAS;  // row-coded target: byte = r << 3 (pads: 0x78)
-    const uint8_t* __restrict__ Qb = a.query - BIAS;  // plain codes (pads: 0x47)
-    const int xdrop = a.xdrop;
-    const int fin_batch = a.fin_batch;
-    const uint32_t long_cap = a.long_cap;
-
-    // ---- the wave's queue: 64-hit buffers, round-robin over all waves of the grid ----
-    const uint64_t num_buf = (a.num_hits + 63) >> 6;
-    const uint64_t G = (uint64_t)gridDim.x * (PAIR_THREADS / 64);
-    uint64_t cur_buf = (uint64_t)blockIdx.x * (PAIR_THREADS / 64) + (threadIdx.x >> 6);
-    uint64_t nxt_buf = cur_buf + G;
-    auto buf_count = [&](uint64_t b) -> int {
-        if (b >= num_buf) return 0;
-        uint64_t rem = a.num_hits - (b << 6);
-        return rem >= 64 ? 64 : (int)rem;
-    };
-    int buf_cnt = buf_count(cur_buf), nxt_cnt = buf_count(nxt_buf), consumed = 0;
-    Hit buf = {0u, 0u}, nxt = {0u, 0u};
-    if (lane < buf_cnt) buf = a.hits[(cur_buf << 6) + lane];
-    if (lane < nxt_cnt) nxt = a.hits[(nxt_buf << 6) + lane];
-
-    // ---- per-lane state ----
-    int phase = PH_FIN;
-    bool has_hit = false, forward = false;
-    uint32_t ref_loc = 0, query_loc = 0, hidx = 0;
-    uint32_t roff = 0, qoff = 0;
-    int dstep = 16;
-    uint32_t bsel = 0x03020100u;
-    uint32_t walked = 0;
-    s16x2 T = {0, 0}, M = {0, 0};  // T.y = running score ; max(M.x, M.y) = running best
-    int bestR = 0, best = 0;
-
-    for (;;) {
-        // ================= 1. advance every live lane by one 16-base window =================
-        if (phase < PH_FIN) {
-            const uint4 rw = load16u(R8b + roff), qw = load16u(Qb + qoff);
-            const uint32_t K = 0x3F3F3F3Fu;  // strips the guard bit of pad bytes: they then read as code 7
-            const uint32_t o0 = (rw.x | qw.x) & K, o1 = (rw.y | qw.y) & K, o2 = (rw.z | qw.z) & K, o3 = (rw.w | qw.w) & K;
-            const bool left = dstep < 0;  // walking order: the left side reverses dwords and bytes
-            const uint32_t w0 = __builtin_amdgcn_perm(0u, left ? o3 : o0, bsel);
-            const uint32_t w1 = __builtin_amdgcn_perm(0u, left ? o2 : o1, bsel);
-            const uint32_t w2 = __builtin_amdgcn_perm(0u, left ? o1 : o2, bsel);
-            const uint32_t w3 = __builtin_amdgcn_perm(0u, left ? o0 : o3, bsel);
-            roff += (uint32_t)dstep;
-            qoff += (uint32_t)dstep;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint32_t w = j < 2 ? w0 : j < 4 ? w1 : j < 6 ? w2 : w3;
-                uint32_t addr;  // byte address of the entry: (16-bit half of w) << 2 in one SDWA shift
-                if (j & 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(addr) : "v"(2), "v"(w));
-                else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(addr) : "v"(2), "v"(w));
-                const s16x2 e = __builtin_bit_cast(s16x2, *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_pair) + addr));
-                const s16x2 Tb = T.yy;
-                T = __builtin_elementwise_add_sat(Tb, e);  // {t + s0, t + s0 + s1}
-                M = __builtin_elementwise_max(M, T);
-            }
-            const int m = max((int)M.x, (int)M.y), t = (int)T.y;
-            const bool dropped = (m - t) > xdrop;
-            walked += 16;
-            if (dropped) {
-                if (phase == PH_RIGHT) {  // -> left side (:457-476): anchor-1, anchor-2, ...
-                    bestR = m;
-                    phase = PH_LEFT;
-                    roff = ref_loc + BIAS - 16u;
-                    qoff = query_loc + BIAS - 16u;
-                    dstep = -16;
-                    bsel = 0x00010203u;
-                    walked = 0;
-                    T = (s16x2){0, 0};
-                    M = (s16x2){0, 0};
-                } else {
-                    best = m;
-                    phase = PH_FIN;
-                }
-            } else if (walked >= long_cap) {  // still alive after long_cap bases: real homology -> exact kernel
-                forward = true;
-                phase = PH_FIN;
-            }
-        }
-
-        // ================= 2. finalise + refill in batches =================
-        const unsigned long long fin = __ballot(phase == PH_FIN);
-        const unsigned long long live = __ballot(phase < PH_FIN);
-        if (fin != 0ull && (__popcll(fin) >= fin_batch || live == 0ull)) {
-            bool cand = false;
-            if (phase == PH_FIN && has_hit) cand = forward || classify(a, bestR + best) != 0;
-            {
-                CandRec cr;
-                cr.ref_loc = ref_loc; cr.query_loc = query_loc; cr.hidx = hidx;
-                stage_append(stage, n_stage, cand, cr, a.cand_list, a.cand_count, a.cand_cap_recs, lane, lane_lt);
-            }
-            unsigned long long need = fin;
-            bool got = false;
-            Hit mine = {0u, 0u};
-            uint32_t mine_idx = 0;
-            while (need != 0ull) {
-                const int avail = buf_cnt - consumed;
-                if (avail <= 0) {
-                    if (nxt_cnt == 0) break;  // queue exhausted
-                    buf = nxt;
-                    buf_cnt = nxt_cnt;
-                    cur_buf = nxt_buf;
-                    consumed = 0;
-                    nxt_buf += G;
-                    nxt_cnt = buf_count(nxt_buf);
-                    if (lane < nxt_cnt) nxt = a.hits[(nxt_buf << 6) + lane];
-                    continue;
-                }
-                const int rank = __popcll(need & lane_lt);
-                const bool take = ((need >> lane) & 1ull) && rank < avail;
-                const int src = (consumed + rank) & 63;
-                const uint32_t hr = (uint32_t)__shfl((int)buf.ref_loc, src, 64);
-                const uint32_t hq = (uint32_t)__shfl((int)buf.query_loc, src, 64);
-                if (take) {
-                    mine.ref_loc = hr;
-                    mine.query_loc = hq;
-                    mine_idx = (uint32_t)(cur_buf << 6) + (uint32_t)src;
-                    got = true;
-                }
-                consumed += min(__popcll(need), avail);
-                need &= ~__ballot(take);
-            }
-            if (phase == PH_FIN) {
-                forward = false;
-                if (got) {
-                    has_hit = true;
-                    ref_loc = mine.ref_loc;
-                    query_loc = mine.query_loc;
-                    hidx = mine_idx;
-                    bool skip = false;
-                    if (a.rm) skip = !(ref_loc >= a.rm_win_start && ref_loc <= a.rm_win_end);  // rm :239-244,:305-333
-                    bestR = 0;
-                    best = 0;
-                    if (ref_loc > a.ref_len || query_loc > a.query_len) skip = true;  // see extend_filter_kernel
-                    if (skip) {
-                        phase = PH_FIN;
-                    } else {
-                        phase = PH_RIGHT;  // :299-324
-                        roff = ref_loc + BIAS;
-                        qoff = query_loc + BIAS;
-                        dstep = 16;
-                        bsel = 0x03020100u;
-                        walked = 0;
-                        T = (s16x2){0, 0};
-                        M = (s16x2){0, 0};
-                    }
-                } else {
-                    has_hit = false;
-                    phase = PH_IDLE;
-                }
-            }
-        }
-        if (__ballot(phase != PH_IDLE) == 0ull) break;
-    }
-    stage_flush(stage, n_stage, a.cand_list, a.cand_count, a.cand_cap_recs, lane);
-}
-
-// =====================================================================================================================
-// 1c. the X-drop filter, PACKED form: 2-bit target, 4-bit query, an upper bound priced in lines and load instructions
+// 1b. the X-drop filter, PACKED form: 2-bit target, 4-bit query, an upper bound priced in lines and load instructions
 // =====================================================================================================================
 // Measured on MI355X (tools/micro/gather_bw.hip, gather_l1.hip): the memory system delivers ~57 G random 128-byte lines
 // per second, and a DIVERGENT 16-byte load (every lane its own line) occupies a CU's L1 for ~140 clocks even when it
 // hits -- so for anchors scattered over a 100 MB target the filter is priced in lines and in target load instructions
 // per hit, not in bytes or VALU.  The byte-coded kernels above fetch ~2.1 lines and issue ~3.4 target loads per hit.
 // Here the target is read from a 2-bit copy: ONE 16-byte load covers 64 bases, so a hit needs one load per side and
-// its whole neighbourhood [loc-64, loc+64) spans 32 bytes (1.25 lines).  Conservative by construction (see 1b):
+// its whole neighbourhood [loc-64, loc+64) spans 32 bytes (1.25 lines).
+// The filter only has to be CONSERVATIVE: every hit it forwards is re-extended exactly by the exact kernels (from the
+// anchor, nothing is carried over), so it may over-estimate a side's best score but must never under-estimate it:
 //   * target codes >= 4 (soft-masked, N, other IUPAC, separators) are stored as code 0, and the table row 0 holds, per
 //     query code, the MAXIMUM over the rows {A, L, N, X, E} -- every score the filter adds is >= the reference's;
-//   * the drop test is evaluated once per 16 bases; adds saturate; entries below -16383 are raised to -16383;
-//   * beyond a block edge the walk reads pad codes: arbitrary scores, but the reference has already stopped there, and a
-//     best over a longer walk is >= the best over its prefix.
+//   * the drop test (:374/:523) is evaluated once per 16 bases instead of per base.  A walk therefore never stops before
+//     the reference's walk does (at the reference's stopping position the test is either not looked at, or it is looked
+//     at a window end beyond it), and the best over a longer walk is >= the best over its prefix;
+//   * two bases are scored per LDS access: the pair index selects an entry holding {s0, s0+s1} as two int16; with the
+//     running score broadcast to both halves, ONE v_pk_add_i16 yields the scores after base 0 and after base 1 and ONE
+//     v_pk_max_i16 folds both into the running maxima.  The adds saturate (clamp) and matrix entries below -16383 are
+//     raised to -16383: both only raise scores;
+//   * beyond a block edge the walk reads pad codes: arbitrary scores, but the reference has already stopped there.
 // Eligibility (engine.hip): 0 <= xdrop <= 16383 and max(M) * long_cap <= 16383 (int16 scores with room for the drop test).
 // Phase copies (encode.hip) make every window byte aligned: copy k = position & 3 (target) / & 1 (query).
 // Left walks: the 128-bit target window is bit-reversed (v_bfrev_b32 + dword order), which also swaps the two bits of
@@ -621,6 +435,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void extend_filter_pair_kernel(Extend
 // The target bits are the low (bank-selecting) part on purpose: the lanes of a wave sit at nearly the same query
 // position (hits are generated query-major) but at unrelated target positions; with the query byte in the low bits the
 // table reads were 16-way bank conflicted (SQ_LDS_BANK_CONFLICT = 87 % of SQ_LDS_IDX_ACTIVE, the kernel's bottleneck).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 constexpr int PK_THREADS = 512;
 constexpr int PK_TAB = 4096;
 
@@ -1254,17 +1069,6 @@ void launch_extend_filter(const ExtendArgs& a, hipStream_t s) {
     if (!a.examined && a.fast_filter == 3) {
         const uint32_t pblocks = (uint32_t)((waves + PK_THREADS / 64 - 1) / (PK_THREADS / 64));
         hipLaunchKernelGGL(extend_filter_packed_kernel, dim3(pblocks), dim3(PK_THREADS), 0, s, a);
-        return;
-    }
-    if (!a.examined && a.fast_filter == 2) {
-        static const size_t lds = PAIR_TAB * sizeof(uint32_t) + (PAIR_THREADS / 64) * STAGE_CAP * sizeof(CandRec);
-        static bool attr_set = false;  // every device of the process runs the same code object; the call is idempotent
-        if (!attr_set) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(extend_filter_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
-        }
-        const uint32_t pblocks = (uint32_t)((waves + PAIR_THREADS / 64 - 1) / (PAIR_THREADS / 64));
-        hipLaunchKernelGGL(extend_filter_pair_kernel, dim3(pblocks), dim3(PAIR_THREADS), lds, s, a);
         return;
     }
     if (a.examined) hipLaunchKernelGGL((extend_filter_kernel<true, false>), dim3(blocks), dim3(EXT_THREADS), 0, s, a);

@@ -66,7 +66,7 @@ struct ExtendArgs {
     uint32_t long_cap;        // bases per side the filter walks before it forwards the hit to the exact kernel
     uint32_t chain_sort_threads;  // workgroup size of the chain bucket sort (0: 512)
     int fast_filter;          // 1: xdrop >= 0 && 7*max(M) <= xdrop: the filter may skip the sticky select (extend.hip)
-                              // 2: additionally eligible for the pair-table upper-bound filter (extend.hip 1b)
+                              // 3: the packed 2-bit / 4-bit upper-bound filter is used (extend.hip 1b)
     CandRec* cand_list;
     uint32_t* cand_count;
     uint32_t cand_cap_recs;

@@ -21,7 +21,7 @@ sub_mat = default_sub_mat(xdrop)
 E.select_devices([0])
 E.InitializeInterface(1)
 kmer = E.GenerateShapePos(SHAPE)
-CONFIGS = [dict(), dict(SEGALIGN_AMD_NO_PACKED_FILTER="1"), dict(SEGALIGN_AMD_NO_PACKED_FILTER="1", SEGALIGN_AMD_NO_PAIR_FILTER="1")] + [json.loads(a) for a in sys.argv[2:]]
+CONFIGS = [dict(), dict(SEGALIGN_AMD_NO_PACKED_FILTER="1")] + [json.loads(a) for a in sys.argv[2:]]
 ref = None
 for cfg in CONFIGS:
     for k in list(os.environ):

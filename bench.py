@@ -107,29 +107,13 @@ def main():
     intervals = shard.plan_intervals(query.size, seed_size, args.interval)
     q_block_len = query.size - seed_size  # q_len handed to the seeder (main.cpp:708)
 
-    import threading
-
     def run_interval(iv, collect=None):
-        bases = iv[1] - iv[0]
-        jobs = [(a, b, rev) for rev in (False, True) for (a, b) in shard.chunks_of(iv, args.chunk, q_block_len, rev)]
-        results = [None] * len(jobs)
-
-        def work(tid):  # ctypes releases the GIL inside the engine call
-            for j in range(tid, len(jobs), nthreads):
-                a, b, rev = jobs[j]
-                out = E.SeedAndFilterRange(a, b, rev, 0)
-                results[j] = (out.size - 1 if out.size else 0, E.last_call_stats() if collect is not None else None)
-
-        nthreads = max(1, args.host_threads)
-        if nthreads == 1:
-            work(0)
-        else:
-            ths = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
-            [t.start() for t in ths]
-            [t.join() for t in ths]
+        """one step: seeder_body::operator() for the interval (src/seeder.cpp:12-127) -- every 250 kbp chunk of both
+        strands through the engine, `host_threads` chunk calls in flight, issued by the library's own C++ threads"""
+        fw, rc, st = E.SeedInterval(iv[0], iv[1], q_block_len, E.STRAND_BOTH, 0, max(1, args.host_threads))
         if collect is not None:
-            collect.extend(r[1] for r in results)
-        return bases, sum(r[0] for r in results)
+            collect.append(st)
+        return iv[1] - iv[0], int(fw.size + rc.size)
 
     my = shard.shard(intervals, rank, world) or intervals
 

@@ -99,6 +99,16 @@ size_t sa_seed_and_filter_range(uint32_t start, uint32_t end, int rev, uint32_t 
 
 void sa_free_segments(sa_segment_pair* p);
 
+/* Additive: seeder_body::operator() of src/seeder.cpp:12-127 for one query interval [start, end) of the block in
+ * `buffer` (q_len = block length - seed size, src/main.cpp:708): the plus-strand chunks, then the minus-strand chunks in
+ * reverse-complement coordinates (:33-34), each through sa_seed_and_filter_range with `threads` calls in flight.
+ * *out_fw / *out_rc receive the HSPs per strand in chunk order without the header elements (free with
+ * sa_free_segments); totals (optional) sums the per-call statistics.  Returns the number of HSPs. */
+struct sa_call_stats; /* defined below */
+size_t sa_seed_interval(uint32_t start, uint32_t end, uint32_t q_len, int strands, uint32_t buffer, int threads,
+                        sa_segment_pair** out_fw, size_t* n_fw, sa_segment_pair** out_rc, size_t* n_rc,
+                        struct sa_call_stats* totals);
+
 /* ---- repeat-masker variant (repeat_masker_src/seed_filter.h:4-8) ----------------------------------------- */
 
 /* SendQueryWriteRequest() of the repeat masker: the query IS the target; builds its reverse complement on the

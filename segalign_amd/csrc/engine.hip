@@ -15,7 +15,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -1071,6 +1073,69 @@ size_t sa_seed_and_filter_range(uint32_t start, uint32_t end, int rev, uint32_t 
 }
 
 void sa_free_segments(sa_segment_pair* p) { free(p); }
+
+// seeder_body::operator() of src/seeder.cpp:12-127 for one query interval: plus-strand chunks [start, end) in steps of
+// wga_chunk, then the minus-strand chunks of the same interval in reverse-complement coordinates (:33-34,89-91), every
+// chunk through sa_seed_and_filter_range; `threads` chunk calls are kept in flight (the reference keeps one per TBB
+// worker).  HSPs are concatenated per strand in chunk order, headers removed (:80-85,115-120).
+size_t sa_seed_interval(uint32_t start, uint32_t end, uint32_t q_len, int strands, uint32_t buffer, int threads,
+                        sa_segment_pair** out_fw, size_t* n_fw, sa_segment_pair** out_rc, size_t* n_rc, sa_call_stats* totals) {
+    require_init("SeedInterval");
+    struct Job { uint32_t a, b; int rev; sa_segment_pair* res; size_t n; };
+    std::vector<Job> jobs;
+    for (int rev = 0; rev < 2; rev++) {
+        if (!(strands & (rev ? SA_STRAND_MINUS : SA_STRAND_PLUS))) continue;
+        const uint32_t a = rev ? q_len - end : start, b = rev ? q_len - start : end;
+        for (uint64_t i = a; i < b; i += g_wga_chunk) jobs.push_back({(uint32_t)i, (uint32_t)std::min<uint64_t>(i + g_wga_chunk, b), rev, nullptr, 0});
+    }
+    sa_call_stats tot;
+    memset(&tot, 0, sizeof(tot));
+    std::mutex mu;
+    std::atomic<size_t> next(0);
+    auto worker = [&]() {
+        for (;;) {
+            const size_t j = next.fetch_add(1);
+            if (j >= jobs.size()) return;
+            Job& jb = jobs[j];
+            jb.n = sa_seed_and_filter_range(jb.a, jb.b, jb.rev, buffer, &jb.res);
+            std::lock_guard<std::mutex> lk(mu);
+            tot.num_seeds += t_stats.num_seeds;
+            tot.num_hits += t_stats.num_hits;
+            tot.num_survivors += t_stats.num_survivors;
+            tot.num_anchors += t_stats.num_anchors;
+            tot.num_examined += t_stats.num_examined;
+            tot.num_examined_filter += t_stats.num_examined_filter;
+            tot.num_candidates += t_stats.num_candidates;
+            tot.num_entropy += t_stats.num_entropy;
+            tot.num_iter += t_stats.num_iter;
+            tot.device = t_stats.device;
+        }
+    };
+    const int nt = std::max(1, std::min<int>(threads, (int)jobs.size()));
+    if (nt == 1) {
+        worker();
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nt; t++) pool.emplace_back(worker);
+        for (auto& th : pool) th.join();
+    }
+    size_t cnt[2] = {0, 0};
+    for (const Job& jb : jobs) if (jb.n > 1) cnt[jb.rev] += jb.n - 1;
+    sa_segment_pair* dst[2];
+    for (int r = 0; r < 2; r++) dst[r] = (sa_segment_pair*)malloc(std::max<size_t>(cnt[r], 1) * sizeof(sa_segment_pair));
+    size_t off[2] = {0, 0};
+    for (Job& jb : jobs) {
+        if (jb.n > 1) {
+            memcpy(dst[jb.rev] + off[jb.rev], jb.res + 1, (jb.n - 1) * sizeof(sa_segment_pair));
+            off[jb.rev] += jb.n - 1;
+        }
+        free(jb.res);
+    }
+    *out_fw = dst[0]; *n_fw = cnt[0];
+    *out_rc = dst[1]; *n_rc = cnt[1];
+    if (totals) *totals = tot;
+    return cnt[0] + cnt[1];
+}
 
 size_t sa_device_make_seeds(uint32_t start, uint32_t end, int rev, uint32_t buffer, uint64_t* dst, size_t cap) {
     require_init("DeviceMakeSeeds");

@@ -35,6 +35,7 @@ C_ABI_SYMBOLS = [
     "sa_get_num_index", "sa_get_index_table_size", "sa_copy_ref_codes", "sa_copy_index_table", "sa_copy_pos_table",
     "sa_copy_query_codes", "sa_get_query_len", "sa_device_make_seeds", "sa_version",
     "sa_rm_mask_interval", "sa_rm_coverage_intervals", "sa_free_intervals", "sa_get_filter_mode",
+    "sa_seed_interval",
 ]
 IVL_DTYPE = np.dtype([("query_start", "<u4"), ("len", "<u4")])  # struct Segment, repeat_masker_src/graph.h:32-35
 STRAND_PLUS, STRAND_MINUS, STRAND_BOTH = 1, 2, 3
@@ -75,6 +76,9 @@ def lib():
     L.sa_seed_and_filter_range.restype = C.c_size_t
     L.sa_seed_and_filter_range.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]
     L.sa_free_segments.argtypes = [C.c_void_p]
+    L.sa_seed_interval.restype = C.c_size_t
+    L.sa_seed_interval.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_void_p),
+                                   C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(CallStats)]
     L.sa_rm_seed_and_filter.restype = C.c_size_t
     L.sa_rm_seed_and_filter.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
     L.sa_rm_mask_interval.restype = C.c_size_t
@@ -188,6 +192,27 @@ def SeedAndFilterRange(start, end, rev, buffer):
     out = C.c_void_p()
     n = lib().sa_seed_and_filter_range(start, end, int(bool(rev)), buffer, C.byref(out))
     return _take(n, out)
+
+
+def SeedInterval(start, end, q_len, strands=STRAND_BOTH, buffer=0, threads=2):
+    """seeder_body::operator() (src/seeder.cpp:12-127) for one query interval, chunk calls issued from C++ threads.
+    Returns (plus-strand HSPs, minus-strand HSPs, summed statistics)."""
+    fw, rc = C.c_void_p(), C.c_void_p()
+    nf, nr = C.c_size_t(), C.c_size_t()
+    st = CallStats()
+    lib().sa_seed_interval(start, end, q_len, strands, buffer, threads, C.byref(fw), C.byref(nf), C.byref(rc), C.byref(nr),
+                           C.byref(st))
+
+    def take(ptr, n):
+        if n == 0:
+            lib().sa_free_segments(ptr)
+            return np.zeros(0, dtype=SEG_DTYPE)
+        buf = (C.c_char * (n * SEG_DTYPE.itemsize)).from_address(ptr.value)
+        a = np.frombuffer(buf, dtype=SEG_DTYPE).copy()
+        lib().sa_free_segments(ptr)
+        return a
+
+    return take(fw, nf.value), take(rc, nr.value), {f[0]: getattr(st, f[0]) for f in CallStats._fields_}
 
 
 # ---- repeat masker ----------------------------------------------------------------------------------------------

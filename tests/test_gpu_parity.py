@@ -70,3 +70,25 @@ def test_examined_counter_matches_oracle(small_case):
     assert stats["num_examined"] == st["num_examined"]
     assert stats["num_candidates"] >= stats["num_survivors"]
     assert stats["num_examined_filter"] > 0
+
+
+@pytest.mark.parametrize("threads", [1, 3])
+def test_seed_interval_equals_the_chunk_loop(small_case, threads):
+    """sa_seed_interval = seeder_body::operator() (src/seeder.cpp:12-127): plus-strand chunks, then minus-strand chunks in
+    rc coordinates, HSPs concatenated per strand without headers -- against the oracle chunk by chunk."""
+    c = small_case
+    from segalign_amd import shard
+    q_len = c.query.size - c.seed_size
+    iv = (30000, min(260000, q_len))
+    want = {False: [], True: []}
+    hits = 0
+    for rev in (False, True):
+        for (s, e) in shard.chunks_of(iv, c.chunk, q_len, rev):
+            segs, st = c.oracle_saf(c.host_seeds(s, e, rev), rev)
+            want[rev].append(segs[1:])
+            hits += st["num_hits"]
+    fw, rc, tot = c.E.SeedInterval(iv[0], iv[1], q_len, c.E.STRAND_BOTH, 0, threads)
+    assert seg_equal(fw, np.concatenate(want[False])) and seg_equal(rc, np.concatenate(want[True]))
+    assert tot["num_hits"] == hits and tot["num_anchors"] == fw.size + rc.size
+    fw1, rc1, _ = c.E.SeedInterval(iv[0], iv[1], q_len, c.E.STRAND_MINUS, 0, threads)
+    assert fw1.size == 0 and seg_equal(rc1, rc)

@@ -249,8 +249,8 @@ def main():
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "ce11 x cb4 stand-in (BASELINE configs[1]): %.0f Mbp 7-record target x 8%%-diverged "
                                    "soft-masked query, 12of19 + transitions, HOXD70, xdrop 910, hspthresh 3000; "
-                                   "step = one %d bp query interval, both strands, %d bp chunks, device-side seeding"
-                                   % (args.target_mbp, args.interval, args.chunk),
+                                   "step = one %d bp query interval, both strands, %d bp chunks (4 chunks of a strand share one "
+                                   "pass over the kernels), device-side seeding" % (args.target_mbp, args.interval, args.chunk),
                        "parallelism": "query-interval shards x%d, no collective" % world,
                        "hsps_per_step": hsps // max(args.steps * world, 1)},
             "setup_s": {"generate": round(t_gen, 2), "target_upload_encode": round(t_ref, 3),

@@ -104,6 +104,12 @@ void sa_free_segments(sa_segment_pair* p);
  * reverse-complement coordinates (:33-34), each through sa_seed_and_filter_range with `threads` calls in flight.
  * *out_fw / *out_rc receive the HSPs per strand in chunk order without the header elements (free with
  * sa_free_segments); totals (optional) sums the per-call statistics.  Returns the number of HSPs. */
+/* Additive: up to sa_max_chunks_per_call() consecutive wga_chunk-sized chunks [start, start+chunk), ... of one strand in one
+ * pass over the kernels.  outs[c] / counts[c] receive exactly what sa_seed_and_filter_range returns for chunk c (own
+ * iteration plan, own dedup scope, own header; NULL / 0 for a chunk without seeds).  Returns the sum of the counts. */
+int sa_max_chunks_per_call(void);
+size_t sa_seed_and_filter_chunks(uint32_t start, uint32_t end, int rev, uint32_t buffer, sa_segment_pair** outs, size_t* counts);
+
 struct sa_call_stats; /* defined below */
 size_t sa_seed_interval(uint32_t start, uint32_t end, uint32_t q_len, int strands, uint32_t buffer, int threads,
                         sa_segment_pair** out_fw, size_t* n_fw, sa_segment_pair** out_rc, size_t* n_rc,

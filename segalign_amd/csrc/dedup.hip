@@ -152,10 +152,12 @@ __global__ __launch_bounds__(UNQ_THREADS) void unique_kernel(const HspRec* __res
     if (threadIdx.x == 0) *out_count = carry;
 }
 
-__global__ __launch_bounds__(256) void strip_kernel(const HspRec* __restrict__ in, uint32_t n, uint4* __restrict__ out) {
+__global__ __launch_bounds__(256) void strip_kernel(const HspRec* __restrict__ in, uint32_t n, uint4* __restrict__ out,
+                                                    uint32_t* __restrict__ out_seg) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const HspRec r = in[i];
         out[i] = make_uint4(r.ref_start, r.query_start, r.len, (uint32_t)r.score);
+        if (out_seg) out_seg[i] = r.seg;
     }
 }
 
@@ -163,49 +165,72 @@ __global__ __launch_bounds__(256) void strip_kernel(const HspRec* __restrict__ i
 // After the chain shortcut a call leaves a few hundred survivors; three library sorts + unique + strip then cost ~65 us of
 // pure launch latency and one extra host sync.  For n <= DEDUP_SMALL_MAX one workgroup does
 //   stable sort by LessDiag -> adjacent-pair unique (hsp_contained, H3) -> stable sort by LessLastz -> 16-byte records
-// in LDS.  The sorts are RANK sorts: rank(i) = #{j : rec[j] < rec[i]} + #{j < i : rec[j] == rec[i] under the order},
-// i.e. exactly the position a stable sort gives element i; O(n^2) comparisons spread over the workgroup, no barrier
-// chain.  (src/seed_filter.cu:776-782, all iterations of the call at once through `seg`.)
-constexpr int DEDUP_SMALL_MAX = 512;  // quadratic work: 512 x 512 comparisons over 1024 threads is still ~10 us
+// in LDS (src/seed_filter.cu:776-782, all iterations -- and all chunks of a multi-chunk call -- at once through `seg`).
+constexpr int DEDUP_SMALL_MAX = 1024;  // one record per thread in the unique step
 constexpr int DEDUP_SMALL_THREADS = 1024;
 
-// stable rank sort of src[0..n) into dst; the workgroup's threads are split into `parts` groups that each count over a
-// slice of j, partial ranks are summed in LDS.  Ends with a barrier.
+constexpr int DEDUP_SMALL_SEGS = 16;  // distinct segment ids (reference iterations x chunks of a call) the small path handles
+
+// Stable sort of a[0..n) by `Less` (segment id first) in LDS, result back in a[]; tmp[] is scratch of the same size.
+// Two steps: (1) group the records by segment (counting sort over <= DEDUP_SMALL_SEGS ids), (2) RANK sort inside every
+// segment: rank(i) = #{j in the segment : rec[j] < rec[i]} + #{j < i : rec[j] equivalent to rec[i]} is exactly the
+// position a stable sort gives element i.  O(n * segment size) comparisons spread over the workgroup (the threads are
+// split into `parts` groups that each count over a slice of the segment), no barrier chain.  Ends with a barrier.
 template <class Less>
-__device__ __forceinline__ void rank_sort_lds(const HspRec* __restrict__ src, HspRec* __restrict__ dst, uint32_t n,
-                                              uint32_t* __restrict__ s_rank) {
+__device__ __forceinline__ void seg_rank_sort_lds(HspRec* __restrict__ a, HspRec* __restrict__ tmp, uint32_t n,
+                                                  uint32_t* __restrict__ s_rank, uint32_t* __restrict__ s_seg /*[2*SEGS+1]*/) {
     Less less;
-    const uint32_t nceil = (n + 63u) & ~63u;                 // elements padded to whole waves
-    const uint32_t parts = nceil ? blockDim.x / nceil : 1u;   // >= 1 because n <= blockDim.x
-    const uint32_t i = threadIdx.x % (nceil ? nceil : 1u), p = threadIdx.x / (nceil ? nceil : 1u);
+    uint32_t* s_cnt = s_seg;                       // [SEGS] records per segment, then running cursors
+    uint32_t* s_beg = s_seg + DEDUP_SMALL_SEGS;    // [SEGS+1] first slot of every segment
+    if (threadIdx.x < DEDUP_SMALL_SEGS) s_cnt[threadIdx.x] = 0;
     for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) s_rank[k] = 0;
     __syncthreads();
+    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) atomicAdd(&s_cnt[a[k].seg & (DEDUP_SMALL_SEGS - 1)], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int g = 0; g < DEDUP_SMALL_SEGS; g++) { s_beg[g] = run; run += s_cnt[g]; s_cnt[g] = s_beg[g]; }
+        s_beg[DEDUP_SMALL_SEGS] = run;
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
+        const HspRec r = a[k];
+        tmp[atomicAdd(&s_cnt[r.seg & (DEDUP_SMALL_SEGS - 1)], 1u)] = r;  // order inside a segment is arbitrary here:
+    }                                                                   // records that compare equal are identical
+    __syncthreads();
+    const uint32_t nceil = (n + 63u) & ~63u;                  // elements padded to whole waves
+    const uint32_t parts = nceil ? blockDim.x / nceil : 1u;    // >= 1 because n <= blockDim.x
+    const uint32_t i = threadIdx.x % (nceil ? nceil : 1u), p = threadIdx.x / (nceil ? nceil : 1u);
     if (i < n && p < parts) {
-        const HspRec me = src[i];
-        const uint32_t j0 = (uint32_t)((uint64_t)n * p / parts), j1 = (uint32_t)((uint64_t)n * (p + 1) / parts);
-        uint32_t rank = 0;
+        const HspRec me = tmp[i];
+        const uint32_t g = me.seg & (DEDUP_SMALL_SEGS - 1);
+        const uint32_t b0 = s_beg[g], m = s_beg[g + 1] - b0;
+        const uint32_t j0 = b0 + (uint32_t)((uint64_t)m * p / parts), j1 = b0 + (uint32_t)((uint64_t)m * (p + 1) / parts);
+        uint32_t rank = p == 0 ? b0 : 0u;
         for (uint32_t j = j0; j < j1; j++) {
-            const HspRec o = src[j];  // one address per wave: LDS broadcast
+            const HspRec o = tmp[j];
             rank += (less(o, me) || (j < i && !less(me, o))) ? 1u : 0u;
         }
         atomicAdd(&s_rank[i], rank);
     }
     __syncthreads();
-    if (threadIdx.x < n) dst[s_rank[threadIdx.x]] = src[threadIdx.x];
+    if (threadIdx.x < n) a[s_rank[threadIdx.x]] = tmp[threadIdx.x];
     __syncthreads();
 }
 
 __global__ __launch_bounds__(DEDUP_SMALL_THREADS) void dedup_small_kernel(const HspRec* __restrict__ in, uint32_t n,
-                                                                          uint4* __restrict__ out, uint32_t* __restrict__ out_count) {
+                                                                          uint4* __restrict__ out, uint32_t* __restrict__ out_seg,
+                                                                          uint32_t* __restrict__ out_count) {
     __shared__ HspRec s_a[DEDUP_SMALL_MAX];
     __shared__ HspRec s_b[DEDUP_SMALL_MAX];
     __shared__ uint32_t s_rank[DEDUP_SMALL_MAX];
+    __shared__ uint32_t s_seg[2 * DEDUP_SMALL_SEGS + 1];
     __shared__ uint32_t s_wave[DEDUP_SMALL_THREADS / 64];
     __shared__ uint32_t s_m;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_a[i] = in[i];
     __syncthreads();
-    rank_sort_lds<LessDiag>(s_a, s_b, n, s_rank);  // :776
+    seg_rank_sort_lds<LessDiag>(s_a, s_b, n, s_rank, s_seg);  // :776
     // adjacent-pair unique on the sorted INPUT sequence (:778-780), order preserving; one element per thread
     {
         const uint32_t i = threadIdx.x;
@@ -213,8 +238,8 @@ __global__ __launch_bounds__(DEDUP_SMALL_THREADS) void dedup_small_kernel(const 
         HspRec me;
         me.ref_start = me.query_start = me.len = 0; me.score = 0; me.seg = 0;
         if (i < n) {
-            me = s_b[i];
-            keep = i == 0 || s_b[i - 1].seg != me.seg || !hsp_contained(s_b[i - 1], me);
+            me = s_a[i];
+            keep = i == 0 || s_a[i - 1].seg != me.seg || !hsp_contained(s_a[i - 1], me);
         }
         const unsigned long long mask = __ballot(keep);
         if (lane == 0) s_wave[wave] = (uint32_t)__popcll(mask);
@@ -225,32 +250,34 @@ __global__ __launch_bounds__(DEDUP_SMALL_THREADS) void dedup_small_kernel(const 
             if (w < wave) base += c;
             total += c;
         }
-        if (keep) s_a[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = me;
+        if (keep) s_b[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = me;
         if (threadIdx.x == 0) s_m = total;
         __syncthreads();
     }
     const uint32_t m = s_m;
-    rank_sort_lds<LessLastz>(s_a, s_b, m, s_rank);  // :782
+    seg_rank_sort_lds<LessLastz>(s_b, s_a, m, s_rank, s_seg);  // :782
     for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
         const HspRec r = s_b[i];
         out[i] = make_uint4(r.ref_start, r.query_start, r.len, (uint32_t)r.score);
+        if (out_seg) out_seg[i] = r.seg;
     }
     if (threadIdx.x == 0) *out_count = m;
 }
 
 uint32_t dedup_small_max() { return DEDUP_SMALL_MAX; }
-void launch_dedup_small(const HspRec* in, uint32_t n, void* out_segment_pairs, uint32_t* out_count, hipStream_t s) {
-    hipLaunchKernelGGL(dedup_small_kernel, dim3(1), dim3(DEDUP_SMALL_THREADS), 0, s, in, n, reinterpret_cast<uint4*>(out_segment_pairs), out_count);
+uint32_t dedup_small_max_segs() { return DEDUP_SMALL_SEGS; }
+void launch_dedup_small(const HspRec* in, uint32_t n, void* out_segment_pairs, uint32_t* out_seg, uint32_t* out_count, hipStream_t s) {
+    hipLaunchKernelGGL(dedup_small_kernel, dim3(1), dim3(DEDUP_SMALL_THREADS), 0, s, in, n, reinterpret_cast<uint4*>(out_segment_pairs), out_seg, out_count);
 }
 
 void launch_unique(const HspRec* in, HspRec* out, uint32_t n, int exact, uint32_t* out_count, hipStream_t s) {
     hipLaunchKernelGGL(unique_kernel, dim3(1), dim3(UNQ_THREADS), 0, s, in, out, n, exact, out_count);
 }
-void launch_strip(const HspRec* in, uint32_t n, void* out_segment_pairs, hipStream_t s) {
+void launch_strip(const HspRec* in, uint32_t n, void* out_segment_pairs, uint32_t* out_seg, hipStream_t s) {
     if (n == 0) return;
     uint32_t g = (n + 255) / 256;
     if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(strip_kernel, dim3(g), dim3(256), 0, s, in, n, reinterpret_cast<uint4*>(out_segment_pairs));
+    hipLaunchKernelGGL(strip_kernel, dim3(g), dim3(256), 0, s, in, n, reinterpret_cast<uint4*>(out_segment_pairs), out_seg);
 }
 
 }  // namespace sa

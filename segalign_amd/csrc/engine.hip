@@ -167,6 +167,7 @@ static int prof_id(const char* name) {
 // per-device state
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int MAX_SLOTS_PER_DEVICE = 4;
+constexpr int SA_MAX_CHUNKS = 4;  // chunks one multi-chunk call carries: 2 reference iterations each = MAX_SEGS segments (8 chunks measured no faster)
 static int SLOTS_PER_DEVICE = 2;  // calls in flight per device (the reference allows one: token == device); SEGALIGN_AMD_SLOTS
 
 struct Counters {  // device-side scalars of one slot
@@ -200,8 +201,12 @@ struct Slot {
     DevBuf<uint32_t> cov_diff, cov_pre, cov_is_start, cov_is_end, cov_sidx, cov_eidx, cov_pairs;
     uint32_t* d_cov_range = nullptr;  // {min query_start, max query_start+len} touched since the last reset
     uint32_t* h_cov = nullptr;        // pinned: range + per-tile totals
-    IterPlan* d_plan = nullptr;
+    IterPlan* d_plan = nullptr;       // SA_MAX_CHUNKS plans (one per chunk of a multi-chunk call)
     Counters* d_cnt = nullptr;
+    DevBuf<uint32_t> out_seg;         // segment id of every final record (multi-chunk calls split their output by it)
+    uint32_t* h_seg = nullptr;        // pinned
+    size_t h_seg_cap = 0;
+    uint32_t* h_bounds = nullptr;     // pinned: flag-prefix values at the chunk boundaries of a multi-chunk call
     // pinned host staging
     IterPlan* h_plan = nullptr;
     Counters* h_cnt = nullptr;
@@ -261,6 +266,7 @@ static int g_max_waves = 4096;    // SEGALIGN_AMD_MAX_WAVES: waves of the filter
 static int g_fast_filter = 0;     // derived in InitializeProcessor: xdrop >= 0 && 7*max(M) <= xdrop
 static int g_packed_filter = 0;   // derived in InitializeProcessor: the packed upper-bound filter may be used
 static int g_chain_sort_threads = 512;  // SEGALIGN_AMD_CHAIN_SORT_THREADS
+static int g_chunks_per_call = SA_MAX_CHUNKS;  // SEGALIGN_AMD_CHUNKS_PER_CALL: chunks sa_seed_interval hands to one multi-chunk call
 static int g_no_small_dedup = 0;  // SEGALIGN_AMD_NO_SMALL_DEDUP=1: always use the library sorts
 static int g_chain = 1;           // chain shortcut of the exact stage (SEGALIGN_AMD_NO_CHAIN=1 turns it off)
 static uint32_t CHAIN_CAP = 1u << 20;  // candidates per batch the chain buffers hold (SEGALIGN_AMD_CHAIN_CAP); larger batches fall back
@@ -338,11 +344,12 @@ static void release_slot(Slot* s) {  // src/seed_filter.cu:798-803
 static void slot_init(Slot& s, int dev) {
     s.dev = dev;
     hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
-    s.d_plan = (IterPlan*)dev_malloc(sizeof(IterPlan), "plan");
+    s.d_plan = (IterPlan*)dev_malloc(sizeof(IterPlan) * SA_MAX_CHUNKS, "plan");
     s.d_cnt = (Counters*)dev_malloc(sizeof(Counters), "counters");
     s.d_cov_range = (uint32_t*)dev_malloc(2 * sizeof(uint32_t), "coverage range");
     if (hipHostMalloc((void**)&s.h_cov, 8 * sizeof(uint32_t)) != hipSuccess ||
-        hipHostMalloc((void**)&s.h_plan, sizeof(IterPlan)) != hipSuccess ||
+        hipHostMalloc((void**)&s.h_bounds, (SA_MAX_CHUNKS + 2) * sizeof(uint32_t)) != hipSuccess ||
+        hipHostMalloc((void**)&s.h_plan, sizeof(IterPlan) * SA_MAX_CHUNKS) != hipSuccess ||
         hipHostMalloc((void**)&s.h_cnt, sizeof(Counters)) != hipSuccess) {
         fprintf(stderr, "Error: hipHostMalloc for slot staging failed\n");
         exit(12);
@@ -362,6 +369,10 @@ static void slot_destroy(Slot& s) {
     s.d_plan = nullptr; s.d_cnt = nullptr; s.d_cov_range = nullptr;
     if (s.h_cov) hipHostFree(s.h_cov);
     s.h_cov = nullptr;
+    s.out_seg.release("out seg");
+    if (s.h_seg) hipHostFree(s.h_seg);
+    if (s.h_bounds) hipHostFree(s.h_bounds);
+    s.h_seg = nullptr; s.h_bounds = nullptr; s.h_seg_cap = 0;
     if (s.h_plan) hipHostFree(s.h_plan);
     if (s.h_cnt) hipHostFree(s.h_cnt);
     if (s.h_seeds) hipHostFree(s.h_seeds);
@@ -389,6 +400,12 @@ struct CoreArgs {
     uint32_t* cov_diff;
     uint32_t cov_diff_len;
     const PackedBuf* query4;  // 4-bit phase copies of `query` (nullptr: the packed filter is not used for this call)
+    // multi-chunk call: the seed vector holds `nchunks` consecutive chunks, chunk c = seeds [seed_bound[c], seed_bound[c+1]);
+    // every chunk gets its own iteration plan, dedup scope and output vector (exactly what nchunks separate calls give)
+    int nchunks;                          // 0 or 1: ordinary call
+    uint32_t seed_bound[SA_MAX_CHUNKS + 1];
+    sa_segment_pair** outs;               // [nchunks]
+    size_t* counts;                       // [nchunks]
 };
 
 static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa_segment_pair** out) {
@@ -401,6 +418,13 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
     uint32_t n_final = 0;
     uint32_t survivors = 0;
     uint64_t n_cand_total = 0, n_ent_total = 0;
+    // chunks of the seed vector (one for an ordinary call)
+    const int K = ca.nchunks > 1 ? ca.nchunks : 1;
+    uint32_t sbound[SA_MAX_CHUNKS + 1] = {0, num_seeds};
+    if (ca.nchunks > 1) memcpy(sbound, ca.seed_bound, sizeof(uint32_t) * (K + 1));
+    uint64_t chunk_hits[SA_MAX_CHUNKS] = {0};
+    uint32_t chunk_first_seg[SA_MAX_CHUNKS + 1] = {0};
+    bool have_seg = false;  // sl->h_seg holds the segment of every final record
 
     if (num_seeds > 0) {
         // ---- bucket lookup + prefix (find_num_hits :157-182 ; inclusive_scan :714) ----
@@ -416,44 +440,61 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
             ProfScope p(sl, "hit_prefix_scan");
             launch_exclusive_scan_u64(sl->count.p, sl->prefix.p, num_seeds, sl->scan_temp.p, st);
         }
-        // ---- iteration plan (:718-745), one D2H ----
+        // ---- iteration plan (:718-745) of every chunk, one D2H ----
         {
             ProfScope p(sl, "iteration_plan");
-            launch_plan(sl->prefix.p, num_seeds, (uint64_t)(uint32_t)g_max_hits, ca.rm ? 0 : 1, sl->d_plan, st);
+            for (int c = 0; c < K; c++)
+                launch_plan(sl->prefix.p + sbound[c], sbound[c + 1] - sbound[c], (uint64_t)(uint32_t)g_max_hits, ca.rm ? 0 : 1,
+                            sl->d_plan + c, st);
         }
         check_launch("lookup/scan/plan");
-        check_memcpy(hipMemcpyAsync(sl->h_plan, sl->d_plan, sizeof(IterPlan), hipMemcpyDeviceToHost, st), "plan");
+        check_memcpy(hipMemcpyAsync(sl->h_plan, sl->d_plan, sizeof(IterPlan) * K, hipMemcpyDeviceToHost, st), "plan");
         check_memcpy(hipMemsetAsync(sl->d_cnt, 0, sizeof(Counters), st), "counters");
         check_sync(st, "plan");
         memset(sl->h_cnt, 0, sizeof(Counters));
-        const IterPlan& plan = *sl->h_plan;
-        if (plan.overflow) {
-            fprintf(stderr, "Error: SeedAndFilter needs %u iterations (> %u); MAX_HITS=%ld is too small for %lu hits\n",
-                    plan.overflow, PLAN_MAX_ITER, (long)g_max_hits, (unsigned long)plan.num_hits);
-            exit(15);
+        // flat list of reference iterations ("segments") over all chunks: global seed / hit offsets of their ends
+        struct SegEnd { int64_t seed_hi; uint64_t hit_hi; };
+        std::vector<SegEnd> segs;
+        {
+            uint64_t hit_base = 0;
+            for (int c = 0; c < K; c++) {
+                const IterPlan& plan = sl->h_plan[c];
+                if (plan.overflow) {
+                    fprintf(stderr, "Error: SeedAndFilter needs %u iterations (> %u); MAX_HITS=%ld is too small for %lu hits\n",
+                            plan.overflow, PLAN_MAX_ITER, (long)g_max_hits, (unsigned long)plan.num_hits);
+                    exit(15);
+                }
+                chunk_first_seg[c] = (uint32_t)segs.size();
+                chunk_hits[c] = plan.num_hits;
+                if (plan.num_hits > 0)
+                    for (uint32_t i = 0; i < plan.num_iter; i++)
+                        segs.push_back({(int64_t)sbound[c] + plan.limit_pos[i] + 1, hit_base + plan.upto[i]});
+                hit_base += plan.num_hits;
+                t_stats.num_iter += plan.num_iter;
+            }
+            chunk_first_seg[K] = (uint32_t)segs.size();
+            num_hits = hit_base;
         }
-        num_hits = plan.num_hits;
-        t_stats.num_iter = plan.num_iter;
 
-        if (num_hits > 0 && plan.num_iter > 0) {
+        if (num_hits > 0 && !segs.empty()) {
             // ---- batches of consecutive iterations: expand (find_hits) + extend (find_hsps) ----
             const uint64_t HIT_BATCH = 1ull << 27;  // 128 Mi hits (1 GiB of 8-byte hits) per batch unless one iteration is larger
             sl->recA.ensure((size_t)std::max<uint64_t>(1u << 20, std::min<uint64_t>(num_hits, 1ull << 26)), "survivors");
             uint32_t it = 0;
             int64_t seed_lo = 0;
             uint64_t hit_lo = 0;
-            while (it < plan.num_iter) {
+            while (it < segs.size()) {
                 ExtendArgs ea;
                 memset(&ea, 0, sizeof(ea));
                 int nseg = 0;
                 int64_t b_seed_lo = seed_lo, b_seed_hi = seed_lo;
                 uint64_t b_hit_lo = hit_lo, b_hit_hi = hit_lo;
                 uint32_t it0 = it;
-                while (it < plan.num_iter && nseg < MAX_SEGS) {
-                    uint64_t upto = plan.upto[it];
+                while (it < segs.size() && nseg < MAX_SEGS) {
+                    uint64_t upto = segs[it].hit_hi;
                     if (nseg > 0 && upto - b_hit_lo > HIT_BATCH) break;
                     ea.seg_end[nseg++] = upto;
-                    b_seed_hi = plan.limit_pos[it] + 1;
+                    b_seed_hi = std::max(b_seed_hi, segs[it].seed_hi);
                     b_hit_hi = upto;
                     it++;
                 }
@@ -590,18 +631,32 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     exit(12);
                 }
             };
+            auto ensure_host_seg = [&](size_t n) {
+                if (sl->h_seg_cap >= n) return;
+                if (sl->h_seg) hipHostFree(sl->h_seg);
+                sl->h_seg_cap = std::max<size_t>(n, 1u << 16);
+                if (hipHostMalloc((void**)&sl->h_seg, sl->h_seg_cap * sizeof(uint32_t)) != hipSuccess) {
+                    fprintf(stderr, "Error: hipHostMalloc for the segment ids failed\n");
+                    exit(12);
+                }
+            };
             if (survivors > 0) {
                 sl->recB.ensure(std::max<size_t>(survivors, sl->recA.cap), "survivors B");
                 size_t tb = sort_temp_bytes(survivors);
                 sl->sort_temp.ensure(tb, "sort temp");
                 HspRec* fin = nullptr;
-                const bool small = !ca.rm && survivors <= dedup_small_max() && !g_no_small_dedup;
+                const bool small = !ca.rm && survivors <= dedup_small_max() && segs.size() <= dedup_small_max_segs() && !g_no_small_dedup;
                 if (small) {  // the whole chain in one workgroup, one D2H of count + records
                     sl->out16.ensure(survivors, "out16");
                     ensure_host_out(survivors);
-                    { ProfScope p(sl, "dedup_small"); launch_dedup_small(sl->recA.p, survivors, sl->out16.p, &sl->d_cnt->uniq, st); }
+                    if (K > 1) { sl->out_seg.ensure(survivors, "out seg"); ensure_host_seg(survivors); }
+                    { ProfScope p(sl, "dedup_small"); launch_dedup_small(sl->recA.p, survivors, sl->out16.p, K > 1 ? sl->out_seg.p : nullptr, &sl->d_cnt->uniq, st); }
                     check_launch("dedup small");
                     check_memcpy(hipMemcpyAsync(sl->h_cnt, sl->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st), "counters");
+                    if (K > 1) {
+                        check_memcpy(hipMemcpyAsync(sl->h_seg, sl->out_seg.p, (size_t)survivors * sizeof(uint32_t), hipMemcpyDeviceToHost, st), "hsp segs");
+                        have_seg = true;
+                    }
                     check_memcpy(hipMemcpyAsync(sl->h_out, sl->out16.p, (size_t)survivors * sizeof(sa_segment_pair),
                                                 hipMemcpyDeviceToHost, st), "hsp_output");  // :788
                     check_sync(st, "hsp_output");
@@ -640,8 +695,13 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                 if (n_final > 0 && fin) {
                     sl->out16.ensure(n_final, "out16");
                     ensure_host_out(n_final);
-                    { ProfScope p(sl, "strip"); launch_strip(fin, n_final, sl->out16.p, st); }
+                    if (K > 1) { sl->out_seg.ensure(n_final, "out seg"); ensure_host_seg(n_final); }
+                    { ProfScope p(sl, "strip"); launch_strip(fin, n_final, sl->out16.p, K > 1 ? sl->out_seg.p : nullptr, st); }
                     check_launch("final sort/strip");
+                    if (K > 1) {
+                        check_memcpy(hipMemcpyAsync(sl->h_seg, sl->out_seg.p, (size_t)n_final * sizeof(uint32_t), hipMemcpyDeviceToHost, st), "hsp segs");
+                        have_seg = true;
+                    }
                     check_memcpy(hipMemcpyAsync(sl->h_out, sl->out16.p, (size_t)n_final * sizeof(sa_segment_pair),
                                                 hipMemcpyDeviceToHost, st), "hsp_output");  // :788
                 }
@@ -654,6 +714,30 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
     t_stats.num_hits = num_hits;
     t_stats.num_survivors = survivors;
     t_stats.num_anchors = n_final;
+    if (K > 1) {
+        // ---- one return vector per chunk: records are ordered by segment, chunk c owns segments
+        //      [chunk_first_seg[c], chunk_first_seg[c+1]) ; a chunk without seeds returns nothing (seeder.cpp:76) ----
+        size_t pos = 0;
+        for (int c = 0; c < K; c++) {
+            size_t n_c = 0;
+            if (have_seg)
+                while (pos + n_c < n_final && sl->h_seg[pos + n_c] < chunk_first_seg[c + 1]) n_c++;
+            if (sbound[c + 1] == sbound[c]) {
+                ca.outs[c] = nullptr;
+                ca.counts[c] = 0;
+            } else {
+                sa_segment_pair* r = (sa_segment_pair*)malloc((n_c + 1) * sizeof(sa_segment_pair));
+                memset(&r[0], 0, sizeof(sa_segment_pair));
+                r[0].len = (uint32_t)n_c;
+                r[0].score = (int32_t)(uint32_t)chunk_hits[c];
+                if (n_c) memcpy(r + 1, sl->h_out + pos, n_c * sizeof(sa_segment_pair));
+                ca.outs[c] = r;
+                ca.counts[c] = n_c + 1;
+            }
+            pos += n_c;
+        }
+        return (size_t)n_final + K;
+    }
     if (out == nullptr) return (size_t)n_final + 1;  // coverage mode: nothing is returned to the host
 
     // ---- return vector: header + HSPs (:804-827 ; rm :857-861) ----
@@ -692,7 +776,10 @@ static void upload_seeds(Slot* sl, const uint64_t* seeds, size_t n) {
 }
 
 // device-side seeder (8f-1): fills sl->seeds for query positions [start,end); returns number of seed words
-static uint32_t device_seeds(Slot* sl, const uint8_t* qcodes, uint32_t start, uint32_t end) {
+// nb > 0: also reports, for nb positions bpos[] in [start, end], the number of seed words emitted before them
+static uint32_t device_seeds(Slot* sl, const uint8_t* qcodes, uint32_t start, uint32_t end, int nb = 0,
+                             const uint32_t* bpos = nullptr, uint32_t* bseed = nullptr) {
+    for (int b = 0; b < nb; b++) bseed[b] = 0;
     if (end <= start) return 0;
     hipStream_t st = sl->stream;
     const uint32_t n = end - start;
@@ -714,8 +801,12 @@ static uint32_t device_seeds(Slot* sl, const uint8_t* qcodes, uint32_t start, ui
     check_launch("seed flags");
     uint32_t nvalid = 0;
     check_memcpy(hipMemcpyAsync(&sl->h_cnt->pad, sl->flag_prefix.p + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st), "nvalid");
+    for (int b = 0; b < nb; b++)
+        check_memcpy(hipMemcpyAsync(&sl->h_bounds[b], sl->flag_prefix.p + (std::min(std::max(bpos[b], start), end) - start), sizeof(uint32_t),
+                                    hipMemcpyDeviceToHost, st), "chunk bounds");
     check_sync(st, "seed flags");
     nvalid = sl->h_cnt->pad;
+    for (int b = 0; b < nb; b++) bseed[b] = sl->h_bounds[b] * per;
     const uint64_t nseeds = (uint64_t)nvalid * per;
     if (nseeds == 0) return 0;
     sl->seeds.ensure(std::max<size_t>((size_t)nseeds, (size_t)g_max_seeds), "seed_offsets");
@@ -829,6 +920,8 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
         if (const char* e = getenv("SEGALIGN_AMD_CHAIN_CAP")) CHAIN_CAP = (uint32_t)std::max(1, atoi(e));
         else CHAIN_CAP = 1u << 20;
         g_no_small_dedup = getenv("SEGALIGN_AMD_NO_SMALL_DEDUP") ? 1 : 0;
+        g_chunks_per_call = SA_MAX_CHUNKS;
+        if (const char* e = getenv("SEGALIGN_AMD_CHUNKS_PER_CALL")) g_chunks_per_call = std::max(1, std::min(SA_MAX_CHUNKS, atoi(e)));
     }
     std::lock_guard<std::mutex> lk(g_mu);
     g_tokens.clear();
@@ -1072,6 +1165,51 @@ size_t sa_seed_and_filter_range(uint32_t start, uint32_t end, int rev, uint32_t 
     return n;
 }
 
+// Up to SA_MAX_CHUNKS consecutive wga_chunk-sized chunks of one strand in ONE pass over the kernels: the chunks share the
+// seeding, lookup, expansion, extension, grouping and ordering launches and the host syncs, while every chunk keeps its own
+// iteration plan, dedup scope and return vector -- bit for bit what one sa_seed_and_filter_range call per chunk returns.
+int sa_max_chunks_per_call(void) { return SA_MAX_CHUNKS; }
+size_t sa_seed_and_filter_chunks(uint32_t start, uint32_t end, int rev, uint32_t buffer, sa_segment_pair** outs, size_t* counts) {
+    require_init("SeedAndFilterChunks");
+    const uint32_t chunk = g_wga_chunk;
+    const int K = end > start ? (int)(((uint64_t)end - start + chunk - 1) / chunk) : 0;
+    if (K > SA_MAX_CHUNKS) {
+        fprintf(stderr, "Error: SeedAndFilterChunks takes at most %d chunks per call\n", SA_MAX_CHUNKS);
+        exit(1);
+    }
+    for (int c = 0; c < K; c++) { outs[c] = nullptr; counts[c] = 0; }
+    if (K == 0) return 0;
+    if (K == 1) {
+        counts[0] = sa_seed_and_filter_range(start, end, rev, buffer, &outs[0]);
+        return counts[0];
+    }
+    Slot* sl = acquire_slot();
+    DevCtx* dc = g_dev[0];
+    for (auto* d : g_dev) if (d->dev == sl->dev) dc = d;
+    const uint8_t* q = rev ? dc->query_rc[buffer].codes : dc->query[buffer].codes;
+    const uint32_t qlen = g_query_len[buffer];
+    const uint32_t lim = qlen >= g_seed_size ? qlen - g_seed_size + 1 : 0;
+    const uint32_t send = std::min(end, lim);  // a seed window must lie inside the block
+    uint32_t bpos[SA_MAX_CHUNKS + 1], bseed[SA_MAX_CHUNKS + 1];
+    for (int c = 0; c <= K; c++) bpos[c] = (uint32_t)std::min<uint64_t>((uint64_t)start + (uint64_t)c * chunk, send);
+    const uint32_t ns = device_seeds(sl, q, start, send, K + 1, bpos, bseed);
+    size_t total = 0;
+    if (ns > 0) {
+        CoreArgs ca = {q, qlen, 0, 0, 0, 0, start, send, nullptr, 0, rev ? &dc->query4_rc[buffer] : &dc->query4[buffer]};
+        ca.nchunks = K;
+        for (int c = 0; c <= K; c++) ca.seed_bound[c] = bseed[c];
+        ca.outs = outs;
+        ca.counts = counts;
+        saf_core(dc, sl, ns, ca, nullptr);
+        for (int c = 0; c < K; c++) total += counts[c];
+    } else {
+        prof_flush(sl);
+        memset(&t_stats, 0, sizeof(t_stats));
+    }
+    release_slot(sl);
+    return total;
+}
+
 void sa_free_segments(sa_segment_pair* p) { free(p); }
 
 // seeder_body::operator() of src/seeder.cpp:12-127 for one query interval: plus-strand chunks [start, end) in steps of
@@ -1081,12 +1219,21 @@ void sa_free_segments(sa_segment_pair* p) { free(p); }
 size_t sa_seed_interval(uint32_t start, uint32_t end, uint32_t q_len, int strands, uint32_t buffer, int threads,
                         sa_segment_pair** out_fw, size_t* n_fw, sa_segment_pair** out_rc, size_t* n_rc, sa_call_stats* totals) {
     require_init("SeedInterval");
-    struct Job { uint32_t a, b; int rev; sa_segment_pair* res; size_t n; };
+    struct Job { uint32_t a, b; int rev; int k; sa_segment_pair* res[SA_MAX_CHUNKS]; size_t n[SA_MAX_CHUNKS]; };
     std::vector<Job> jobs;
+    const int per_job = g_chunks_per_call;  // chunks of one strand that share one pass over the kernels
     for (int rev = 0; rev < 2; rev++) {
         if (!(strands & (rev ? SA_STRAND_MINUS : SA_STRAND_PLUS))) continue;
         const uint32_t a = rev ? q_len - end : start, b = rev ? q_len - start : end;
-        for (uint64_t i = a; i < b; i += g_wga_chunk) jobs.push_back({(uint32_t)i, (uint32_t)std::min<uint64_t>(i + g_wga_chunk, b), rev, nullptr, 0});
+        for (uint64_t i = a; i < b; i += (uint64_t)g_wga_chunk * per_job) {
+            Job jb;
+            memset(&jb, 0, sizeof(jb));
+            jb.a = (uint32_t)i;
+            jb.b = (uint32_t)std::min<uint64_t>(i + (uint64_t)g_wga_chunk * per_job, b);
+            jb.rev = rev;
+            jb.k = (int)(((uint64_t)jb.b - jb.a + g_wga_chunk - 1) / g_wga_chunk);
+            jobs.push_back(jb);
+        }
     }
     sa_call_stats tot;
     memset(&tot, 0, sizeof(tot));
@@ -1097,7 +1244,7 @@ size_t sa_seed_interval(uint32_t start, uint32_t end, uint32_t q_len, int strand
             const size_t j = next.fetch_add(1);
             if (j >= jobs.size()) return;
             Job& jb = jobs[j];
-            jb.n = sa_seed_and_filter_range(jb.a, jb.b, jb.rev, buffer, &jb.res);
+            sa_seed_and_filter_chunks(jb.a, jb.b, jb.rev, buffer, jb.res, jb.n);
             std::lock_guard<std::mutex> lk(mu);
             tot.num_seeds += t_stats.num_seeds;
             tot.num_hits += t_stats.num_hits;
@@ -1120,17 +1267,19 @@ size_t sa_seed_interval(uint32_t start, uint32_t end, uint32_t q_len, int strand
         for (auto& th : pool) th.join();
     }
     size_t cnt[2] = {0, 0};
-    for (const Job& jb : jobs) if (jb.n > 1) cnt[jb.rev] += jb.n - 1;
+    for (const Job& jb : jobs)
+        for (int c = 0; c < jb.k; c++) if (jb.n[c] > 1) cnt[jb.rev] += jb.n[c] - 1;
     sa_segment_pair* dst[2];
     for (int r = 0; r < 2; r++) dst[r] = (sa_segment_pair*)malloc(std::max<size_t>(cnt[r], 1) * sizeof(sa_segment_pair));
     size_t off[2] = {0, 0};
-    for (Job& jb : jobs) {
-        if (jb.n > 1) {
-            memcpy(dst[jb.rev] + off[jb.rev], jb.res + 1, (jb.n - 1) * sizeof(sa_segment_pair));
-            off[jb.rev] += jb.n - 1;
+    for (Job& jb : jobs)
+        for (int c = 0; c < jb.k; c++) {
+            if (jb.n[c] > 1) {
+                memcpy(dst[jb.rev] + off[jb.rev], jb.res[c] + 1, (jb.n[c] - 1) * sizeof(sa_segment_pair));
+                off[jb.rev] += jb.n[c] - 1;
+            }
+            free(jb.res[c]);
         }
-        free(jb.res);
-    }
     *out_fw = dst[0]; *n_fw = cnt[0];
     *out_rc = dst[1]; *n_rc = cnt[1];
     if (totals) *totals = tot;

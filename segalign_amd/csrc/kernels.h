@@ -161,10 +161,12 @@ void launch_sort(const HspRec* in, HspRec* out, size_t n, SortOrder order, void*
 // adjacent-pair unique (thrust::unique_copy on device, hazard H3) within each segment; order preserving.
 // exact = 0: hspEqual of seed_filter.cu:47-52 ; exact = 1: field equality (repeat masker :80-85)
 void launch_unique(const HspRec* in, HspRec* out, uint32_t n, int exact, uint32_t* out_count, hipStream_t s);
-void launch_strip(const HspRec* in, uint32_t n, void* out_segment_pairs, hipStream_t s);
+void launch_strip(const HspRec* in, uint32_t n, void* out_segment_pairs, uint32_t* out_seg /*nullable*/, hipStream_t s);
 // sort(diag) -> unique -> sort(lastz) -> 16-byte records for n <= dedup_small_max() survivors in ONE workgroup
 uint32_t dedup_small_max();
-void launch_dedup_small(const HspRec* in, uint32_t n, void* out_segment_pairs, uint32_t* out_count, hipStream_t s);
+uint32_t dedup_small_max_segs();
+void launch_dedup_small(const HspRec* in, uint32_t n, void* out_segment_pairs, uint32_t* out_seg /*nullable*/,
+                        uint32_t* out_count, hipStream_t s);
 
 // ---- coverage.hip (repeat-masker post-processing, repeat_masker_src/seeder.cpp:153-188) ------------------------
 struct SegPair16 { uint32_t ref_start, query_start, len; int32_t score; };  // layout of sa_segment_pair / segmentPair

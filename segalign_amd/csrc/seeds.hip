@@ -122,8 +122,11 @@ __global__ __launch_bounds__(EXP_SEEDS) void expand_hits_kernel(const uint64_t* 
 __global__ void plan_kernel(const uint64_t* __restrict__ excl, uint32_t num_seeds, uint64_t max_hits, int wrap32,
                             IterPlan* __restrict__ plan) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // `excl` may point into the prefix of a larger seed vector (several chunks planned from one scan): all values are
+    // taken relative to excl[0], which is 0 for a stand-alone call
     const uint64_t* incl = excl + 1;
-    uint64_t num_hits = num_seeds ? incl[num_seeds - 1] : 0;  // :716
+    const uint64_t base = excl[0];
+    uint64_t num_hits = num_seeds ? incl[num_seeds - 1] - base : 0;  // :716
     if (wrap32) num_hits &= 0xFFFFFFFFull;
     plan->num_hits = num_hits;
     plan->num_iter = 0;
@@ -138,13 +141,13 @@ __global__ void plan_kernel(const uint64_t* __restrict__ excl, uint32_t num_seed
         uint32_t lo = 0, hi = num_seeds;
         while (lo < hi) {
             uint32_t mid = lo + (hi - lo) / 2;
-            uint64_t v = incl[mid];
+            uint64_t v = incl[mid] - base;
             if (wrap32) v &= 0xFFFFFFFFull;
             if (v < limit) lo = mid + 1; else hi = mid;
         }
         int64_t pos = (int64_t)lo - 1;  // -1 == the reference's wrapped index (hazard H5): treated as "0 hits"
         plan->limit_pos[i] = pos;
-        uint64_t at = pos >= 0 ? incl[pos] : 0;
+        uint64_t at = pos >= 0 ? incl[pos] - base : 0;
         limit = at + max_hits;
         if (wrap32) limit &= 0xFFFFFFFFull;
         if (limit > num_hits) limit = num_hits;
@@ -153,7 +156,7 @@ __global__ void plan_kernel(const uint64_t* __restrict__ excl, uint32_t num_seed
     if (plan->limit_pos[num_iter - 1] == plan->limit_pos[num_iter - 2]) num_iter--;  // :743
     for (uint32_t i = 0; i < num_iter; i++) {
         int64_t p = plan->limit_pos[i];
-        plan->upto[i] = p >= 0 ? incl[p] : 0;
+        plan->upto[i] = p >= 0 ? incl[p] - base : 0;
     }
     plan->num_iter = num_iter;
 }

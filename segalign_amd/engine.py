@@ -35,7 +35,7 @@ C_ABI_SYMBOLS = [
     "sa_get_num_index", "sa_get_index_table_size", "sa_copy_ref_codes", "sa_copy_index_table", "sa_copy_pos_table",
     "sa_copy_query_codes", "sa_get_query_len", "sa_device_make_seeds", "sa_version",
     "sa_rm_mask_interval", "sa_rm_coverage_intervals", "sa_free_intervals", "sa_get_filter_mode",
-    "sa_seed_interval",
+    "sa_seed_interval", "sa_seed_and_filter_chunks", "sa_max_chunks_per_call",
 ]
 IVL_DTYPE = np.dtype([("query_start", "<u4"), ("len", "<u4")])  # struct Segment, repeat_masker_src/graph.h:32-35
 STRAND_PLUS, STRAND_MINUS, STRAND_BOTH = 1, 2, 3
@@ -76,6 +76,8 @@ def lib():
     L.sa_seed_and_filter_range.restype = C.c_size_t
     L.sa_seed_and_filter_range.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]
     L.sa_free_segments.argtypes = [C.c_void_p]
+    L.sa_seed_and_filter_chunks.restype = C.c_size_t
+    L.sa_seed_and_filter_chunks.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.sa_seed_interval.restype = C.c_size_t
     L.sa_seed_interval.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_void_p),
                                    C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(CallStats)]
@@ -192,6 +194,19 @@ def SeedAndFilterRange(start, end, rev, buffer):
     out = C.c_void_p()
     n = lib().sa_seed_and_filter_range(start, end, int(bool(rev)), buffer, C.byref(out))
     return _take(n, out)
+
+
+def SeedAndFilterChunks(start, end, rev, buffer):
+    """Up to sa_max_chunks_per_call() consecutive chunks of one strand in one pass; returns one vector per chunk, each
+    identical to SeedAndFilterRange of that chunk (empty array for a chunk without seeds)."""
+    k = lib().sa_max_chunks_per_call()
+    outs = (C.c_void_p * k)()
+    counts = (C.c_size_t * k)()
+    lib().sa_seed_and_filter_chunks(start, end, int(bool(rev)), buffer, outs, counts)
+    res = []
+    for c in range(k):
+        res.append(_take(counts[c], C.c_void_p(outs[c])) if outs[c] else np.zeros(0, dtype=SEG_DTYPE))
+    return res
 
 
 def SeedInterval(start, end, q_len, strands=STRAND_BOTH, buffer=0, threads=2):

@@ -152,26 +152,43 @@ static void seed_interval(size_t q_block_start, uint32_t q_len /* block_len - se
         if (rev == 1 && !(cfg.strand == "minus" || cfg.strand == "both")) continue;
         uint32_t a = rev ? q_len - iv.end : iv.start, b = rev ? q_len - iv.start : iv.end;  // :33-34
         std::vector<sa_segment_pair>& dst = rev ? out.rc : out.fw;
-        for (uint32_t i = a; i < b; i += cfg.wga_chunk) {
+        if (!cfg.host_seeding) {
+            // device seeding: up to sa_max_chunks_per_call() consecutive chunks share one pass over the kernels; every
+            // chunk still gets its own return vector, identical to one call per chunk
+            const int kmax = sa_max_chunks_per_call();
+            std::vector<sa_segment_pair*> res((size_t)kmax, nullptr);
+            std::vector<size_t> n((size_t)kmax, 0);
+            for (uint64_t i = a; i < b; i += (uint64_t)cfg.wga_chunk * kmax) {
+                const uint32_t e = (uint32_t)std::min<uint64_t>(i + (uint64_t)cfg.wga_chunk * kmax, b);
+                sa_seed_and_filter_chunks((uint32_t)i, e, rev, buffer, res.data(), n.data());
+                for (int c = 0; c < kmax; c++) {
+                    if (!n[c]) continue;
+                    g_num_seed_hits += (uint32_t)res[c][0].score;
+                    if (n[c] > 1) {
+                        dst.insert(dst.end(), res[c] + 1, res[c] + n[c]);
+                        g_num_hsps += n[c] - 1;
+                    }
+                    sa_free_segments(res[c]);
+                }
+            }
+            continue;
+        }
+        for (uint32_t i = a; i < b; i += cfg.wga_chunk) {  // the reference's loop: seed words built on the host, :57-74
             uint32_t e = std::min(i + cfg.wga_chunk, b);
             sa_segment_pair* res = nullptr;
             size_t n = 0;
-            if (cfg.host_seeding) {
-                const std::string& buf = rev ? Qrc : Q.buf;
-                std::vector<uint64_t> seeds;
-                for (uint32_t j = i; j < e; j++) {
-                    uint64_t k = host_kmer(buf.data(), q_block_start + j);
-                    if (k != (1u << 31)) {
-                        seeds.push_back((k << 32) + j);
-                        if (cfg.transition)
-                            for (int t = 0; t < shape_weight; t++)
-                                if (transition_pos[t]) seeds.push_back(((k ^ ((uint64_t)2 << (2 * t))) << 32) + j);
-                    }
+            const std::string& buf = rev ? Qrc : Q.buf;
+            std::vector<uint64_t> seeds;
+            for (uint32_t j = i; j < e; j++) {
+                uint64_t k = host_kmer(buf.data(), q_block_start + j);
+                if (k != (1u << 31)) {
+                    seeds.push_back((k << 32) + j);
+                    if (cfg.transition)
+                        for (int t = 0; t < shape_weight; t++)
+                            if (transition_pos[t]) seeds.push_back(((k ^ ((uint64_t)2 << (2 * t))) << 32) + j);
                 }
-                if (!seeds.empty()) n = sa_seed_and_filter(seeds.data(), seeds.size(), rev, buffer, &res);
-            } else {
-                n = sa_seed_and_filter_range(i, e, rev, buffer, &res);
             }
+            if (!seeds.empty()) n = sa_seed_and_filter(seeds.data(), seeds.size(), rev, buffer, &res);
             if (n) {
                 g_num_seed_hits += (uint32_t)res[0].score;
                 if (n > 1) {

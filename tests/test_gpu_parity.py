@@ -92,3 +92,22 @@ def test_seed_interval_equals_the_chunk_loop(small_case, threads):
     assert tot["num_hits"] == hits and tot["num_anchors"] == fw.size + rc.size
     fw1, rc1, _ = c.E.SeedInterval(iv[0], iv[1], q_len, c.E.STRAND_MINUS, 0, threads)
     assert fw1.size == 0 and seg_equal(rc1, rc)
+
+
+@pytest.mark.parametrize("rev", [False, True])
+def test_multi_chunk_call_equals_one_call_per_chunk(small_case, rev):
+    """sa_seed_and_filter_chunks: several chunks share one pass over the kernels, but every chunk keeps its own iteration
+    plan, dedup scope and header -- the vectors must equal the per-chunk calls (and the oracle) exactly"""
+    c = small_case
+    q_len = c.query.size - c.seed_size
+    k = 3
+    for start in (0, 40000):
+        end = min(start + k * c.chunk, q_len)
+        got = c.E.SeedAndFilterChunks(start, end, rev, 0)
+        nch = -(-(end - start) // c.chunk)
+        assert all(g.size == 0 for g in got[nch:])
+        for i in range(nch):
+            s, e = start + i * c.chunk, min(start + (i + 1) * c.chunk, end)
+            want, _ = c.oracle_saf(c.host_seeds(s, e, rev), rev)
+            assert seg_equal(got[i], want), (rev, start, i, got[i][:3], want[:3])
+            assert seg_equal(got[i], c.E.SeedAndFilterRange(s, e, rev, 0))

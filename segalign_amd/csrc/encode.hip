@@ -81,21 +81,29 @@ __global__ __launch_bounds__(256) void row_code_kernel(const uint8_t* __restrict
 }
 
 // ---- packed copies for the packed X-drop filter (extend.hip 1b) ---------------------------------------------------
-// 2 bits per base, codes >= 4 stored as 0; PHASE copy k holds bases [4j+k, 4j+k+4) in byte j, so that a window that
-// starts (or ends) at ANY base position is byte aligned in the copy k = position & 3.
+// 2 bits per base, codes >= 4 stored as 0; PHASE copy k holds bases [4j+k, 4j+k+4) in (logical) byte j, so that a window
+// that starts (or ends) at ANY base position is byte aligned in the copy k = position & 3.
+// Physical layout = OVERLAPPED 128-byte lines: line L holds the logical bytes [96 L, 96 L + 128) of the copy (logical
+// byte jj = PACK2_BIAS + index of the 4-base group), i.e. the last 32 bytes of every line repeat the first 32 of the
+// next.  Any 32-byte span that starts in the first 96 bytes of a line lies inside that line, so the filter fetches the
+// left and right 16-byte windows of a hit (logical bytes [jj-16, jj+16)) from ONE line whatever the anchor position:
+// 1.0 target lines per hit instead of 1 + 31/128 (storage x 4/3).  Physical byte of logical byte jj in the line chosen
+// for logical byte jb (jb <= jj < jb + 32):  jj + 32 * (jb / 96).
 __global__ __launch_bounds__(256) void pack2_phase_kernel(const uint8_t* __restrict__ codes, uint32_t len,
-                                                          uint8_t* __restrict__ out, size_t copy_stride, uint32_t nbytes) {
-    const uint64_t total = (uint64_t)nbytes * 4;
+                                                          uint8_t* __restrict__ out, size_t copy_stride, uint32_t nphys) {
+    const uint64_t total = (uint64_t)nphys * 4;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t k = (uint32_t)(i / nbytes), j = (uint32_t)(i % nbytes);
+        const uint32_t k = (uint32_t)(i / nphys), p = (uint32_t)(i % nphys);
+        const int64_t jj = (int64_t)(p >> 7) * PACK2_PAYLOAD + (p & 127u);
+        const int64_t j = jj - PACK2_BIAS;  // index of the 4-base group: bases [4j+k, 4j+k+4)
         uint32_t v = 0;
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            const uint64_t pos = (uint64_t)j * 4 + k + b;
-            const uint32_t c = pos < len ? codes[pos] : 0u;
+            const int64_t pos = j * 4 + k + b;
+            const uint32_t c = (pos >= 0 && pos < (int64_t)len) ? codes[pos] : 0u;
             v |= (c < 4u ? c : 0u) << (2 * b);
         }
-        out[k * copy_stride + j] = (uint8_t)v;
+        out[k * copy_stride + p] = (uint8_t)v;
     }
 }
 // 4 bits per base (code & 7), phase copy k holds bases [2j+k, 2j+k+2) in byte j, first base in the low nibble
@@ -129,8 +137,12 @@ void launch_row_code(const uint8_t* codes, uint8_t* out, uint32_t len, hipStream
     if (len == 0) return;
     hipLaunchKernelGGL(row_code_kernel, dim3(grid_for(len / 16 + 1, 256)), dim3(256), 0, s, codes, out, len);
 }
-void launch_pack2_phases(const uint8_t* codes, uint32_t len, uint8_t* out, size_t copy_stride, uint32_t nbytes, hipStream_t s) {
-    hipLaunchKernelGGL(pack2_phase_kernel, dim3(grid_for((uint64_t)nbytes * 4, 256)), dim3(256), 0, s, codes, len, out, copy_stride, nbytes);
+uint32_t pack2_phys_bytes(uint32_t len) {  // physical bytes of one 2-bit copy: logical bytes up to len/4 + 64 + bias, in lines
+    const uint64_t jjmax = (uint64_t)len / 4 + 64 + PACK2_BIAS;
+    return (uint32_t)((jjmax / PACK2_PAYLOAD + 2) * 128);
+}
+void launch_pack2_phases(const uint8_t* codes, uint32_t len, uint8_t* out, size_t copy_stride, uint32_t nphys, hipStream_t s) {
+    hipLaunchKernelGGL(pack2_phase_kernel, dim3(grid_for((uint64_t)nphys * 4, 256)), dim3(256), 0, s, codes, len, out, copy_stride, nphys);
 }
 void launch_pack4_phases(const uint8_t* codes, uint32_t len, uint8_t* out, size_t copy_stride, uint32_t nbytes, hipStream_t s) {
     hipLaunchKernelGGL(pack4_phase_kernel, dim3(grid_for((uint64_t)nbytes * 2, 256)), dim3(256), 0, s, codes, len, out, copy_stride, nbytes);

@@ -117,16 +117,22 @@ struct PackedBuf {  // phase copies of a packed sequence (packed X-drop filter):
     size_t stride = 0;
     void create(const uint8_t* codes, uint32_t len, int bits, const char* tag, hipStream_t s) {
         release(tag);
-        const int copies = bits == 2 ? 4 : 2;
-        const uint32_t nbytes = len / (bits == 2 ? 4 : 2) + 1;
+        if (bits == 2) {  // overlapped-line layout (encode.hip): no separate pads, the layout carries its own bias
+            const uint32_t nphys = pack2_phys_bytes(len);
+            stride = nphys;
+            alloc = (uint8_t*)dev_malloc(stride * 4, tag);
+            base = alloc;
+            launch_pack2_phases(codes, len, base, stride, nphys, s);  // writes every physical byte (0 outside the block)
+            return;
+        }
+        const uint32_t nbytes = len / 2 + 1;
         stride = ((size_t)nbytes + 2 * PACK_PAD + 127) & ~(size_t)127;
-        alloc = (uint8_t*)dev_malloc(stride * copies, tag);
-        // pads: 2-bit copies read as code 0, 4-bit copies as code 7 in both nibbles (any content keeps the filter's
-        // scores upper bounds; these make a walk that leaves the block die quickly under the default matrices)
-        check_memcpy(hipMemsetAsync(alloc, bits == 2 ? 0x00 : 0x77, stride * copies, s), tag);
+        alloc = (uint8_t*)dev_malloc(stride * 2, tag);
+        // pads read as code 7 in both nibbles (any content keeps the filter's scores upper bounds; this makes a walk that
+        // leaves the block die quickly under the default matrices)
+        check_memcpy(hipMemsetAsync(alloc, 0x77, stride * 2, s), tag);
         base = alloc + PACK_PAD;
-        if (bits == 2) launch_pack2_phases(codes, len, base, stride, nbytes, s);
-        else launch_pack4_phases(codes, len, base, stride, nbytes, s);
+        launch_pack4_phases(codes, len, base, stride, nbytes, s);
     }
     void release(const char* tag) {
         dev_free(alloc, tag);

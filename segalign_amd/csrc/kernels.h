@@ -49,7 +49,7 @@ struct EntRec {               // finished hit with hspthresh <= total <= 3*hspth
 };
 
 struct ExtendArgs {
-    const uint8_t* ref2;      // packed filter: 2-bit target, phase copy k at ref2 + k*ref2_stride (byte 0 = bases k..k+3)
+    const uint8_t* ref2;      // packed filter: 2-bit target, phase copy k at ref2 + k*ref2_stride, overlapped-line layout
     size_t ref2_stride;
     const uint8_t* query4;    // packed filter: 4-bit query of this call's strand, phase copy k at query4 + k*query4_stride
     size_t query4_stride;
@@ -107,8 +107,13 @@ void launch_rev_comp_codes(const uint8_t* codes, uint8_t* codes_rc, uint32_t len
 // row-coded copy of the target for the extension kernel: out[i] = codes[i] << 3
 void launch_row_code(const uint8_t* codes, uint8_t* out, uint32_t len, hipStream_t s);
 // phase copies for the packed filter: out + k*copy_stride is copy k (4 copies at 2 bit/base, 2 copies at 4 bit/base)
-constexpr int PACK_PAD = 64;  // pad bytes in front of / behind every packed copy
-void launch_pack2_phases(const uint8_t* codes, uint32_t len, uint8_t* out, size_t copy_stride, uint32_t nbytes, hipStream_t s);
+constexpr int PACK_PAD = 64;  // pad bytes in front of / behind every 4-bit copy
+// 2-bit copies use overlapped 128-byte lines (encode.hip): 96 new bytes + the first 32 of the next line; logical byte =
+// PACK2_BIAS + group index, physical byte of logical jj in the line chosen for logical jb = jj + 32 * (jb / 96)
+constexpr int PACK2_PAYLOAD = 96;
+constexpr int PACK2_BIAS = 96;
+uint32_t pack2_phys_bytes(uint32_t len);
+void launch_pack2_phases(const uint8_t* codes, uint32_t len, uint8_t* out, size_t copy_stride, uint32_t nphys, hipStream_t s);
 void launch_pack4_phases(const uint8_t* codes, uint32_t len, uint8_t* out, size_t copy_stride, uint32_t nbytes, hipStream_t s);
 
 // ---- scan.hip --------------------------------------------------------------------------------------------------

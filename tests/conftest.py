@@ -25,3 +25,12 @@ def engine():
     from segalign_amd import engine as E
     E.lib()
     return E
+
+
+@pytest.fixture(scope="session")
+def standin_100mbp():
+    """BASELINE configs[1] stand-in (100 Mbp 7-record target x 8 %-diverged soft-masked query with inversions), generated
+    once per session and shared by the full-size modules (configs[1], [3], [4])."""
+    from segalign_amd import synth
+    return synth.make_pair(100_000_000, 3, 4, sub_rate=0.08, mask_frac=0.2, records=7, invert_frac=0.3,
+                           invert_block=100_000)

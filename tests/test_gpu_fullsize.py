@@ -12,10 +12,9 @@ SHAPE = "TTT0T00TT00T0T0TTTT"
 
 
 @pytest.fixture(scope="module")
-def full(oracle, engine):
+def full(oracle, engine, standin_100mbp):
     E, O = engine, oracle
-    target, query = synth.make_pair(100_000_000, 3, 4, sub_rate=0.08, mask_frac=0.2, records=7, invert_frac=0.3,
-                                    invert_block=100_000)
+    target, query = standin_100mbp
     sub_mat = O.build_sub_mat(910)
     E.InitializeInterface(1)
     k = E.GenerateShapePos(SHAPE)
@@ -107,3 +106,71 @@ def test_one_full_chunk_bit_exact_vs_oracle(full, rev):
     got = E.SeedAndFilter(seeds, rev, 0)
     assert st["num_hits"] > 5_000_000
     assert got.shape == want.shape and np.all(got == want)
+
+
+# ---- BASELINE configs[3]: repeat-masker path on the same 100 Mbp target (self-alignment, neighbor_proportion 0.2, M 1) ----
+@pytest.fixture(scope="module")
+def full_rm(full):
+    """run_segalign_repeat_masker's engine state: the query IS the target (repeat_masker_src/seed_filter.cu:951-961)."""
+    E, O, target = full["E"], full["O"], full["target"]
+    E.RmSendQueryWriteRequest()
+    rcodes = E.copy_ref_codes()
+    yield dict(full, rcodes=rcodes, rc_codes=O.rev_comp_codes(rcodes),
+               rc_ascii=np.frombuffer(O.rev_comp_ascii(target.tobytes(), 0, target.size), dtype=np.uint8),
+               index=E.copy_index_table(), pos=E.copy_pos_table())
+    E.RmClearQuery()
+
+
+def test_configs3_repeat_masker_plan_intervals_properties(full_rm):
+    """Whole intervals of the reference's plan (repeat_masker_src/main.cpp:316-436) through sa_rm_mask_interval at full
+    size: the runs are sorted, disjoint, non-empty, inside the block; totals are consistent; the call is deterministic."""
+    E, O, target = full_rm["E"], full_rm["O"], full_rm["target"]
+    L = target.size
+    tasks = O.rm_plan(L, 1000000000, 10000000, 0.2, 19)
+    assert tasks.size == 10 and int(tasks["block_len"][0]) == L
+    seen = 0
+    for t in (tasks[0], tasks[5], tasks[-1]):
+        a, b, ws, we = int(t["start"]), int(t["end"]), int(t["ref_start"]), int(t["ref_end"])
+        iv, tot = E.RmMaskInterval(a, b, ws, we, E.STRAND_BOTH, 1)
+        iv2, tot2 = E.RmMaskInterval(a, b, ws, we, E.STRAND_BOTH, 1)
+        assert np.array_equal(iv, iv2) and tot == tot2
+        assert tot["num_seeds"] > 0 and tot["num_hits"] > tot["num_seeds"] and tot["num_hsps"] > 0
+        s = iv["query_start"].astype(np.int64)
+        e = s + iv["len"].astype(np.int64)
+        assert np.all(iv["len"] > 0) and np.all(s >= 0) and np.all(e <= L)
+        assert np.all(s[1:] > e[:-1])  # maximal runs: strictly separated, ascending
+        # the trivial self-alignment covers every upper-case stretch of the interval that a seed reaches: the masked runs
+        # lie inside the interval's own coordinates (plus strand) or anywhere in the window (minus strand)
+        assert s.size > 100
+        seen += s.size
+    assert seen > 1000
+
+
+@pytest.mark.parametrize("strands", [1, 2])
+def test_configs3_repeat_masker_chunks_bit_exact_vs_oracle(full_rm, strands):
+    """Two 250 kbp chunks of one interval, one strand per case: sa_rm_seed_and_filter (windowed SeedAndFilter, rm
+    :724-876) and sa_rm_mask_interval (the whole seeder body) against the oracle, table copied from the device."""
+    E, O, target = full_rm["E"], full_rm["O"], full_rm["target"]
+    L, chunk = target.size, 250000
+    rev = strands == 2
+    start_pos, end_pos, ws, we = 42_000_000, 42_500_000, 40_000_000, 52_000_000
+    end_pos_rc = L - 1 - start_pos
+    hsps = []
+    for i in range(start_pos, end_pos, chunk):
+        s0, s1 = i, min(i + chunk, end_pos)
+        if rev:  # repeat_masker_src/seeder.cpp:118-119
+            s0 = L - 1 - s1
+            s1 = min(s0 + chunk, end_pos_rc)
+        buf = full_rm["rc_ascii"] if rev else target
+        seeds = O.make_seeds(buf.tobytes(), 0, s0, s1, 19, full_rm["k"], True)
+        want, st = O.seed_and_filter(full_rm["rcodes"], full_rm["rc_codes"] if rev else full_rm["rcodes"], full_rm["index"],
+                                     full_rm["pos"], seeds, full_rm["sub_mat"], rm=(rev, ws, we))
+        got = E.RmSeedAndFilter(seeds, rev, ws, we)
+        assert st["num_hits"] > 1_000_000
+        assert got.shape == want.shape and np.all(got == want)
+        hsps.append(want[1:])
+    allh = np.concatenate(hsps)
+    assert allh.size > 0
+    want_iv = O.rm_coverage_intervals(allh, L, 1)
+    got_iv, tot = E.RmMaskInterval(start_pos, end_pos, ws, we, strands, 1)
+    assert np.array_equal(got_iv, want_iv) and tot["num_hsps"] == allh.size

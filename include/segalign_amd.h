@@ -203,6 +203,12 @@ uint32_t sa_get_query_len(uint32_t buffer);
 /* seed words the device seeder produces for [start,end) (8f-1), for comparison with src/seeder.cpp's vector */
 size_t sa_device_make_seeds(uint32_t start, uint32_t end, int rev, uint32_t buffer, uint64_t* dst, size_t cap);
 
+/* The extension stage alone (find_hsps + compaction of the passing hits, src/seed_filter.cu:232-680) for caller-supplied
+ * anchors: ref_query_pairs[2i] = ref_loc, [2i+1] = query_loc on the resident target / strand `rev` of query `buffer`.
+ * out[0] = header {len = count}; the passing records follow unordered and not de-duplicated (exact duplicates of one
+ * run of anchors may already be merged).  Used to check the extension kernels against golden vectors. */
+size_t sa_extend_hits(const uint32_t* ref_query_pairs, size_t num_hits, int rev, uint32_t buffer, sa_segment_pair** out);
+
 const char* sa_version(void);
 
 #ifdef __cplusplus

@@ -21,6 +21,19 @@
 //   ShutdownProcessor_ptr     g_ShutdownProcessor     (src/seed_filter.h:8,14)        src/seed_filter.cu:946
 //   void GenerateSeedPosTable(char*, size_t, uint32_t, uint32_t, int, int) (ntcoding.h:9)  seed_pos_table.cu:49
 //
+// The repeat-masker binary (repeat_masker_src/) declares THE SAME NAMES with different signatures
+// (repeat_masker_src/seed_filter.h:4-14): its translation unit does instead
+//          #define SEGALIGN_AMD_COMPAT_DEFINE_RM
+//          #include "segalign_amd_compat.hpp"
+// which defines
+//   InitializeProcessor_ptr   g_InitializeProcessor   (repeat_masker_src/seed_filter.h:4,10)   repeat_masker_src/seed_filter.cu:983
+//   SendQueryWriteRequest_ptr g_SendQueryWriteRequest  void(*)()                                (:5,11)   :984
+//   SeedAndFilter_ptr         g_SeedAndFilter          vector<segmentPair>(*)(vector<uint64_t>, bool rev, uint32_t ref_start,
+//                                                      uint32_t ref_end)                        (:6,12)   :985
+//   ClearQuery_ptr            g_ClearQuery             void(*)()                                (:7,13)   :986
+//   ShutdownProcessor_ptr     g_ShutdownProcessor                                               (:8,14)   :987
+// plus the three common/ symbols and GenerateSeedPosTable as above.
+//
 // Two things the reference keeps in host globals are bridged explicitly:
 //   * the seed shape: GenerateShapePos (ntcoding.cpp:21-37) fills `shape_pos[] / transition_pos[]`, which
 //     ntcoding.cpp exports as plain globals (ntcoding.cpp:6-8); the compat GenerateSeedPosTable re-derives the shape
@@ -50,9 +63,16 @@ typedef void (*ClearRef_ptr)();
 typedef void (*ShutdownProcessor_ptr)();
 typedef void (*InitializeProcessor_ptr)(bool transition, uint32_t WGA_CHUNK, uint32_t input_seed_size, int* sub_mat,
                                         int input_xdrop, int input_hspthresh, bool input_noentropy);
+#if defined(SEGALIGN_AMD_COMPAT_RM) || defined(SEGALIGN_AMD_COMPAT_DEFINE_RM)  // repeat_masker_src/seed_filter.h:5-7
+typedef void (*SendQueryWriteRequest_ptr)();
+typedef std::vector<segmentPair> (*SeedAndFilter_ptr)(std::vector<uint64_t> seed_offset_vector, bool rev, uint32_t ref_start,
+                                                      uint32_t ref_end);
+typedef void (*ClearQuery_ptr)();
+#else                                                                            // src/seed_filter.h:5-7
 typedef void (*SendQueryWriteRequest_ptr)(size_t addr, uint32_t len, uint32_t buffer);
 typedef std::vector<segmentPair> (*SeedAndFilter_ptr)(std::vector<uint64_t> seed_offset_vector, bool rev, uint32_t buffer);
 typedef void (*ClearQuery_ptr)(uint32_t buffer);
+#endif
 #endif
 
 static_assert(sizeof(segmentPair) == sizeof(sa_segment_pair), "segmentPair layout (src/graph.h:25-30)");
@@ -105,7 +125,11 @@ inline std::vector<segmentPair> SeedAndFilter(std::vector<uint64_t> seed_offset_
     return v;
 }
 
-// repeat masker flavour: SeedAndFilter(seeds, rev, ref_start, ref_end) (repeat_masker_src/seed_filter.h:6)
+// repeat masker flavour (repeat_masker_src/seed_filter.h:5-7): the query IS the resident target
+inline void RmSendQueryWriteRequest() { sa_rm_send_query_write_request(); }  // repeat_masker_src/seed_filter.cu:951-961
+inline void RmClearQuery() { sa_rm_clear_query(); }                          // repeat_masker_src/seed_filter.cu:964-972
+// SeedAndFilter(seeds, rev, ref_start, ref_end) (repeat_masker_src/seed_filter.cu:724-876); element 0 packs the 64-bit
+// hit / anchor counts as {ref_start, query_start} / {len, score} (:857-861)
 inline std::vector<segmentPair> RmSeedAndFilter(std::vector<uint64_t> seed_offset_vector, bool rev, uint32_t ref_start,
                                                 uint32_t ref_end) {
     sa_segment_pair* out = nullptr;
@@ -130,6 +154,22 @@ inline std::string shape_from_arrays(const int* shape_pos, int weight, const int
 
 }  // namespace segalign_amd_compat
 
+#if defined(SEGALIGN_AMD_COMPAT_DEFINE) && defined(SEGALIGN_AMD_COMPAT_DEFINE_RM)
+#error "one binary links either src/ (SEGALIGN_AMD_COMPAT_DEFINE) or repeat_masker_src/ (SEGALIGN_AMD_COMPAT_DEFINE_RM)"
+#endif
+
+#ifdef SEGALIGN_AMD_COMPAT_DEFINE_RM
+// ---- the definitions repeat_masker_src/seed_filter.cu:983-987 and common/seed_filter_interface.cu:115-117 used to provide ----
+InitializeInterface_ptr g_InitializeInterface = segalign_amd_compat::InitializeInterface;      // seed_filter_interface.cu:115
+SendRefWriteRequest_ptr g_SendRefWriteRequest = segalign_amd_compat::SendRefWriteRequest;      // :116
+ClearRef_ptr g_ClearRef = segalign_amd_compat::ClearRef;                                       // :117
+InitializeProcessor_ptr g_InitializeProcessor = segalign_amd_compat::InitializeProcessor;      // repeat_masker_src/seed_filter.cu:983
+SendQueryWriteRequest_ptr g_SendQueryWriteRequest = segalign_amd_compat::RmSendQueryWriteRequest;  // :984
+SeedAndFilter_ptr g_SeedAndFilter = segalign_amd_compat::RmSeedAndFilter;                      // :985
+ClearQuery_ptr g_ClearQuery = segalign_amd_compat::RmClearQuery;                               // :986
+ShutdownProcessor_ptr g_ShutdownProcessor = segalign_amd_compat::ShutdownProcessor;            // :987
+#endif
+
 #ifdef SEGALIGN_AMD_COMPAT_DEFINE
 // ---- the definitions the reference's .cu files used to provide -----------------------------------------------------
 InitializeInterface_ptr g_InitializeInterface = segalign_amd_compat::InitializeInterface;      // seed_filter_interface.cu:115
@@ -140,7 +180,9 @@ SendQueryWriteRequest_ptr g_SendQueryWriteRequest = segalign_amd_compat::SendQue
 SeedAndFilter_ptr g_SeedAndFilter = segalign_amd_compat::SeedAndFilter;                        // :944
 ClearQuery_ptr g_ClearQuery = segalign_amd_compat::ClearQuery;                                 // :945
 ShutdownProcessor_ptr g_ShutdownProcessor = segalign_amd_compat::ShutdownProcessor;            // :946
+#endif
 
+#if defined(SEGALIGN_AMD_COMPAT_DEFINE) || defined(SEGALIGN_AMD_COMPAT_DEFINE_RM)
 // globals of common/ntcoding.cpp:6-8 (that file stays in the build)
 extern int shape_pos[32];
 extern int shape_size;
@@ -152,4 +194,4 @@ void GenerateSeedPosTable(char* ref_str, size_t start_addr, uint32_t ref_length,
     sa_generate_shape_pos(shape.c_str());
     sa_generate_seed_pos_table(ref_str, start_addr, ref_length, step, shape_span, kmer_size);
 }
-#endif  // SEGALIGN_AMD_COMPAT_DEFINE
+#endif  // SEGALIGN_AMD_COMPAT_DEFINE / _RM

@@ -24,6 +24,7 @@
 #include "../../include/segalign_amd.h"
 #include "kernels.h"
 #include "plan.h"
+#include "probe.h"
 
 namespace sa {
 
@@ -207,6 +208,13 @@ struct Slot {
     DevBuf<uint32_t> cov_diff, cov_pre, cov_is_start, cov_is_end, cov_sidx, cov_eidx, cov_pairs;
     uint32_t* d_cov_range = nullptr;  // {min query_start, max query_start+len} touched since the last reset
     uint32_t* h_cov = nullptr;        // pinned: range + per-tile totals
+    // table-direct path (probe.hip): per-position scratch, compacted non-empty positions, chunk plans
+    DevBuf<uint64_t> td_toff, td_prefix, td_off;
+    DevBuf<uint32_t> td_tcnt, td_qpos;
+    DevBuf<uint8_t> td_partial;
+    void* d_td_bounds = nullptr;
+    TdPlan* d_td_plan = nullptr;
+    TdPlan* h_td_plan = nullptr;      // pinned
     IterPlan* d_plan = nullptr;       // SA_MAX_CHUNKS plans (one per chunk of a multi-chunk call)
     Counters* d_cnt = nullptr;
     DevBuf<uint32_t> out_seg;         // segment id of every final record (multi-chunk calls split their output by it)
@@ -242,6 +250,14 @@ struct DevCtx {
     uint32_t* pos_table = nullptr;
     uint32_t num_index = 0;
     uint32_t nkeys = 0;
+    // neighbourhood table (probe.hip): per key the concatenation of the buckets of the key's seed words
+    std::mutex nbr_mu;
+    uint64_t* nbr_start = nullptr;       // nkeys + 1
+    uint32_t* nbr_pos = nullptr;         // == pos_table when no transition word exists (nbr_alias)
+    bool nbr_alias = false;
+    uint64_t nbr_total = 0;
+    uint32_t nbr_tmask = 0;
+    int nbr_state = 0;                   // 0: not built, 1: ready, -1: not available for this table (memory, 32-bit run lengths)
     SeqBuf query[SA_BUFFER_DEPTH], query_rc[SA_BUFFER_DEPTH];
     Slot slots[MAX_SLOTS_PER_DEVICE];
 };
@@ -274,6 +290,7 @@ static int g_packed_filter = 0;   // derived in InitializeProcessor: the packed 
 static int g_chain_sort_threads = 512;  // SEGALIGN_AMD_CHAIN_SORT_THREADS
 static int g_chunks_per_call = SA_MAX_CHUNKS;  // SEGALIGN_AMD_CHUNKS_PER_CALL: chunks sa_seed_interval hands to one multi-chunk call
 static int g_no_small_dedup = 0;  // SEGALIGN_AMD_NO_SMALL_DEDUP=1: always use the library sorts
+static int g_td = 1;              // table-direct lookup (neighbourhood table + position probe, probe.hip); SEGALIGN_AMD_NO_TD=1 turns it off
 static int g_chain = 1;           // chain shortcut of the exact stage (SEGALIGN_AMD_NO_CHAIN=1 turns it off)
 static uint32_t CHAIN_CAP = 1u << 20;  // candidates per batch the chain buffers hold (SEGALIGN_AMD_CHAIN_CAP); larger batches fall back
 static SeedShape g_shape = {0, 0, 0, {0}};
@@ -353,9 +370,12 @@ static void slot_init(Slot& s, int dev) {
     s.d_plan = (IterPlan*)dev_malloc(sizeof(IterPlan) * SA_MAX_CHUNKS, "plan");
     s.d_cnt = (Counters*)dev_malloc(sizeof(Counters), "counters");
     s.d_cov_range = (uint32_t*)dev_malloc(2 * sizeof(uint32_t), "coverage range");
+    s.d_td_bounds = dev_malloc(probe_bounds_bytes(), "probe bounds");
+    s.d_td_plan = (TdPlan*)dev_malloc(sizeof(TdPlan) * SA_MAX_CHUNKS, "probe plan");
     if (hipHostMalloc((void**)&s.h_cov, 8 * sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc((void**)&s.h_bounds, (SA_MAX_CHUNKS + 2) * sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc((void**)&s.h_plan, sizeof(IterPlan) * SA_MAX_CHUNKS) != hipSuccess ||
+        hipHostMalloc((void**)&s.h_td_plan, sizeof(TdPlan) * SA_MAX_CHUNKS) != hipSuccess ||
         hipHostMalloc((void**)&s.h_cnt, sizeof(Counters)) != hipSuccess) {
         fprintf(stderr, "Error: hipHostMalloc for slot staging failed\n");
         exit(12);
@@ -371,6 +391,12 @@ static void slot_destroy(Slot& s) {
     s.chain_heads.release("chain"); s.chain_bucket_cnt.release("chain"); s.chain_bucket_start.release("chain"); s.ent_list.release("entropy list");
     s.cov_diff.release("coverage"); s.cov_pre.release("coverage"); s.cov_is_start.release("coverage");
     s.cov_is_end.release("coverage"); s.cov_sidx.release("coverage"); s.cov_eidx.release("coverage"); s.cov_pairs.release("coverage");
+    s.td_toff.release("probe"); s.td_prefix.release("probe"); s.td_off.release("probe"); s.td_tcnt.release("probe");
+    s.td_qpos.release("probe"); s.td_partial.release("probe");
+    dev_free(s.d_td_bounds, "probe bounds"); dev_free(s.d_td_plan, "probe plan");
+    s.d_td_bounds = nullptr; s.d_td_plan = nullptr;
+    if (s.h_td_plan) hipHostFree(s.h_td_plan);
+    s.h_td_plan = nullptr;
     dev_free(s.d_plan, "plan"); dev_free(s.d_cnt, "counters"); dev_free(s.d_cov_range, "coverage range");
     s.d_plan = nullptr; s.d_cnt = nullptr; s.d_cov_range = nullptr;
     if (s.h_cov) hipHostFree(s.h_cov);
@@ -412,6 +438,13 @@ struct CoreArgs {
     uint32_t seed_bound[SA_MAX_CHUNKS + 1];
     sa_segment_pair** outs;               // [nchunks]
     size_t* counts;                       // [nchunks]
+    // table-direct call (td_front has filled sl->h_td_plan and the compacted position arrays): no seed words, no per-word
+    // extents, no hit list; the filter reads its anchors out of the neighbourhood table
+    int td;
+    uint32_t td_words;                    // seed words per valid position (1 + transition positions)
+    // sa_extend_hits (introspection): sl->hits already holds raw_hits anchors; one iteration, no lookup, no dedup -- the
+    // survivors of the extension stage (find_hsps + done-flag compaction) are returned as they are
+    uint64_t raw_hits;
 };
 
 static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa_segment_pair** out) {
@@ -433,6 +466,32 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
     bool have_seg = false;  // sl->h_seg holds the segment of every final record
 
     if (num_seeds > 0) {
+        // flat list of reference iterations ("segments") over all chunks: global seed / hit offsets of their ends
+        struct SegEnd { int64_t seed_hi; uint64_t hit_hi; };
+        std::vector<SegEnd> segs;
+        if (ca.raw_hits) {
+            check_memcpy(hipMemsetAsync(sl->d_cnt, 0, sizeof(Counters), st), "counters");
+            memset(sl->h_cnt, 0, sizeof(Counters));
+            segs.push_back({1, ca.raw_hits});
+            chunk_hits[0] = num_hits = ca.raw_hits;
+            chunk_first_seg[1] = 1;
+        } else if (ca.td) {
+            // ---- table-direct: td_front has probed the positions and planned every chunk (probe.hip); counters were cleared there ----
+            memset(sl->h_cnt, 0, sizeof(Counters));
+            for (int c = 0; c < K; c++) {
+                const TdPlan& tp = sl->h_td_plan[c];
+                chunk_first_seg[c] = (uint32_t)segs.size();
+                chunk_hits[c] = tp.num_hits;
+                sbound[c + 1] = sbound[c] + tp.num_valid * ca.td_words;
+                if (tp.num_hits > 0) {  // num_hits < MAX_HITS: exactly two iterations (:721-724,:732-741)
+                    segs.push_back({0, tp.split});
+                    segs.push_back({0, tp.hit_base + tp.num_hits});
+                    t_stats.num_iter += 2;
+                }
+                num_hits = tp.hit_base + tp.num_hits;
+            }
+            chunk_first_seg[K] = (uint32_t)segs.size();
+        } else {
         // ---- bucket lookup + prefix (find_num_hits :157-182 ; inclusive_scan :714) ----
         sl->start.ensure(num_seeds, "seed start");
         sl->count.ensure(num_seeds, "seed count");
@@ -458,9 +517,6 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
         check_memcpy(hipMemsetAsync(sl->d_cnt, 0, sizeof(Counters), st), "counters");
         check_sync(st, "plan");
         memset(sl->h_cnt, 0, sizeof(Counters));
-        // flat list of reference iterations ("segments") over all chunks: global seed / hit offsets of their ends
-        struct SegEnd { int64_t seed_hi; uint64_t hit_hi; };
-        std::vector<SegEnd> segs;
         {
             uint64_t hit_base = 0;
             for (int c = 0; c < K; c++) {
@@ -481,6 +537,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
             chunk_first_seg[K] = (uint32_t)segs.size();
             num_hits = hit_base;
         }
+        }
 
         if (num_hits > 0 && !segs.empty()) {
             // ---- batches of consecutive iterations: expand (find_hits) + extend (find_hsps) ----
@@ -498,7 +555,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                 uint32_t it0 = it;
                 while (it < segs.size() && nseg < MAX_SEGS) {
                     uint64_t upto = segs[it].hit_hi;
-                    if (nseg > 0 && upto - b_hit_lo > HIT_BATCH) break;
+                    if (!ca.td && nseg > 0 && upto - b_hit_lo > HIT_BATCH) break;  // (no hit list in a table-direct call)
                     ea.seg_end[nseg++] = upto;
                     b_seed_hi = std::max(b_seed_hi, segs[it].seed_hi);
                     b_hit_hi = upto;
@@ -507,14 +564,22 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                 seed_lo = b_seed_hi;
                 hit_lo = b_hit_hi;
                 const uint64_t bh = b_hit_hi - b_hit_lo;
-                if (bh == 0 || b_seed_hi <= b_seed_lo) continue;  // iterations without hits produce nothing (H5)
-                sl->hits.ensure((size_t)bh, "hits");
-                {
+                if (bh == 0 || (!ca.td && b_seed_hi <= b_seed_lo)) continue;  // iterations without hits produce nothing (H5)
+                if (ca.td) {
+                    ea.td = 1;
+                    ea.td_prefix = sl->td_prefix.p;
+                    ea.td_off = sl->td_off.p;
+                    ea.td_qpos = sl->td_qpos.p;
+                    ea.td_m = sl->h_td_plan[K - 1].m_hi;
+                    ea.td_pos = dc->nbr_pos;
+                    ea.seed_size = g_seed_size;
+                } else if (!ca.raw_hits) {
+                    sl->hits.ensure((size_t)bh, "hits");
                     ProfScope p(sl, "expand_hits");
                     launch_expand_hits(sl->seeds.p, sl->start.p, sl->count.p, sl->prefix.p, (uint32_t)b_seed_lo,
                                        (uint32_t)b_seed_hi, b_hit_lo, dc->pos_table, g_seed_size, sl->hits.p, st);
                 }
-                ea.hits = sl->hits.p;
+                ea.hits = ca.td ? nullptr : sl->hits.p;
                 ea.ref8 = dc->ref8.codes;
                 ea.fin_batch = g_fin_batch;
                 ea.bufs_per_wave = g_bufs_per_wave;
@@ -646,7 +711,16 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     exit(12);
                 }
             };
-            if (survivors > 0) {
+            if (survivors > 0 && ca.raw_hits) {  // the extension stage's own output, unordered
+                sl->out16.ensure(survivors, "out16");
+                ensure_host_out(survivors);
+                launch_strip(sl->recA.p, survivors, sl->out16.p, nullptr, st);
+                check_launch("strip");
+                check_memcpy(hipMemcpyAsync(sl->h_out, sl->out16.p, (size_t)survivors * sizeof(sa_segment_pair), hipMemcpyDeviceToHost, st),
+                             "hsp_output");
+                check_sync(st, "hsp_output");
+                n_final = survivors;
+            } else if (survivors > 0) {
                 sl->recB.ensure(std::max<size_t>(survivors, sl->recA.cap), "survivors B");
                 size_t tb = sort_temp_bytes(survivors);
                 sl->sort_temp.ensure(tb, "sort temp");
@@ -824,6 +898,136 @@ static uint32_t device_seeds(Slot* sl, const uint8_t* qcodes, uint32_t start, ui
     return (uint32_t)nseeds;
 }
 
+// ---- table-direct lookup (probe.hip) -----------------------------------------------------------------------------------
+static uint32_t seed_tmask() {
+    return g_transition ? (g_shape.transition_mask & ((1u << g_shape.weight) - 1u)) : 0u;
+}
+
+__global__ void widen_u32_kernel(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[i];
+}
+
+static void nbr_release(DevCtx* dc) {
+    dev_free(dc->nbr_start, "nbr_start");
+    if (!dc->nbr_alias) dev_free(dc->nbr_pos, "nbr_pos");
+    dc->nbr_start = nullptr;
+    dc->nbr_pos = nullptr;
+    dc->nbr_alias = false;
+    dc->nbr_total = 0;
+    dc->nbr_state = 0;
+}
+
+// Builds (once per table and transition mask) the neighbourhood table of the device; false when it is not available:
+// no table yet, a merged run longer than 2^32 entries, or not enough free HBM for (words per position) x pos_table.
+static bool ensure_nbr(DevCtx* dc) {
+    if (!g_td || !dc->bucket_start || !dc->pos_table) return false;
+    const uint32_t tmask = seed_tmask();
+    std::lock_guard<std::mutex> lk(dc->nbr_mu);
+    if (dc->nbr_state != 0 && dc->nbr_tmask == tmask) return dc->nbr_state == 1;
+    check_set_device(dc->dev, "neighbourhood table");
+    hipStream_t st = dc->admin;
+    nbr_release(dc);
+    dc->nbr_tmask = tmask;
+    dc->nbr_state = -1;
+    const uint32_t nkeys = dc->nkeys;
+    dc->nbr_start = (uint64_t*)dev_malloc(((size_t)nkeys + 1) * sizeof(uint64_t), "nbr_start");
+    if (tmask == 0) {  // one word per position: the runs ARE the buckets
+        hipLaunchKernelGGL(widen_u32_kernel, dim3(4096), dim3(256), 0, st, dc->bucket_start, dc->nbr_start, nkeys + 1);
+        check_launch("nbr widen");
+        check_sync(st, "nbr widen");
+        dc->nbr_pos = dc->pos_table;
+        dc->nbr_alias = true;
+        dc->nbr_total = dc->num_index;
+        dc->nbr_state = 1;
+        return true;
+    }
+    uint32_t* cnt = (uint32_t*)dev_malloc(((size_t)nkeys + 1) * sizeof(uint32_t), "nbr counts");
+    void* scan_tmp = dev_malloc(scan_temp_bytes(nkeys), "scan temp");
+    check_memcpy(hipMemsetAsync(cnt + nkeys, 0, sizeof(uint32_t), st), "nbr overflow flag");  // cnt[nkeys] doubles as the flag
+    launch_nbr_count(dc->bucket_start, nkeys, tmask, g_shape.weight, cnt, cnt + nkeys, st);
+    launch_exclusive_scan_u64(cnt, dc->nbr_start, nkeys, scan_tmp, st);
+    check_launch("nbr count/scan");
+    uint64_t total = 0;
+    uint32_t overflow = 0;
+    check_memcpy(hipMemcpyAsync(&total, dc->nbr_start + nkeys, sizeof(uint64_t), hipMemcpyDeviceToHost, st), "nbr total");
+    check_memcpy(hipMemcpyAsync(&overflow, cnt + nkeys, sizeof(uint32_t), hipMemcpyDeviceToHost, st), "nbr overflow");
+    check_sync(st, "nbr count");
+    dev_free(cnt, "nbr counts");
+    dev_free(scan_tmp, "scan temp");
+    size_t free_b = 0, total_b = 0;
+    hipMemGetInfo(&free_b, &total_b);
+    const size_t need = (size_t)std::max<uint64_t>(total, 1) * sizeof(uint32_t);
+    if (overflow || need + ((size_t)8 << 30) > free_b) {  // keep 8 GiB for the slots' work buffers
+        dev_free(dc->nbr_start, "nbr_start");
+        dc->nbr_start = nullptr;
+        return false;
+    }
+    dc->nbr_pos = (uint32_t*)dev_malloc(need, "nbr_pos");
+    launch_nbr_fill(dc->bucket_start, dc->pos_table, nkeys, tmask, g_shape.weight, dc->nbr_start, dc->nbr_pos, st);
+    check_launch("nbr fill");
+    check_sync(st, "nbr fill");
+    dc->nbr_total = total;
+    dc->nbr_state = 1;
+    return true;
+}
+
+// may this call take the table-direct path?  (the anchors are only ever read by the packed filter's TD fetch)
+static bool td_eligible(DevCtx* dc, const PackedBuf* query4) {
+    return g_td && g_packed_filter && !g_count_examined && query4 && query4->base && dc->ref2.base && ensure_nbr(dc);
+}
+
+// Position probe + chunk plans for query positions [bpos[0], bpos[K]) (chunk c = [bpos[c], bpos[c+1])); one D2H, one sync.
+// Returns the number of seed words the reference would have been handed (0: nothing to do), or UINT32_MAX when the call must
+// take the general path: a chunk with num_hits >= MAX_HITS (more than two reference iterations), hit counts that wrap the
+// reference's uint32 arithmetic, or more than 2^32 hits in the call (the filter indexes hits with 32 bits).
+static uint32_t td_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, int K, const uint32_t* bpos, int rm, uint32_t* words_out) {
+    hipStream_t st = sl->stream;
+    const uint32_t start = bpos[0], end = bpos[K];
+    const uint32_t tmask = seed_tmask();
+    const uint32_t words = 1u + (uint32_t)__builtin_popcount(tmask);
+    *words_out = words;
+    if (end <= start) return 0;
+    const uint32_t n = end - start;
+    SeedShape sh = g_shape;
+    sh.span = (int)g_seed_size;
+    sl->td_toff.ensure(n, "probe scratch");
+    sl->td_tcnt.ensure(n, "probe scratch");
+    sl->td_prefix.ensure((size_t)n + 1, "probe prefix");
+    sl->td_off.ensure(n, "probe runs");
+    sl->td_qpos.ensure(n, "probe positions");
+    sl->td_partial.ensure(probe_partial_bytes(n), "probe partials");
+    TdBounds tb;
+    tb.nb = K + 1;
+    for (int c = 0; c <= K; c++) tb.pos[c] = bpos[c];
+    {
+        ProfScope p(sl, "seed_probe");
+        launch_probe_lookup(qcodes, start, n, sh, dc->nbr_start, dc->nkeys, sl->td_toff.p, sl->td_tcnt.p, sl->td_partial.p, st);
+    }
+    {
+        ProfScope p(sl, "probe_compact");
+        launch_probe_compact(start, n, sl->td_toff.p, sl->td_tcnt.p, sl->td_partial.p, sl->d_td_bounds, sl->td_prefix.p, sl->td_off.p,
+                             sl->td_qpos.p, tb, st);
+    }
+    {
+        ProfScope p(sl, "iteration_plan");
+        launch_probe_plan(qcodes, sh, tmask, dc->bucket_start, sl->d_td_bounds, K, sl->td_prefix.p, sl->td_qpos.p, sl->d_td_plan, st);
+    }
+    check_launch("probe");
+    check_memcpy(hipMemcpyAsync(sl->h_td_plan, sl->d_td_plan, sizeof(TdPlan) * K, hipMemcpyDeviceToHost, st), "probe plan");
+    check_memcpy(hipMemsetAsync(sl->d_cnt, 0, sizeof(Counters), st), "counters");
+    check_sync(st, "probe plan");
+    uint64_t nvalid = 0;
+    for (int c = 0; c < K; c++) {
+        const TdPlan& tp = sl->h_td_plan[c];
+        nvalid += tp.num_valid;
+        if (tp.num_hits >= (uint64_t)(uint32_t)g_max_hits) return 0xFFFFFFFFu;
+        if (!rm && tp.num_hits > 0xFFFFFFFFull) return 0xFFFFFFFFu;
+    }
+    if (sl->h_td_plan[K - 1].hit_base + sl->h_td_plan[K - 1].num_hits > 0xFFFFFFFFull) return 0xFFFFFFFFu;
+    if (nvalid * words >= 0xFFFFFFFFull) return 0xFFFFFFFFu;
+    return (uint32_t)(nvalid * words);
+}
+
 static void require_init(const char* who) {
     if (g_ndev <= 0) {
         fprintf(stderr, "Error: %s called before InitializeInterface\n", who);
@@ -921,6 +1125,7 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
                            !getenv("SEGALIGN_AMD_NO_PACKED_FILTER")) ? 1 : 0;
         if (getenv("SEGALIGN_AMD_NO_FAST_FILTER")) { g_fast_filter = 0; g_packed_filter = 0; }
         g_chain = getenv("SEGALIGN_AMD_NO_CHAIN") ? 0 : 1;
+        g_td = getenv("SEGALIGN_AMD_NO_TD") ? 0 : 1;
         g_chain_sort_threads = 512;
         if (const char* e = getenv("SEGALIGN_AMD_CHAIN_SORT_THREADS")) g_chain_sort_threads = std::max(64, std::min(512, atoi(e) & ~63));
         if (const char* e = getenv("SEGALIGN_AMD_CHAIN_CAP")) CHAIN_CAP = (uint32_t)std::max(1, atoi(e));
@@ -958,6 +1163,7 @@ void sa_shutdown_processor(void) {  // src/seed_filter.cu:932-940
         dc->ref_rc.release("d_seq_rc");
         dc->ref4.release("d_seq 4-bit");
         dc->ref4_rc.release("d_seq_rc 4-bit");
+        nbr_release(dc);
         dev_free(dc->bucket_start, "d_index_table");
         dev_free(dc->pos_table, "d_pos_table");
         dc->bucket_start = dc->pos_table = nullptr;
@@ -1004,6 +1210,7 @@ void sa_clear_ref(void) {  // seed_filter_interface.cu:103-113
         dc->ref8.release("d_ref_seq rows");
         dc->ref2.release("d_ref_seq 2-bit");
         dc->ref_host_ptr = nullptr;
+        nbr_release(dc);
         dev_free(dc->bucket_start, "d_index_table");
         dev_free(dc->pos_table, "d_pos_table");
         dc->bucket_start = dc->pos_table = nullptr;
@@ -1065,6 +1272,7 @@ void sa_generate_seed_pos_table(const char* ref_str, size_t start_addr, uint32_t
             dev_free(tmp, "tmp table seq");
             codes = tmp_codes.codes;
         }
+        nbr_release(dc);
         dev_free(dc->bucket_start, "d_index_table");
         dev_free(dc->pos_table, "d_pos_table");
         uint32_t* hist = (uint32_t*)dev_malloc(((size_t)nkeys + 1) * sizeof(uint32_t), "kmer histogram");
@@ -1089,6 +1297,9 @@ void sa_generate_seed_pos_table(const char* ref_str, size_t start_addr, uint32_t
         tmp_codes.release("table codes");
         dc->num_index = num_index;
         dc->nkeys = nkeys;
+        // the neighbourhood table belongs to the table build when the processor parameters are already known (the reference
+        // calls InitializeProcessor first, src/main.cpp:298 before :621); otherwise the first table-direct call builds it
+        if (g_proc_init && g_packed_filter) ensure_nbr(dc);
     }
 }
 
@@ -1157,11 +1368,20 @@ size_t sa_seed_and_filter_range(uint32_t start, uint32_t end, int rev, uint32_t 
     // a seed window must lie inside the block: positions j with j + span <= len
     uint32_t lim = qlen >= g_seed_size ? qlen - g_seed_size + 1 : 0;
     if (end > lim) end = lim;
-    uint32_t ns = device_seeds(sl, q, start, end);
+    const PackedBuf* q4 = rev ? &dc->query4_rc[buffer] : &dc->query4[buffer];
+    uint32_t ns = 0xFFFFFFFFu, words = 0;
+    if (td_eligible(dc, q4)) {
+        const uint32_t bp[2] = {start, std::max(start, end)};
+        ns = td_front(dc, sl, q, 1, bp, 0, &words);
+    }
+    const bool td = ns != 0xFFFFFFFFu;
+    if (!td) ns = device_seeds(sl, q, start, end);
     size_t n = 0;
     *out = nullptr;
     if (ns > 0) {  // seeder.cpp:76: the engine is only called for a non-empty seed vector
-        CoreArgs ca = {q, qlen, 0, 0, 0, 0, start, end, nullptr, 0, rev ? &dc->query4_rc[buffer] : &dc->query4[buffer]};
+        CoreArgs ca = {q, qlen, 0, 0, 0, 0, start, end, nullptr, 0, q4};
+        ca.td = td ? 1 : 0;
+        ca.td_words = words;
         n = saf_core(dc, sl, ns, ca, out);
     } else {
         prof_flush(sl);
@@ -1198,12 +1418,18 @@ size_t sa_seed_and_filter_chunks(uint32_t start, uint32_t end, int rev, uint32_t
     const uint32_t send = std::min(end, lim);  // a seed window must lie inside the block
     uint32_t bpos[SA_MAX_CHUNKS + 1], bseed[SA_MAX_CHUNKS + 1];
     for (int c = 0; c <= K; c++) bpos[c] = (uint32_t)std::min<uint64_t>((uint64_t)start + (uint64_t)c * chunk, send);
-    const uint32_t ns = device_seeds(sl, q, start, send, K + 1, bpos, bseed);
+    const PackedBuf* q4 = rev ? &dc->query4_rc[buffer] : &dc->query4[buffer];
+    uint32_t ns = 0xFFFFFFFFu, words = 0;
+    if (td_eligible(dc, q4)) ns = td_front(dc, sl, q, K, bpos, 0, &words);
+    const bool td = ns != 0xFFFFFFFFu;
+    if (!td) ns = device_seeds(sl, q, start, send, K + 1, bpos, bseed);
     size_t total = 0;
     if (ns > 0) {
-        CoreArgs ca = {q, qlen, 0, 0, 0, 0, start, send, nullptr, 0, rev ? &dc->query4_rc[buffer] : &dc->query4[buffer]};
+        CoreArgs ca = {q, qlen, 0, 0, 0, 0, start, send, nullptr, 0, q4};
         ca.nchunks = K;
-        for (int c = 0; c <= K; c++) ca.seed_bound[c] = bseed[c];
+        ca.td = td ? 1 : 0;
+        ca.td_words = words;
+        for (int c = 0; c <= K; c++) ca.seed_bound[c] = td ? 0u : bseed[c];  // (a table-direct call derives them from its chunk plans)
         ca.outs = outs;
         ca.counts = counts;
         saf_core(dc, sl, ns, ca, nullptr);
@@ -1217,6 +1443,34 @@ size_t sa_seed_and_filter_chunks(uint32_t start, uint32_t end, int rev, uint32_t
 }
 
 void sa_free_segments(sa_segment_pair* p) { free(p); }
+
+// Introspection (tests): the extension stage alone -- find_hsps + compaction of the passing hits (src/seed_filter.cu:232-680)
+// -- for caller-supplied anchors {ref_loc, query_loc} on the resident target / query strand.  Returns 1 + the number of
+// passing hits; out[0] is a header {len = count}, the records follow in no particular order and are NOT de-duplicated,
+// except that exact duplicates may already be merged (the chain shortcut extends one member of a run of anchors that
+// provably produce the identical record).
+size_t sa_extend_hits(const uint32_t* ref_query_pairs, size_t num_hits, int rev, uint32_t buffer, sa_segment_pair** out) {
+    require_init("ExtendHits");
+    if (buffer >= SA_BUFFER_DEPTH) {
+        fprintf(stderr, "Error: query buffer %u out of range\n", buffer);
+        exit(1);
+    }
+    Slot* sl = acquire_slot();
+    DevCtx* dc = g_dev[0];
+    for (auto* d : g_dev) if (d->dev == sl->dev) dc = d;
+    size_t n = 0;
+    *out = nullptr;
+    if (num_hits > 0) {
+        sl->hits.ensure(num_hits, "hits");
+        check_memcpy(hipMemcpyAsync(sl->hits.p, ref_query_pairs, num_hits * sizeof(Hit), hipMemcpyHostToDevice, sl->stream), "hits");
+        CoreArgs ca = {rev ? dc->query_rc[buffer].codes : dc->query[buffer].codes, g_query_len[buffer], 0, 0, 0, 0, 0, 0, nullptr, 0,
+                       rev ? &dc->query4_rc[buffer] : &dc->query4[buffer]};
+        ca.raw_hits = num_hits;
+        n = saf_core(dc, sl, 1, ca, out);
+    }
+    release_slot(sl);
+    return n;
+}
 
 // seeder_body::operator() of src/seeder.cpp:12-127 for one query interval: plus-strand chunks [start, end) in steps of
 // wga_chunk, then the minus-strand chunks of the same interval in reverse-complement coordinates (:33-34,89-91), every
@@ -1467,9 +1721,18 @@ size_t sa_rm_mask_interval(uint32_t start_pos, uint32_t end_pos, uint32_t ref_st
             }
             if (s1 > lim) s1 = lim;
             const uint8_t* q = rev ? dc->ref_rc.codes : dc->ref.codes;
-            const uint32_t ns = device_seeds(sl, q, s0, s1);
+            const PackedBuf* q4 = rev ? &dc->ref4_rc : &dc->ref4;
+            uint32_t ns = 0xFFFFFFFFu, words = 0;
+            if (td_eligible(dc, q4)) {
+                const uint32_t bp[2] = {s0, std::max(s0, s1)};
+                ns = td_front(dc, sl, q, 1, bp, 1, &words);
+            }
+            const bool td = ns != 0xFFFFFFFFu;
+            if (!td) ns = device_seeds(sl, q, s0, s1);
             if (ns == 0) continue;  // :103,140
-            CoreArgs ca = {q, block_len, 1, rev, ref_start, ref_end, s0, s1, sl->cov_diff.p, block_len + 1, rev ? &dc->ref4_rc : &dc->ref4};
+            CoreArgs ca = {q, block_len, 1, rev, ref_start, ref_end, s0, s1, sl->cov_diff.p, block_len + 1, q4};
+            ca.td = td ? 1 : 0;
+            ca.td_words = words;
             saf_core(dc, sl, ns, ca, nullptr);
             tot_seeds += ns;
             tot_hits += t_stats.num_hits;

@@ -439,6 +439,11 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 constexpr int PK_THREADS = 512;
 constexpr int PK_TAB = 4096;
 
+// TD = true: the anchors are not read from a hit list but straight out of the neighbourhood table (probe.hip): every wave
+// owns a CONTIGUOUS range of the call's hit indices, keeps the compacted position m0 that holds the first hit of its next
+// 64-hit buffer, loads the 64 following position prefixes with one coalesced load, finds every lane's position with six
+// shuffles and gathers the run entry.  No hit list is written or read (16*S + 4*H instead of 16*S + 12*H).
+template <bool TD>
 __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(ExtendArgs a) {
     __shared__ uint32_t s_pk[PK_TAB];
     __shared__ CandRec s_cand[PK_THREADS / 64][STAGE_CAP];
@@ -470,20 +475,69 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
     const int fin_batch = a.fin_batch;
     const uint32_t long_cap = a.long_cap;
 
-    // ---- the wave's queue: 64-hit buffers, round-robin over all waves of the grid ----
+    // ---- the wave's queue of 64-hit buffers: round-robin over all waves of the grid (hit list), or one contiguous range
+    //      per wave (TD) ----
     const uint64_t num_buf = (a.num_hits + 63) >> 6;
-    const uint64_t G = (uint64_t)gridDim.x * (PK_THREADS / 64);
-    uint64_t cur_buf = (uint64_t)blockIdx.x * (PK_THREADS / 64) + (threadIdx.x >> 6);
+    const uint64_t W = (uint64_t)gridDim.x * (PK_THREADS / 64);
+    const uint64_t wid = (uint64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (PK_THREADS / 64) + (threadIdx.x >> 6)));
+    const uint64_t G = TD ? 1ull : W;
+    const uint64_t buf_end = TD ? ((wid + 1) * num_buf) / W : num_buf;
+    uint64_t cur_buf = TD ? (wid * num_buf) / W : wid;
     uint64_t nxt_buf = cur_buf + G;
     auto buf_count = [&](uint64_t b) -> int {
-        if (b >= num_buf) return 0;
+        if (b >= buf_end) return 0;
         uint64_t rem = a.num_hits - (b << 6);
         return rem >= 64 ? 64 : (int)rem;
     };
+    uint32_t td_m0 = 0;  // TD: td_prefix[td_m0] <= 64 * (next buffer to fetch) < td_prefix[td_m0 + 1]
+    if (TD && cur_buf < buf_end) {
+        const uint64_t g0 = cur_buf << 6;
+        uint32_t lo = 0, hi = a.td_m;  // td_prefix[0] = 0 <= g0 < td_prefix[td_m] = num_hits
+        while (lo + 1 < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (a.td_prefix[mid] <= g0) lo = mid; else hi = mid;
+        }
+        td_m0 = lo;
+    }
+    auto fetch = [&](uint64_t b, int cnt) -> Hit {
+        Hit h = {0u, 0u};
+        if (!TD) {
+            if (lane < cnt) h = a.hits[(b << 6) + lane];
+            return h;
+        }
+        if (cnt == 0) return h;  // wave-uniform
+        const uint64_t g0 = b << 6;
+        const uint32_t mi = td_m0 + (uint32_t)lane;
+        const uint64_t pv = a.td_prefix[mi < a.td_m ? mi : a.td_m];
+        const uint64_t d = pv - g0;  // lanes >= 1: > 0 (invariant); lane 0: <= 0, handled below
+        const uint32_t R = lane == 0 ? 0u : (mi > a.td_m ? 0xFFFFFFFFu : (d > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)d));
+        const uint64_t pv0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pv >> 32)) << 32) |
+                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pv);
+        const uint32_t d0 = (uint32_t)(g0 - pv0);  // hits of position td_m0 that belong to earlier buffers
+        uint32_t lo = 0, rv = 0;                   // largest window entry whose first hit is <= this lane's hit
+#pragma unroll
+        for (uint32_t step = 32; step >= 1; step >>= 1) {
+            const uint32_t cand = lo + step;
+            const uint32_t v = (uint32_t)__shfl((int)R, (int)(cand & 63u), 64);
+            if (cand < 64u && v <= (uint32_t)lane) { lo = cand; rv = v; }
+        }
+        if (lane < cnt) {
+            const uint32_t k = lo == 0u ? d0 + (uint32_t)lane : (uint32_t)lane - rv;
+            const uint32_t m = td_m0 + lo;
+            h.ref_loc = a.td_pos[a.td_off[m] + k] + a.seed_size;  // :220
+            h.query_loc = a.td_qpos[m] + a.seed_size;             // :204
+        }
+        // advance to the position that holds hit g0 + 64: entries 1..63 by their lanes, entry 64 by lane 0
+        uint64_t p64 = 0;
+        const bool has64 = td_m0 + 64u <= a.td_m;
+        if (lane == 0 && has64) p64 = a.td_prefix[td_m0 + 64u];
+        const bool adv = lane == 0 ? (has64 && p64 - g0 <= 64ull) : (R <= 64u);
+        td_m0 += (uint32_t)__popcll(__ballot(adv));
+        return h;
+    };
     int buf_cnt = buf_count(cur_buf), nxt_cnt = buf_count(nxt_buf), consumed = 0;
-    Hit buf = {0u, 0u}, nxt = {0u, 0u};
-    if (lane < buf_cnt) buf = a.hits[(cur_buf << 6) + lane];
-    if (lane < nxt_cnt) nxt = a.hits[(nxt_buf << 6) + lane];
+    Hit buf = fetch(cur_buf, buf_cnt);
+    Hit nxt = fetch(nxt_buf, nxt_cnt);
 
     // ---- per-lane state ----
     int phase = PH_FIN;
@@ -614,7 +668,7 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
                     consumed = 0;
                     nxt_buf += G;
                     nxt_cnt = buf_count(nxt_buf);
-                    if (lane < nxt_cnt) nxt = a.hits[(nxt_buf << 6) + lane];
+                    nxt = fetch(nxt_buf, nxt_cnt);
                     continue;
                 }
                 const int rank = __popcll(need & lane_lt);
@@ -1074,7 +1128,8 @@ void launch_extend_filter(const ExtendArgs& a, hipStream_t s) {
     const uint32_t blocks = (uint32_t)((waves + 3) / 4);
     if (!a.examined && a.fast_filter == 3) {
         const uint32_t pblocks = (uint32_t)((waves + PK_THREADS / 64 - 1) / (PK_THREADS / 64));
-        hipLaunchKernelGGL(extend_filter_packed_kernel, dim3(pblocks), dim3(PK_THREADS), 0, s, a);
+        if (a.td) hipLaunchKernelGGL(extend_filter_packed_kernel<true>, dim3(pblocks), dim3(PK_THREADS), 0, s, a);
+        else hipLaunchKernelGGL(extend_filter_packed_kernel<false>, dim3(pblocks), dim3(PK_THREADS), 0, s, a);
         return;
     }
     if (a.examined) hipLaunchKernelGGL((extend_filter_kernel<true, false>), dim3(blocks), dim3(EXT_THREADS), 0, s, a);

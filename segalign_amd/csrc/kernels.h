@@ -85,6 +85,15 @@ struct ExtendArgs {
     uint32_t max_waves;       // wave budget of the main kernel (resident waves of the chip)
     uint32_t long_blocks, ent_blocks;  // grid sizes of the long / entropy kernels (they read their counts on device)
     const Hit* hits;
+    // TD ("table direct", probe.hip): no hit list -- hit g of the call is entry g - td_prefix[m] of the run of the m-th
+    // non-empty query position; the packed filter reads its anchors straight out of the neighbourhood table
+    int td;
+    const uint64_t* td_prefix;  // [td_m + 1] call-wide index of each non-empty position's first hit; td_prefix[td_m] = num_hits
+    const uint64_t* td_off;     // [td_m] offset of the position's run in td_pos
+    const uint32_t* td_qpos;    // [td_m] query position (seed start)
+    uint32_t td_m;
+    const uint32_t* td_pos;     // neighbourhood table runs: seed START positions in the target (+ seed_size = anchor, :220)
+    uint32_t seed_size;
     uint64_t num_hits;
     uint64_t hit_base;        // global index of hits[0] inside the call (segment boundaries are global)
     int num_segs;

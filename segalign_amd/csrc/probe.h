@@ -1,0 +1,42 @@
+// probe.h -- launcher declarations of probe.hip (neighbourhood table + position probe; see the file header there).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace sa {
+
+constexpr int TD_MAX_BOUNDS = 8;  // chunk boundaries of one call: SA_MAX_CHUNKS + 1 <= 8
+
+struct TdBounds {                 // query positions of the chunk boundaries of a call, ascending; pos[0] = start, pos[nb-1] = end
+    int nb;
+    uint32_t pos[TD_MAX_BOUNDS];
+};
+
+struct TdPlan {                   // per chunk, written by probe_plan_kernel
+    uint64_t hit_base;            // offset of the chunk's first hit inside the call
+    uint64_t num_hits;            // src/seed_filter.cu:716
+    uint64_t split;               // call-wide hit offset where the reference's last iteration starts (:732-741, num_hits < MAX_HITS)
+    uint32_t num_valid;           // valid seed positions (seed words = num_valid * words per position)
+    uint32_t m_lo, m_hi;          // the chunk's range of compacted (non-empty) positions
+    uint32_t pad;
+};
+
+// neighbourhood table build
+void launch_nbr_count(const uint32_t* bucket_start, uint32_t nkeys, uint32_t tmask, int weight, uint32_t* cnt, uint32_t* overflow,
+                      hipStream_t s);
+void launch_nbr_fill(const uint32_t* bucket_start, const uint32_t* pos_table, uint32_t nkeys, uint32_t tmask, int weight,
+                     const uint64_t* nbr_start, uint32_t* nbr_pos, hipStream_t s);
+
+// position probe of n = end - start query positions; t_off/t_cnt: n entries of scratch; c_prefix: n + 1, c_off / c_qpos: n
+size_t probe_partial_bytes(uint32_t n);
+size_t probe_bounds_bytes();
+void launch_probe_lookup(const uint8_t* query, uint32_t start, uint32_t n, SeedShape sh, const uint64_t* nbr_start, uint32_t nkeys,
+                         uint64_t* t_off, uint32_t* t_cnt, void* partial_buf, hipStream_t s);
+void launch_probe_compact(uint32_t start, uint32_t n, const uint64_t* t_off, const uint32_t* t_cnt, void* partial_buf, void* bounds_buf,
+                          uint64_t* c_prefix, uint64_t* c_off, uint32_t* c_qpos, const TdBounds& bpos, hipStream_t s);
+void launch_probe_plan(const uint8_t* query, SeedShape sh, uint32_t tmask, const uint32_t* bucket_start, const void* bounds_buf, int nchunks,
+                       const uint64_t* c_prefix, const uint32_t* c_qpos, TdPlan* plan, hipStream_t s);
+
+}  // namespace sa

@@ -1,0 +1,273 @@
+// probe.hip -- the NEIGHBOURHOOD seed table and the position probe: seed lookup without seed words.
+//
+// Reference shape (src/seeder.cpp:57-74 + src/seed_filter.cu:157-230): the host emits, per valid query position, 13 seed
+// words (the k-mer and its 12 single-transition neighbours, key ^ (2 << 2t)); find_num_hits gathers one bucket extent per
+// WORD from the 4^k-entry index table, a scan turns the counts into offsets, find_hits copies every bucket into a hit list.
+// On a 100 Mbp target every one of those 13 gathers touches its own 128-byte line of the index table and its own line of
+// the position table to use ~8 + ~20 bytes: the lookup moves ~8x its algorithmic bytes (profiles/r01).
+//
+// MI355X shape: 288 GB of HBM buy a table in which the 13 buckets a query position needs are ONE contiguous run.
+//   nbr_start[key] .. nbr_start[key+1]  =  bucket(key) ++ bucket(key ^ (2<<2t0)) ++ bucket(key ^ (2<<2t1)) ++ ...
+// in exactly the order src/seeder.cpp:60-69 emits the seed words, so the concatenation of the runs of consecutive query
+// positions IS the reference's hit list order (up to the order inside a bucket, which no consumer depends on, SURVEY a-6).
+// One probe per query POSITION (one 16-byte extent, one contiguous run) replaces 13 probes per position; seed words,
+// per-word extents and per-word prefix sums are never materialised, and the X-drop filter reads its anchors straight
+// out of the runs (extend.hip, TD fetch), so there is no hit list either.  Table size = (1 + #transition positions) x
+// pos_table (4.2 GB for a 100 Mbp block, ~26 GB for a 500 Mbp block) + 8 bytes per key.
+//
+// Per call (positions [start, end) of one strand, up to SA_MAX_CHUNKS chunks):
+//   probe_kernel    position -> k-mer (kmer_dev.h) -> {run offset, run length}; per-block sums of (hits, non-empty, valid)
+//   probe_partials  exclusive scan of the block sums (one workgroup)
+//   probe_compact   order-preserving compaction of the NON-EMPTY positions: c_prefix (hit offset of the position's first
+//                   hit inside the call), c_off (run offset), c_qpos; prefix values at the chunk boundaries
+//   probe_plan      per chunk: number of hits, and the reference's iteration split (src/seed_filter.cu:718-745 for
+//                   num_hits < MAX_HITS: everything before the LAST HIT-BEARING SEED WORD / that word's hits) -- found from
+//                   the last non-empty position and the plain bucket sizes of its 13 words
+#include "kernels.h"
+#include "kmer_dev.h"
+#include "probe.h"
+
+namespace sa {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// neighbourhood table build (once per target block, from the plain table of table.hip)
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t bucket_len(const uint32_t* __restrict__ bucket_start, uint32_t key) {
+    return bucket_start[key + 1] - bucket_start[key];
+}
+
+// merged run length per key; *overflow is set if a run does not fit 32 bits (the probe keeps run lengths in u32)
+__global__ __launch_bounds__(256) void nbr_count_kernel(const uint32_t* __restrict__ bucket_start, uint32_t nkeys, uint32_t tmask,
+                                                        int weight, uint32_t* __restrict__ cnt, uint32_t* __restrict__ overflow) {
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nkeys; k += gridDim.x * blockDim.x) {
+        uint64_t c = bucket_len(bucket_start, k);
+        for (int t = 0; t < weight; t++)
+            if ((tmask >> t) & 1u) c += bucket_len(bucket_start, k ^ (2u << (2 * t)));
+        if (c > 0xFFFFFFFFull) { atomicOr(overflow, 1u); c = 0xFFFFFFFFull; }
+        cnt[k] = (uint32_t)c;
+    }
+}
+
+// One 16-lane group per key copies the key's 1 + popcount(tmask) buckets into its run, sub-run after sub-run (seed word
+// order).  Buckets are short (T / 4^k entries), so a group streams a ~250-byte run while its 16 lanes share the loads.
+constexpr int NBR_GROUP = 16;
+__global__ __launch_bounds__(256) void nbr_fill_kernel(const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ pos_table,
+                                                       uint32_t nkeys, uint32_t tmask, int weight,
+                                                       const uint64_t* __restrict__ nbr_start, uint32_t* __restrict__ nbr_pos) {
+    const uint32_t gl = threadIdx.x & (NBR_GROUP - 1);
+    const uint32_t groups = gridDim.x * (blockDim.x / NBR_GROUP);
+    for (uint32_t k = blockIdx.x * (blockDim.x / NBR_GROUP) + threadIdx.x / NBR_GROUP; k < nkeys; k += groups) {
+        uint64_t o = nbr_start[k];
+        for (int j = -1; j < weight; j++) {
+            if (j >= 0 && !((tmask >> j) & 1u)) continue;
+            const uint32_t kk = j < 0 ? k : (k ^ (2u << (2 * j)));
+            const uint32_t b = bucket_start[kk], n = bucket_start[kk + 1] - b;
+            for (uint32_t i = gl; i < n; i += NBR_GROUP) nbr_pos[o + i] = pos_table[b + i];
+            o += n;
+        }
+    }
+}
+
+void launch_nbr_count(const uint32_t* bucket_start, uint32_t nkeys, uint32_t tmask, int weight, uint32_t* cnt, uint32_t* overflow,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(nbr_count_kernel, dim3(4096), dim3(256), 0, s, bucket_start, nkeys, tmask, weight, cnt, overflow);
+}
+void launch_nbr_fill(const uint32_t* bucket_start, const uint32_t* pos_table, uint32_t nkeys, uint32_t tmask, int weight,
+                     const uint64_t* nbr_start, uint32_t* nbr_pos, hipStream_t s) {
+    hipLaunchKernelGGL(nbr_fill_kernel, dim3(8192), dim3(256), 0, s, bucket_start, pos_table, nkeys, tmask, weight, nbr_start, nbr_pos);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// probe: positions -> runs
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int PR_THREADS = 256;
+constexpr int PR_ITEMS = 4;                       // consecutive positions per thread
+constexpr int PR_TILE = PR_THREADS * PR_ITEMS;    // positions per workgroup
+
+struct Tri { uint64_t hits; uint32_t ne, valid; };  // (hits, non-empty positions, valid positions)
+
+__device__ __forceinline__ Tri tri_add(Tri a, Tri b) { return {a.hits + b.hits, a.ne + b.ne, a.valid + b.valid}; }
+
+__device__ __forceinline__ Tri wave_incl_scan(Tri v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint64_t h = __shfl_up(v.hits, off, 64);
+        const uint32_t a = __shfl_up(v.ne, off, 64), b = __shfl_up(v.valid, off, 64);
+        if (lane >= off) { v.hits += h; v.ne += a; v.valid += b; }
+    }
+    return v;
+}
+// exclusive prefix over the workgroup + workgroup total
+__device__ __forceinline__ Tri block_excl_scan(Tri v, Tri& total) {
+    __shared__ Tri s_wave[PR_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const Tri inc = wave_incl_scan(v);
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    Tri base = {0, 0, 0}, tot = {0, 0, 0};
+#pragma unroll
+    for (int w = 0; w < PR_THREADS / 64; w++) {
+        const Tri s = s_wave[w];
+        if (w < wave) base = tri_add(base, s);
+        tot = tri_add(tot, s);
+    }
+    __syncthreads();
+    total = tot;
+    return {base.hits + inc.hits - v.hits, base.ne + inc.ne - v.ne, base.valid + inc.valid - v.valid};
+}
+
+constexpr uint64_t PR_VALID = 1ull << 63;  // flag inside t_off: the window at this position is a valid k-mer
+
+__global__ __launch_bounds__(PR_THREADS) void probe_kernel(const uint8_t* __restrict__ query, uint32_t start, uint32_t n, SeedShape sh,
+                                                           const uint64_t* __restrict__ nbr_start, uint32_t nkeys,
+                                                           uint64_t* __restrict__ t_off, uint32_t* __restrict__ t_cnt,
+                                                           Tri* __restrict__ partial) {
+    const uint32_t i0 = blockIdx.x * PR_TILE + threadIdx.x * PR_ITEMS;
+    Tri mine = {0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < PR_ITEMS; j++) {
+        const uint32_t i = i0 + j;
+        if (i >= n) break;
+        uint32_t key;
+        uint64_t off = 0;
+        uint32_t cnt = 0;
+        if (kmer_at(query, start + i, sh, key) && key < nkeys) {
+            const uint64_t b = nbr_start[key], e = nbr_start[key + 1];  // adjacent: one 16-byte extent per POSITION
+            off = b | PR_VALID;
+            cnt = (uint32_t)(e - b);
+            mine.valid++;
+            mine.ne += cnt ? 1u : 0u;
+            mine.hits += cnt;
+        }
+        t_off[i] = off;
+        t_cnt[i] = cnt;
+    }
+    Tri total;
+    block_excl_scan(mine, total);
+    if (threadIdx.x == 0) partial[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(PR_THREADS) void probe_partials_kernel(Tri* __restrict__ partial, uint32_t nblocks, Tri* __restrict__ total_out) {
+    Tri carry = {0, 0, 0};
+    for (uint32_t base = 0; base < nblocks; base += PR_THREADS) {
+        const uint32_t i = base + threadIdx.x;
+        const Tri v = i < nblocks ? partial[i] : Tri{0, 0, 0};
+        Tri total;
+        const Tri ex = block_excl_scan(v, total);
+        if (i < nblocks) partial[i] = tri_add(carry, ex);
+        carry = tri_add(carry, total);
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+
+// bounds[c] = exclusive prefix (hits, non-empty, valid) at position bpos[c] - start, c = 0..nb-1 (a bound == n takes the total)
+__global__ __launch_bounds__(PR_THREADS) void probe_compact_kernel(uint32_t start, uint32_t n, const uint64_t* __restrict__ t_off,
+                                                                   const uint32_t* __restrict__ t_cnt, const Tri* __restrict__ partial,
+                                                                   const Tri* __restrict__ total, uint64_t* __restrict__ c_prefix,
+                                                                   uint64_t* __restrict__ c_off, uint32_t* __restrict__ c_qpos,
+                                                                   TdBounds bpos, Tri* __restrict__ bounds) {
+    const uint32_t i0 = blockIdx.x * PR_TILE + threadIdx.x * PR_ITEMS;
+    uint64_t off[PR_ITEMS];
+    uint32_t cnt[PR_ITEMS];
+    Tri mine = {0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < PR_ITEMS; j++) {
+        const uint32_t i = i0 + j;
+        off[j] = 0;
+        cnt[j] = 0;
+        if (i < n) {
+            off[j] = t_off[i];
+            cnt[j] = t_cnt[i];
+            mine.valid += (off[j] & PR_VALID) ? 1u : 0u;
+            mine.ne += cnt[j] ? 1u : 0u;
+            mine.hits += cnt[j];
+        }
+    }
+    Tri tot;
+    Tri run = tri_add(block_excl_scan(mine, tot), partial[blockIdx.x]);
+#pragma unroll
+    for (int j = 0; j < PR_ITEMS; j++) {
+        const uint32_t i = i0 + j;
+        if (i >= n) break;
+#pragma unroll
+        for (int c = 0; c < TD_MAX_BOUNDS; c++)
+            if (c < bpos.nb && bpos.pos[c] - start == i) bounds[c] = run;
+        if (cnt[j]) {
+            c_prefix[run.ne] = run.hits;
+            c_off[run.ne] = off[j] & ~PR_VALID;
+            c_qpos[run.ne] = start + i;
+        }
+        run.hits += cnt[j];
+        run.ne += cnt[j] ? 1u : 0u;
+        run.valid += (off[j] & PR_VALID) ? 1u : 0u;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const Tri t = *total;
+        c_prefix[t.ne] = t.hits;  // sentinel: one past the last non-empty position
+        for (int c = 0; c < bpos.nb; c++)
+            if (bpos.pos[c] - start >= n) bounds[c] = t;
+    }
+}
+
+// one lane per chunk
+__global__ void probe_plan_kernel(const uint8_t* __restrict__ query, SeedShape sh, uint32_t tmask, const uint32_t* __restrict__ bucket_start,
+                                  const Tri* __restrict__ bounds, int nchunks, const uint64_t* __restrict__ c_prefix,
+                                  const uint32_t* __restrict__ c_qpos, TdPlan* __restrict__ plan) {
+    const int c = threadIdx.x;
+    if (c >= nchunks) return;
+    const Tri lo = bounds[c], hi = bounds[c + 1];
+    TdPlan p;
+    p.hit_base = lo.hits;
+    p.num_hits = hi.hits - lo.hits;
+    p.num_valid = hi.valid - lo.valid;
+    p.m_lo = lo.ne;
+    p.m_hi = hi.ne;
+    p.split = lo.hits;
+    if (p.num_hits > 0) {
+        // the last hit-bearing seed word of the chunk (:732-739 with limit = num_hits) lives in the last non-empty position:
+        // walk that position's words in emission order (seeder.cpp:60-69) over the PLAIN buckets
+        const uint32_t m = hi.ne - 1;
+        uint32_t key = 0;
+        kmer_at(query, c_qpos[m], sh, key);
+        uint64_t before = 0, before_last = 0;
+        uint32_t n0 = bucket_len(bucket_start, key);
+        if (n0) before_last = 0;
+        before = n0;
+        for (int t = 0; t < sh.weight; t++)
+            if ((tmask >> t) & 1u) {
+                const uint32_t nt = bucket_len(bucket_start, key ^ (2u << (2 * t)));
+                if (nt) before_last = before;
+                before += nt;
+            }
+        p.split = c_prefix[m] + before_last;  // iteration 0 = hits [hit_base, split), iteration 1 = [split, hit_base + num_hits)
+    }
+    plan[c] = p;
+}
+
+size_t probe_partial_bytes(uint32_t n) { return ((size_t)(n + PR_TILE - 1) / PR_TILE + 2) * sizeof(Tri); }
+size_t probe_bounds_bytes() { return (size_t)TD_MAX_BOUNDS * sizeof(Tri); }
+
+static inline uint32_t probe_blocks(uint32_t n) { return (n + PR_TILE - 1) / PR_TILE; }
+
+void launch_probe_lookup(const uint8_t* query, uint32_t start, uint32_t n, SeedShape sh, const uint64_t* nbr_start, uint32_t nkeys,
+                         uint64_t* t_off, uint32_t* t_cnt, void* partial_buf, hipStream_t s) {
+    hipLaunchKernelGGL(probe_kernel, dim3(probe_blocks(n)), dim3(PR_THREADS), 0, s, query, start, n, sh, nbr_start, nkeys, t_off, t_cnt,
+                       reinterpret_cast<Tri*>(partial_buf));
+}
+void launch_probe_compact(uint32_t start, uint32_t n, const uint64_t* t_off, const uint32_t* t_cnt, void* partial_buf, void* bounds_buf,
+                          uint64_t* c_prefix, uint64_t* c_off, uint32_t* c_qpos, const TdBounds& bpos, hipStream_t s) {
+    Tri* partial = reinterpret_cast<Tri*>(partial_buf);
+    const uint32_t nblocks = probe_blocks(n);
+    Tri* total = partial + nblocks;
+    hipLaunchKernelGGL(probe_partials_kernel, dim3(1), dim3(PR_THREADS), 0, s, partial, nblocks, total);
+    hipLaunchKernelGGL(probe_compact_kernel, dim3(nblocks), dim3(PR_THREADS), 0, s, start, n, t_off, t_cnt, partial, total, c_prefix, c_off,
+                       c_qpos, bpos, reinterpret_cast<Tri*>(bounds_buf));
+}
+void launch_probe_plan(const uint8_t* query, SeedShape sh, uint32_t tmask, const uint32_t* bucket_start, const void* bounds_buf, int nchunks,
+                       const uint64_t* c_prefix, const uint32_t* c_qpos, TdPlan* plan, hipStream_t s) {
+    hipLaunchKernelGGL(probe_plan_kernel, dim3(1), dim3(64), 0, s, query, sh, tmask, bucket_start, reinterpret_cast<const Tri*>(bounds_buf),
+                       nchunks, c_prefix, c_qpos, plan);
+}
+
+}  // namespace sa

@@ -35,7 +35,7 @@ C_ABI_SYMBOLS = [
     "sa_get_num_index", "sa_get_index_table_size", "sa_copy_ref_codes", "sa_copy_index_table", "sa_copy_pos_table",
     "sa_copy_query_codes", "sa_get_query_len", "sa_device_make_seeds", "sa_version",
     "sa_rm_mask_interval", "sa_rm_coverage_intervals", "sa_free_intervals", "sa_get_filter_mode",
-    "sa_seed_interval", "sa_seed_and_filter_chunks", "sa_max_chunks_per_call",
+    "sa_seed_interval", "sa_seed_and_filter_chunks", "sa_max_chunks_per_call", "sa_extend_hits",
 ]
 IVL_DTYPE = np.dtype([("query_start", "<u4"), ("len", "<u4")])  # struct Segment, repeat_masker_src/graph.h:32-35
 STRAND_PLUS, STRAND_MINUS, STRAND_BOTH = 1, 2, 3
@@ -109,6 +109,8 @@ def lib():
     L.sa_copy_query_codes.argtypes = [C.c_int, C.c_uint32, C.c_int, C.c_void_p]
     L.sa_device_make_seeds.restype = C.c_size_t
     L.sa_device_make_seeds.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t]
+    L.sa_extend_hits.restype = C.c_size_t
+    L.sa_extend_hits.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]
     L.sa_version.restype = C.c_char_p
     _lib = L
     return L
@@ -207,6 +209,14 @@ def SeedAndFilterChunks(start, end, rev, buffer):
     for c in range(k):
         res.append(_take(counts[c], C.c_void_p(outs[c])) if outs[c] else np.zeros(0, dtype=SEG_DTYPE))
     return res
+
+
+def ExtendHits(hits, rev, buffer):
+    """Extension stage alone for anchors [(ref_loc, query_loc), ...]: passing records, unordered (header removed)."""
+    h = np.ascontiguousarray(hits, dtype=np.uint32).reshape(-1, 2)
+    out = C.c_void_p()
+    n = lib().sa_extend_hits(h.ctypes.data, h.shape[0], int(bool(rev)), buffer, C.byref(out))
+    return _take(n, out)[1:]
 
 
 def SeedInterval(start, end, q_len, strands=STRAND_BOTH, buffer=0, threads=2):

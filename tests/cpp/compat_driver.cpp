@@ -4,7 +4,13 @@
 // It is test code: tests/test_gpu_compat.py compiles it with g++, runs it on the GPU box and compares every HSP with
 // the oracle.  Host threads call g_SeedAndFilter concurrently like the TBB seeder bodies do.
 //
-// usage: compat_driver <target.txt> <query.txt> <shape> <chunk> <transition 0|1> <threads>
+// Built twice (tests/test_compat_header.py): plain = the src/ binary's symbols; with -DCOMPAT_DRIVER_RM = the repeat
+// masker's symbols of the same names (repeat_masker_src/seed_filter.h:4-14): g_SendQueryWriteRequest(),
+// g_SeedAndFilter(seeds, rev, ref_start, ref_end), g_ClearQuery(), driven like repeat_masker_src/seeder.cpp:73-146 (the query
+// IS the target; the minus-strand chunk is derived from the plus-strand chunk end, :118-119); <query.txt> is then ignored
+// and the two extra arguments are the target window.
+//
+// usage: compat_driver <target.txt> <query.txt> <shape> <chunk> <transition 0|1> <threads> [rm: <ref_start> <ref_end>]
 //   target/query: one block each, records already joined by '&' (src/main.cpp:343-409)
 // output (stdout): for every (strand, chunk) in order:  "C <rev> <start> <end> <n_hsps> <num_hits>" then n lines
 //   "<ref_start> <query_start> <len> <score>"
@@ -20,7 +26,11 @@
 #include <thread>
 #include <vector>
 
+#ifdef COMPAT_DRIVER_RM
+#define SEGALIGN_AMD_COMPAT_DEFINE_RM
+#else
 #define SEGALIGN_AMD_COMPAT_DEFINE
+#endif
 #include "segalign_amd_compat.hpp"
 
 // ---- the part of common/ntcoding.cpp the host keeps (restated for this test host, not copied) -----------------------
@@ -106,15 +116,35 @@ int main(int argc, char** argv) {
     g_InitializeProcessor(transition, chunk, span, sub_mat, xdrop, hspthresh, false);                 // main.cpp:298
     g_SendRefWriteRequest(&target[0], 0, (uint32_t)target.size());                                    // main.cpp:615
     GenerateSeedPosTable(&target[0], 0, (uint32_t)target.size(), 1, (int)span, kmer_size);           // main.cpp:621
+    struct Job { bool rev; uint32_t s, e; std::vector<segmentPair> out; };
+    std::vector<Job> jobs;
+#ifdef COMPAT_DRIVER_RM
+    if (argc < 9) {
+        fprintf(stderr, "rm mode needs <ref_start> <ref_end>\n");
+        return 1;
+    }
+    const uint32_t rm_ref_start = (uint32_t)strtoul(argv[7], nullptr, 10), rm_ref_end = (uint32_t)strtoul(argv[8], nullptr, 10);
+    query = target;                                                                                   // rm main.cpp: one arena
+    g_SendQueryWriteRequest();                                                                        // rm main.cpp:420
+    std::string query_rc = HostRevComp(query);
+    {
+        const uint32_t L = (uint32_t)target.size(), start_pos = 0, end_pos = L - span;                // one block, one interval
+        const uint32_t end_pos_rc = L - 1 - start_pos;                                                // rm seeder.cpp:46-47
+        for (uint32_t i = start_pos; i < end_pos; i += chunk) {                                       // rm seeder.cpp:73-77
+            const uint32_t e = std::min(i + chunk, end_pos);
+            jobs.push_back({false, i, e, {}});
+            const uint32_t s_rc = L - 1 - e;                                                          // rm seeder.cpp:118-119
+            jobs.push_back({true, s_rc, std::min(std::min(s_rc + chunk, end_pos_rc), L - span + 1), {}});
+        }
+    }
+#else
     segalign_amd_compat::query_arena() = &query[0];                                                   // query_DRAM->buffer
     g_SendQueryWriteRequest(0, (uint32_t)query.size(), 0);                                            // main.cpp:661
     std::string query_rc = HostRevComp(query);                                                        // main.cpp:372
-
-    struct Job { bool rev; uint32_t s, e; std::vector<segmentPair> out; };
-    std::vector<Job> jobs;
     const uint32_t end_pos = (uint32_t)query.size() - span;                                           // main.cpp:383
     for (int rev = 0; rev < 2; rev++)
         for (uint32_t i = 0; i < end_pos; i += chunk) jobs.push_back({rev != 0, i, std::min(i + chunk, end_pos), {}});
+#endif
 
     std::atomic<size_t> next(0);
     auto worker = [&]() {
@@ -133,7 +163,11 @@ int main(int argc, char** argv) {
                             if (transition_pos[t] == 1) seeds.push_back(((k ^ ((uint64_t)2 << (2 * t))) << 32) + p);
                 }
             }
+#ifdef COMPAT_DRIVER_RM
+            if (!seeds.empty()) job.out = g_SeedAndFilter(seeds, job.rev, rm_ref_start, rm_ref_end);  // rm seeder.cpp:103-105,140-142
+#else
             if (!seeds.empty()) job.out = g_SeedAndFilter(seeds, job.rev, 0);                         // seeder.cpp:76-78
+#endif
         }
     };
     std::vector<std::thread> pool;
@@ -142,12 +176,20 @@ int main(int argc, char** argv) {
 
     for (auto& job : jobs) {
         size_t n = job.out.empty() ? 0 : job.out.size() - 1;
+#ifdef COMPAT_DRIVER_RM  // 64-bit counts packed into the header (repeat_masker_src/seed_filter.cu:857-861)
+        long hits = job.out.empty() ? 0 : (long)(((uint64_t)job.out[0].query_start << 32) | job.out[0].ref_start);
+#else
         long hits = job.out.empty() ? 0 : job.out[0].score;
+#endif
         printf("C %d %u %u %zu %ld\n", job.rev ? 1 : 0, job.s, job.e, n, hits);
         for (size_t i = 1; i < job.out.size(); i++)
             printf("%u %u %u %d\n", job.out[i].ref_start, job.out[i].query_start, job.out[i].len, job.out[i].score);
     }
+#ifdef COMPAT_DRIVER_RM
+    g_ClearQuery();
+#else
     g_ClearQuery(0);
+#endif
     g_ClearRef();
     g_ShutdownProcessor();                                                                            // main.cpp:743
     return 0;

@@ -37,9 +37,29 @@ def _run(nproc, steps):
     return json.loads(out[-1])
 
 
-def test_two_ranks_cover_what_one_rank_covers():
-    # 60 Mbp -> 6 intervals.  1 rank x 6 steps and 2 ranks x 3 steps must process the same bases and chunk checksum.
-    one = _run(1, 6)
-    two = _run(2, 3)
+def _model(world, steps, qlen=60_000_000, interval=10_000_000, chunk=250_000):
+    """Independent statement of the bench's work map: in step k rank r walks the interval list from interval r + k on,
+    wrapping (weak scaling: every rank covers every interval once per step); chunks per src/seeder.cpp:48-51,:33-34."""
+    ivs = shard.plan_intervals(qlen, 19, interval)
+    bases = check = 0
+    for r in range(world):
+        for k in range(steps):
+            for i in range(len(ivs)):
+                iv = ivs[(r + k + i) % len(ivs)]
+                bases += iv[1] - iv[0]
+                for rev in (False, True):
+                    s, e = (qlen - 19 - iv[1], qlen - 19 - iv[0]) if rev else iv
+                    for a in range(s, e, chunk):
+                        check += (i + 1) * ((a * 31 + min(a + chunk, e) * 17 + int(rev)) % 1000003)
+    return bases, check
+
+
+def test_rank_walks_and_reduction_match_the_model():
+    # 60 Mbp -> 6 intervals; the stub engine's checksum depends on WHICH interval a rank visits WHEN, so a wrong
+    # interval-to-rank map, a wrong chunk bound or a wrong sum/max reduction changes the line
+    one = _run(1, 2)
+    two = _run(2, 2)
     assert two["n_gpus"] == 2 and two["scaling"] == "weak"
-    assert one["bases"] == two["bases"] and one["checksum"] == two["checksum"]
+    assert (one["bases"], one["checksum"]) == _model(1, 2)
+    assert (two["bases"], two["checksum"]) == _model(2, 2)
+    assert two["bases"] == 2 * one["bases"]  # weak scaling: per-GPU work is fixed

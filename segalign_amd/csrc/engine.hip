@@ -89,14 +89,19 @@ struct DevBuf {  // grow-only device buffer
     }
 };
 
-struct SeqBuf {  // encoded sequence with SEQ_PAD guard bytes on both sides
+struct SeqBuf {  // encoded sequence with SEQ_PAD guard bytes on both sides; the allocation is kept and reused (grow-only):
+                 // hipMalloc / hipFree synchronise the device, which would stall the calls running on the other query buffer
     uint8_t* alloc = nullptr;
     uint8_t* codes = nullptr;
     uint32_t len = 0;
+    size_t cap = 0;
     void create(uint32_t n, const char* tag, hipStream_t s, bool row_coded = false) {
-        release(tag);
         size_t bytes = (size_t)n + 2 * SEQ_PAD + 64;  // +64: the k-mer window reads 32 bytes from any position
-        alloc = (uint8_t*)dev_malloc(bytes, tag);
+        if (!alloc || cap < bytes) {
+            dev_free(alloc, tag);
+            cap = bytes + bytes / 16;
+            alloc = (uint8_t*)dev_malloc(cap, tag);
+        }
         // guard bytes carry bit 6: OR-ed into a matrix index they select a terminator entry of the extension kernels'
         // 128-entry table, so a window that runs over a block edge stops the walk without any bounds arithmetic.
         // Below the guard bit they hold the code 7 ('E', the record separator) in the buffer's own coding, so a reader
@@ -105,40 +110,56 @@ struct SeqBuf {  // encoded sequence with SEQ_PAD guard bytes on both sides
         codes = alloc + SEQ_PAD;
         len = n;
     }
+    void clear() {  // ClearQuery / ClearRef: the block is gone, the memory stays with the engine
+        codes = nullptr;
+        len = 0;
+    }
     void release(const char* tag) {
         dev_free(alloc, tag);
         alloc = codes = nullptr;
         len = 0;
+        cap = 0;
     }
 };
 
-struct PackedBuf {  // phase copies of a packed sequence (packed X-drop filter): copy k at base + k*stride
+struct PackedBuf {  // phase copies of a packed sequence (packed X-drop filter): copy k at base + k*stride; grow-only like SeqBuf
     uint8_t* alloc = nullptr;
     uint8_t* base = nullptr;
     size_t stride = 0;
+    size_t cap = 0;
+    void reserve(size_t bytes, const char* tag) {
+        if (alloc && cap >= bytes) return;
+        dev_free(alloc, tag);
+        cap = bytes + bytes / 16;
+        alloc = (uint8_t*)dev_malloc(cap, tag);
+    }
     void create(const uint8_t* codes, uint32_t len, int bits, const char* tag, hipStream_t s) {
-        release(tag);
         if (bits == 2) {  // overlapped-line layout (encode.hip): no separate pads, the layout carries its own bias
             const uint32_t nphys = pack2_phys_bytes(len);
             stride = nphys;
-            alloc = (uint8_t*)dev_malloc(stride * 4, tag);
+            reserve(stride * 4, tag);
             base = alloc;
             launch_pack2_phases(codes, len, base, stride, nphys, s);  // writes every physical byte (0 outside the block)
             return;
         }
         const uint32_t nbytes = len / 2 + 1;
         stride = ((size_t)nbytes + 2 * PACK_PAD + 127) & ~(size_t)127;
-        alloc = (uint8_t*)dev_malloc(stride * 2, tag);
+        reserve(stride * 2, tag);
         // pads read as code 7 in both nibbles (any content keeps the filter's scores upper bounds; this makes a walk that
         // leaves the block die quickly under the default matrices)
         check_memcpy(hipMemsetAsync(alloc, 0x77, stride * 2, s), tag);
         base = alloc + PACK_PAD;
         launch_pack4_phases(codes, len, base, stride, nbytes, s);
     }
+    void clear() {
+        base = nullptr;
+        stride = 0;
+    }
     void release(const char* tag) {
         dev_free(alloc, tag);
         alloc = base = nullptr;
         stride = 0;
+        cap = 0;
     }
 };
 
@@ -209,8 +230,9 @@ struct Slot {
     uint32_t* d_cov_range = nullptr;  // {min query_start, max query_start+len} touched since the last reset
     uint32_t* h_cov = nullptr;        // pinned: range + per-tile totals
     // table-direct path (probe.hip): per-position scratch, compacted non-empty positions, chunk plans
-    DevBuf<uint64_t> td_toff, td_prefix, td_off;
-    DevBuf<uint32_t> td_tcnt, td_qpos;
+    DevBuf<uint64_t> td_toff;
+    DevBuf<uint32_t> td_tcnt;
+    DevBuf<TdRec> td_rec;
     DevBuf<uint8_t> td_partial;
     void* d_td_bounds = nullptr;
     TdPlan* d_td_plan = nullptr;
@@ -250,6 +272,13 @@ struct DevCtx {
     uint32_t* pos_table = nullptr;
     uint32_t num_index = 0;
     uint32_t nkeys = 0;
+    // sequence upload: ASCII goes through a ring of two pinned buffers into a reused device staging buffer, so the copies
+    // are real asynchronous DMA on the admin stream (a pageable hipMemcpyAsync is staged synchronously by the runtime) and
+    // nothing is allocated or freed per block (the reference mallocs + frees a temp per call, seed_filter_interface.cu:90-99,
+    // src/seed_filter.cu:905-918)
+    DevBuf<uint8_t> up_tmp;
+    uint8_t* up_pinned[2] = {nullptr, nullptr};
+    hipEvent_t up_ev[2] = {nullptr, nullptr};
     // neighbourhood table (probe.hip): per key the concatenation of the buckets of the key's seed words
     std::mutex nbr_mu;
     uint64_t* nbr_start = nullptr;       // nkeys + 1
@@ -391,8 +420,7 @@ static void slot_destroy(Slot& s) {
     s.chain_heads.release("chain"); s.chain_bucket_cnt.release("chain"); s.chain_bucket_start.release("chain"); s.ent_list.release("entropy list");
     s.cov_diff.release("coverage"); s.cov_pre.release("coverage"); s.cov_is_start.release("coverage");
     s.cov_is_end.release("coverage"); s.cov_sidx.release("coverage"); s.cov_eidx.release("coverage"); s.cov_pairs.release("coverage");
-    s.td_toff.release("probe"); s.td_prefix.release("probe"); s.td_off.release("probe"); s.td_tcnt.release("probe");
-    s.td_qpos.release("probe"); s.td_partial.release("probe");
+    s.td_toff.release("probe"); s.td_tcnt.release("probe"); s.td_rec.release("probe"); s.td_partial.release("probe");
     dev_free(s.d_td_bounds, "probe bounds"); dev_free(s.d_td_plan, "probe plan");
     s.d_td_bounds = nullptr; s.d_td_plan = nullptr;
     if (s.h_td_plan) hipHostFree(s.h_td_plan);
@@ -567,9 +595,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                 if (bh == 0 || (!ca.td && b_seed_hi <= b_seed_lo)) continue;  // iterations without hits produce nothing (H5)
                 if (ca.td) {
                     ea.td = 1;
-                    ea.td_prefix = sl->td_prefix.p;
-                    ea.td_off = sl->td_off.p;
-                    ea.td_qpos = sl->td_qpos.p;
+                    ea.td_rec = sl->td_rec.p;
                     ea.td_m = sl->h_td_plan[K - 1].m_hi;
                     ea.td_pos = dc->nbr_pos;
                     ea.seed_size = g_seed_size;
@@ -992,9 +1018,7 @@ static uint32_t td_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, int K, con
     sh.span = (int)g_seed_size;
     sl->td_toff.ensure(n, "probe scratch");
     sl->td_tcnt.ensure(n, "probe scratch");
-    sl->td_prefix.ensure((size_t)n + 1, "probe prefix");
-    sl->td_off.ensure(n, "probe runs");
-    sl->td_qpos.ensure(n, "probe positions");
+    sl->td_rec.ensure((size_t)n + 1, "probe records");
     sl->td_partial.ensure(probe_partial_bytes(n), "probe partials");
     TdBounds tb;
     tb.nb = K + 1;
@@ -1005,12 +1029,11 @@ static uint32_t td_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, int K, con
     }
     {
         ProfScope p(sl, "probe_compact");
-        launch_probe_compact(start, n, sl->td_toff.p, sl->td_tcnt.p, sl->td_partial.p, sl->d_td_bounds, sl->td_prefix.p, sl->td_off.p,
-                             sl->td_qpos.p, tb, st);
+        launch_probe_compact(start, n, sl->td_toff.p, sl->td_tcnt.p, sl->td_partial.p, sl->d_td_bounds, sl->td_rec.p, tb, st);
     }
     {
         ProfScope p(sl, "iteration_plan");
-        launch_probe_plan(qcodes, sh, tmask, dc->bucket_start, sl->d_td_bounds, K, sl->td_prefix.p, sl->td_qpos.p, sl->d_td_plan, st);
+        launch_probe_plan(qcodes, sh, tmask, dc->bucket_start, sl->d_td_bounds, K, sl->td_rec.p, sl->d_td_plan, st);
     }
     check_launch("probe");
     check_memcpy(hipMemcpyAsync(sl->h_td_plan, sl->d_td_plan, sizeof(TdPlan) * K, hipMemcpyDeviceToHost, st), "probe plan");
@@ -1028,9 +1051,44 @@ static uint32_t td_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, int K, con
     return (uint32_t)(nvalid * words);
 }
 
+// ---- ASCII upload through the pinned ring (see DevCtx) -------------------------------------------------------------
+constexpr size_t UP_CHUNK = (size_t)32 << 20;
+static const uint8_t* upload_ascii(DevCtx* dc, const char* src, size_t len, const char* tag) {
+    hipStream_t st = dc->admin;
+    dc->up_tmp.ensure(len + 64, tag);
+    for (int k = 0; k < 2; k++)
+        if (!dc->up_pinned[k]) {
+            if (hipHostMalloc((void**)&dc->up_pinned[k], UP_CHUNK) != hipSuccess || hipEventCreateWithFlags(&dc->up_ev[k], hipEventDisableTiming) != hipSuccess) {
+                fprintf(stderr, "Error: hipHostMalloc for the upload ring failed\n");
+                exit(12);
+            }
+        }
+    size_t i = 0;
+    for (size_t off = 0; off < len; off += UP_CHUNK, i++) {
+        const int k = (int)(i & 1);
+        const size_t n = std::min(UP_CHUNK, len - off);
+        if (i >= 2) hipEventSynchronize(dc->up_ev[k]);  // the DMA that last used this pinned buffer has finished
+        memcpy(dc->up_pinned[k], src + off, n);
+        check_memcpy(hipMemcpyAsync(dc->up_tmp.p + off, dc->up_pinned[k], n, hipMemcpyHostToDevice, st), tag);
+        hipEventRecord(dc->up_ev[k], st);
+    }
+    return dc->up_tmp.p;
+}
+
 static void require_init(const char* who) {
     if (g_ndev <= 0) {
         fprintf(stderr, "Error: %s called before InitializeInterface\n", who);
+        exit(1);
+    }
+}
+static void require_proc(const char* who, uint32_t buffer) {  // hot entry points: processor initialised, buffer id in range
+    require_init(who);
+    if (!g_proc_init) {
+        fprintf(stderr, "Error: %s called before InitializeProcessor\n", who);
+        exit(1);
+    }
+    if (buffer >= SA_BUFFER_DEPTH) {
+        fprintf(stderr, "Error: %s: query buffer %u out of range (BUFFER_DEPTH %d)\n", who, buffer, SA_BUFFER_DEPTH);
         exit(1);
     }
 }
@@ -1052,6 +1110,7 @@ void sa_select_devices(const int* ids, int n) {
 }
 
 void sa_shutdown_processor(void);
+static void destroy_interface();
 
 int sa_initialize_interface(int num_gpu) {  // seed_filter_interface.cu:49-80
     int n = 0;
@@ -1076,7 +1135,7 @@ int sa_initialize_interface(int num_gpu) {  // seed_filter_interface.cu:49-80
         exit(10);
     }
     fprintf(stderr, "Using %d GPU(s)\n", use);
-    if (!g_dev.empty()) sa_shutdown_processor();  // re-initialisation: release the previous contexts first
+    if (!g_dev.empty()) destroy_interface();  // re-initialisation: release the previous contexts first
     g_ndev = use;
     for (int g = 0; g < use; g++) {
         const int ord = g_selected.empty() ? g : g_selected[g];
@@ -1121,6 +1180,8 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
         g_fast_filter = (xdrop >= 0 && (int64_t)7 * std::max(mx, 0) <= (int64_t)xdrop) ? 1 : 0;
         // int16 score arithmetic: the best of a side (<= max(M) * long_cap rounded up to whole 64-base windows) and xdrop itself must stay well inside
         // the saturation range, or a walk could never satisfy the drop test and every hit would become a candidate
+        // the 4-bit query copies carry PACK_PAD bytes = 2 * PACK_PAD bases of padding: a capped walk must end inside it
+        if (g_long_cap > 2 * PACK_PAD) g_long_cap = 2 * PACK_PAD;
         g_packed_filter = (xdrop >= 0 && xdrop <= 16383 && (int64_t)std::max(mx, 0) * (((int64_t)g_long_cap + 63) / 64 * 64) <= 16383 &&
                            !getenv("SEGALIGN_AMD_NO_PACKED_FILTER")) ? 1 : 0;
         if (getenv("SEGALIGN_AMD_NO_FAST_FILTER")) { g_fast_filter = 0; g_packed_filter = 0; }
@@ -1152,36 +1213,62 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
     g_proc_init = true;
 }
 
-void sa_shutdown_processor(void) {  // src/seed_filter.cu:932-940
+// everything the engine holds on one device except the context itself (what the reference's cudaDeviceReset() wipes, :939)
+static void release_device_state(DevCtx* dc) {
+    check_set_device(dc->dev, "ShutdownProcessor");
+    hipDeviceSynchronize();
+    for (int k = 0; k < MAX_SLOTS_PER_DEVICE; k++) if (dc->slots[k].stream) slot_destroy(dc->slots[k]);
+    dc->ref.release("d_ref_seq");
+    dc->ref8.release("d_ref_seq rows");
+    dc->ref2.release("d_ref_seq 2-bit");
+    dc->ref_rc.release("d_seq_rc");
+    dc->ref4.release("d_seq 4-bit");
+    dc->ref4_rc.release("d_seq_rc 4-bit");
+    dc->ref_host_ptr = nullptr;
+    nbr_release(dc);
+    dev_free(dc->bucket_start, "d_index_table");
+    dev_free(dc->pos_table, "d_pos_table");
+    dc->bucket_start = dc->pos_table = nullptr;
+    dc->num_index = 0;
+    for (int b = 0; b < SA_BUFFER_DEPTH; b++) {
+        dc->query[b].release("d_query_seq");
+        dc->query_rc[b].release("d_query_rc_seq");
+        dc->query4[b].release("d_query_seq 4-bit");
+        dc->query4_rc[b].release("d_query_rc_seq 4-bit");
+    }
+    dc->up_tmp.release("upload staging");
+    for (int k = 0; k < 2; k++) {
+        if (dc->up_pinned[k]) hipHostFree(dc->up_pinned[k]);
+        if (dc->up_ev[k]) hipEventDestroy(dc->up_ev[k]);
+        dc->up_pinned[k] = nullptr;
+        dc->up_ev[k] = nullptr;
+    }
+    dev_free(dc->d_sub_mat, "sub_mat");
+    dc->d_sub_mat = nullptr;
+}
+
+// g_ShutdownProcessor (src/seed_filter.cu:932-940): the reference clears its device vectors and resets the device, which
+// also drops the target and the tables.  Same here; the INTERFACE (device list, contexts) stays, so a host may run
+// InitializeProcessor / SendRefWriteRequest again without a second InitializeInterface.
+void sa_shutdown_processor(void) {
+    for (auto* dc : g_dev) release_device_state(dc);
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_tokens.clear();
+    }
+    g_proc_init = false;
+    for (uint32_t b = 0; b < SA_BUFFER_DEPTH; b++) g_query_len[b] = 0;
+}
+
+static void destroy_interface() {  // re-initialisation of the interface: contexts go too
+    sa_shutdown_processor();
     for (auto* dc : g_dev) {
-        check_set_device(dc->dev, "ShutdownProcessor");
-        hipDeviceSynchronize();
-        for (int k = 0; k < MAX_SLOTS_PER_DEVICE; k++) if (dc->slots[k].stream) slot_destroy(dc->slots[k]);
-        dc->ref.release("d_ref_seq");
-        dc->ref8.release("d_ref_seq rows");
-        dc->ref2.release("d_ref_seq 2-bit");
-        dc->ref_rc.release("d_seq_rc");
-        dc->ref4.release("d_seq 4-bit");
-        dc->ref4_rc.release("d_seq_rc 4-bit");
-        nbr_release(dc);
-        dev_free(dc->bucket_start, "d_index_table");
-        dev_free(dc->pos_table, "d_pos_table");
-        dc->bucket_start = dc->pos_table = nullptr;
-        for (int b = 0; b < SA_BUFFER_DEPTH; b++) {
-            dc->query[b].release("d_query_seq");
-            dc->query_rc[b].release("d_query_rc_seq");
-            dc->query4[b].release("d_query_seq 4-bit");
-            dc->query4_rc[b].release("d_query_rc_seq 4-bit");
-        }
-        dev_free(dc->d_sub_mat, "sub_mat");
-        dc->d_sub_mat = nullptr;
+        check_set_device(dc->dev, "InitializeInterface");
         if (dc->admin) hipStreamDestroy(dc->admin);
         delete dc;
     }
     g_dev.clear();
-    g_tokens.clear();
     g_ndev = 0;
-    g_proc_init = false;
 }
 
 // ---- target ---------------------------------------------------------------------------------------------------------
@@ -1189,8 +1276,7 @@ void sa_send_ref_write_request(const char* seq, size_t addr, uint32_t len) {  //
     require_init("SendRefWriteRequest");
     for (auto* dc : g_dev) {
         check_set_device(dc->dev, "SendRefWriteRequest");
-        uint8_t* tmp = (uint8_t*)dev_malloc((size_t)len + 16, "tmp_ref_seq");
-        check_memcpy(hipMemcpyAsync(tmp, seq + addr, len, hipMemcpyHostToDevice, dc->admin), "ref_seq");
+        const uint8_t* tmp = upload_ascii(dc, seq + addr, len, "ref_seq");
         dc->ref.create(len, "ref_seq", dc->admin);
         launch_encode(tmp, dc->ref.codes, len, dc->admin);
         dc->ref8.create(len, "ref_seq rows", dc->admin, true);
@@ -1198,7 +1284,6 @@ void sa_send_ref_write_request(const char* seq, size_t addr, uint32_t len) {  //
         dc->ref2.create(dc->ref.codes, len, 2, "ref_seq 2-bit", dc->admin);
         check_launch("compress_string");
         check_sync(dc->admin, "SendRefWriteRequest");
-        dev_free(tmp, "d_ref_seq_tmp");
         dc->ref_host_ptr = seq + addr;
     }
 }
@@ -1264,12 +1349,10 @@ void sa_generate_seed_pos_table(const char* ref_str, size_t start_addr, uint32_t
         SeqBuf tmp_codes;
         if (!(dc->ref.codes && dc->ref_host_ptr == ref_str + start_addr && dc->ref.len == ref_length)) {
             // not the resident block: encode a private copy
-            uint8_t* tmp = (uint8_t*)dev_malloc((size_t)ref_length + 16, "tmp table seq");
-            check_memcpy(hipMemcpyAsync(tmp, ref_str + start_addr, ref_length, hipMemcpyHostToDevice, st), "table seq");
+            const uint8_t* tmp = upload_ascii(dc, ref_str + start_addr, ref_length, "table seq");
             tmp_codes.create(ref_length, "table codes", st);
             launch_encode(tmp, tmp_codes.codes, ref_length, st);
             check_sync(st, "table encode");
-            dev_free(tmp, "tmp table seq");
             codes = tmp_codes.codes;
         }
         nbr_release(dc);
@@ -1314,8 +1397,7 @@ void sa_send_query_write_request(const char* query_buffer, size_t addr, uint32_t
     for (auto* dc : g_dev) {
         check_set_device(dc->dev, "SendQueryWriteRequest");
         hipStream_t st = dc->admin;
-        uint8_t* tmp = (uint8_t*)dev_malloc((size_t)len + 16, "tmp query_seq");
-        check_memcpy(hipMemcpyAsync(tmp, query_buffer + addr, len, hipMemcpyHostToDevice, st), "query_seq");
+        const uint8_t* tmp = upload_ascii(dc, query_buffer + addr, len, "query_seq");
         dc->query[buffer].create(len, "query_seq", st);
         dc->query_rc[buffer].create(len, "query_rc_seq", st);
         launch_encode_rev_comp(tmp, dc->query[buffer].codes, dc->query_rc[buffer].codes, len, st);
@@ -1323,24 +1405,24 @@ void sa_send_query_write_request(const char* query_buffer, size_t addr, uint32_t
         dc->query4_rc[buffer].create(dc->query_rc[buffer].codes, len, 4, "query_rc_seq 4-bit", st);
         check_launch("compress_string_rev_comp");
         check_sync(st, "SendQueryWriteRequest");
-        dev_free(tmp, "d_query_seq_tmp");
     }
 }
 
 void sa_clear_query(uint32_t buffer) {  // :921-930
     if (buffer >= SA_BUFFER_DEPTH) return;
     for (auto* dc : g_dev) {
-        check_set_device(dc->dev, "ClearQuery");
-        dc->query[buffer].release("d_query_seq");
-        dc->query_rc[buffer].release("d_query_rc_seq");
-        dc->query4[buffer].release("d_query_seq 4-bit");
-        dc->query4_rc[buffer].release("d_query_rc_seq 4-bit");
+        // the reference frees here (:921-930); the engine keeps the allocations for the next block of this buffer: a
+        // hipFree would synchronise the device under the calls that are running on the OTHER query buffer
+        dc->query[buffer].clear();
+        dc->query_rc[buffer].clear();
+        dc->query4[buffer].clear();
+        dc->query4_rc[buffer].clear();
     }
 }
 
 // ---- hot calls ------------------------------------------------------------------------------------------------------
 size_t sa_seed_and_filter(const uint64_t* seeds, size_t num_seeds, int rev, uint32_t buffer, sa_segment_pair** out) {
-    require_init("SeedAndFilter");
+    require_proc("SeedAndFilter", buffer);
     if ((int64_t)num_seeds > g_max_seeds) {  // :688-692
         printf("MAX_SEEDS exceeded\n");
         fflush(stdout);
@@ -1359,7 +1441,7 @@ size_t sa_seed_and_filter(const uint64_t* seeds, size_t num_seeds, int rev, uint
 }
 
 size_t sa_seed_and_filter_range(uint32_t start, uint32_t end, int rev, uint32_t buffer, sa_segment_pair** out) {
-    require_init("SeedAndFilterRange");
+    require_proc("SeedAndFilterRange", buffer);
     Slot* sl = acquire_slot();
     DevCtx* dc = g_dev[0];
     for (auto* d : g_dev) if (d->dev == sl->dev) dc = d;
@@ -1396,7 +1478,7 @@ size_t sa_seed_and_filter_range(uint32_t start, uint32_t end, int rev, uint32_t 
 // iteration plan, dedup scope and return vector -- bit for bit what one sa_seed_and_filter_range call per chunk returns.
 int sa_max_chunks_per_call(void) { return SA_MAX_CHUNKS; }
 size_t sa_seed_and_filter_chunks(uint32_t start, uint32_t end, int rev, uint32_t buffer, sa_segment_pair** outs, size_t* counts) {
-    require_init("SeedAndFilterChunks");
+    require_proc("SeedAndFilterChunks", buffer);
     const uint32_t chunk = g_wga_chunk;
     const int K = end > start ? (int)(((uint64_t)end - start + chunk - 1) / chunk) : 0;
     if (K > SA_MAX_CHUNKS) {
@@ -1478,7 +1560,7 @@ size_t sa_extend_hits(const uint32_t* ref_query_pairs, size_t num_hits, int rev,
 // worker).  HSPs are concatenated per strand in chunk order, headers removed (:80-85,115-120).
 size_t sa_seed_interval(uint32_t start, uint32_t end, uint32_t q_len, int strands, uint32_t buffer, int threads,
                         sa_segment_pair** out_fw, size_t* n_fw, sa_segment_pair** out_rc, size_t* n_rc, sa_call_stats* totals) {
-    require_init("SeedInterval");
+    require_proc("SeedInterval", buffer);
     struct Job { uint32_t a, b; int rev; int k; sa_segment_pair* res[SA_MAX_CHUNKS]; size_t n[SA_MAX_CHUNKS]; };
     std::vector<Job> jobs;
     const int per_job = g_chunks_per_call;  // chunks of one strand that share one pass over the kernels
@@ -1547,7 +1629,7 @@ size_t sa_seed_interval(uint32_t start, uint32_t end, uint32_t q_len, int strand
 }
 
 size_t sa_device_make_seeds(uint32_t start, uint32_t end, int rev, uint32_t buffer, uint64_t* dst, size_t cap) {
-    require_init("DeviceMakeSeeds");
+    require_proc("DeviceMakeSeeds", buffer);
     Slot* sl = acquire_slot();
     DevCtx* dc = g_dev[0];
     for (auto* d : g_dev) if (d->dev == sl->dev) dc = d;

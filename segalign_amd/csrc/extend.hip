@@ -489,15 +489,29 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
         uint64_t rem = a.num_hits - (b << 6);
         return rem >= 64 ? 64 : (int)rem;
     };
-    uint32_t td_m0 = 0;  // TD: td_prefix[td_m0] <= 64 * (next buffer to fetch) < td_prefix[td_m0 + 1]
+    // TD state: td_rec[td_m0].prefix <= 64 * (next buffer to fetch) < td_rec[td_m0 + 1].prefix.  The window -- the records
+    // td_m0 .. td_m0 + 63, one per lane, plus the prefix of record td_m0 + 64 in lane 0 -- is loaded ONE FETCH AHEAD, so a
+    // fetch itself never waits for memory: it searches the window held in registers with shuffles, issues the gather of the
+    // run entries (consumed a whole buffer later) and the load of the next window.
+    uint32_t td_m0 = 0;
+    TdRec win = {0u, 0u, 0ull};
+    uint32_t win64 = 0;
+    auto load_window = [&]() {
+        const uint32_t mi = td_m0 + (uint32_t)lane;
+        win = a.td_rec[mi < a.td_m ? mi : a.td_m];
+        if (mi > a.td_m) win.prefix = 0xFFFFFFFFu;  // past the sentinel
+        win64 = 0xFFFFFFFFu;
+        if (lane == 0 && td_m0 + 64u <= a.td_m) win64 = a.td_rec[td_m0 + 64u].prefix;
+    };
     if (TD && cur_buf < buf_end) {
-        const uint64_t g0 = cur_buf << 6;
-        uint32_t lo = 0, hi = a.td_m;  // td_prefix[0] = 0 <= g0 < td_prefix[td_m] = num_hits
+        const uint32_t g0 = (uint32_t)(cur_buf << 6);
+        uint32_t lo = 0, hi = a.td_m;  // td_rec[0].prefix = 0 <= g0 < td_rec[td_m].prefix = num_hits
         while (lo + 1 < hi) {
             const uint32_t mid = lo + ((hi - lo) >> 1);
-            if (a.td_prefix[mid] <= g0) lo = mid; else hi = mid;
+            if (a.td_rec[mid].prefix <= g0) lo = mid; else hi = mid;
         }
         td_m0 = lo;
+        load_window();
     }
     auto fetch = [&](uint64_t b, int cnt) -> Hit {
         Hit h = {0u, 0u};
@@ -506,33 +520,31 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
             return h;
         }
         if (cnt == 0) return h;  // wave-uniform
-        const uint64_t g0 = b << 6;
-        const uint32_t mi = td_m0 + (uint32_t)lane;
-        const uint64_t pv = a.td_prefix[mi < a.td_m ? mi : a.td_m];
-        const uint64_t d = pv - g0;  // lanes >= 1: > 0 (invariant); lane 0: <= 0, handled below
-        const uint32_t R = lane == 0 ? 0u : (mi > a.td_m ? 0xFFFFFFFFu : (d > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)d));
-        const uint64_t pv0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pv >> 32)) << 32) |
-                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pv);
-        const uint32_t d0 = (uint32_t)(g0 - pv0);  // hits of position td_m0 that belong to earlier buffers
-        uint32_t lo = 0, rv = 0;                   // largest window entry whose first hit is <= this lane's hit
+        const uint32_t g0 = (uint32_t)(b << 6);
+        // R: first hit of the lane's record relative to g0; lanes >= 1 hold values >= 1 (invariant), lane 0 counts as 0;
+        // records past the sentinel as infinity (prefix differences are < 2^32, the clamp keeps the order)
+        const uint32_t d = win.prefix - g0;
+        const uint32_t R = lane == 0 ? 0u : (win.prefix == 0xFFFFFFFFu ? 0xFFFFFFFFu : d);
+        const uint32_t d0 = g0 - (uint32_t)__builtin_amdgcn_readfirstlane((int)win.prefix);  // hits of record td_m0 in earlier buffers
+        uint32_t lo = 0, rv = 0;  // largest window entry whose first hit is <= this lane's hit
 #pragma unroll
         for (uint32_t step = 32; step >= 1; step >>= 1) {
             const uint32_t cand = lo + step;
             const uint32_t v = (uint32_t)__shfl((int)R, (int)(cand & 63u), 64);
             if (cand < 64u && v <= (uint32_t)lane) { lo = cand; rv = v; }
         }
+        const uint32_t o_lo = (uint32_t)__shfl((int)(uint32_t)win.off, (int)lo, 64);
+        const uint32_t o_hi = (uint32_t)__shfl((int)(uint32_t)(win.off >> 32), (int)lo, 64);
+        const uint32_t qp = (uint32_t)__shfl((int)win.qpos, (int)lo, 64);
         if (lane < cnt) {
             const uint32_t k = lo == 0u ? d0 + (uint32_t)lane : (uint32_t)lane - rv;
-            const uint32_t m = td_m0 + lo;
-            h.ref_loc = a.td_pos[a.td_off[m] + k] + a.seed_size;  // :220
-            h.query_loc = a.td_qpos[m] + a.seed_size;             // :204
+            h.ref_loc = a.td_pos[(((uint64_t)o_hi << 32) | o_lo) + k] + a.seed_size;  // :220
+            h.query_loc = qp + a.seed_size;                                          // :204
         }
-        // advance to the position that holds hit g0 + 64: entries 1..63 by their lanes, entry 64 by lane 0
-        uint64_t p64 = 0;
-        const bool has64 = td_m0 + 64u <= a.td_m;
-        if (lane == 0 && has64) p64 = a.td_prefix[td_m0 + 64u];
-        const bool adv = lane == 0 ? (has64 && p64 - g0 <= 64ull) : (R <= 64u);
+        // advance to the record that holds hit g0 + 64: entries 1..63 by their lanes, entry 64 by lane 0; next window
+        const bool adv = lane == 0 ? (win64 != 0xFFFFFFFFu && win64 - g0 <= 64u) : (R <= 64u);
         td_m0 += (uint32_t)__popcll(__ballot(adv));
+        load_window();
         return h;
     };
     int buf_cnt = buf_count(cur_buf), nxt_cnt = buf_count(nxt_buf), consumed = 0;

@@ -48,6 +48,12 @@ struct EntRec {               // finished hit with hspthresh <= total <= 3*hspth
     uint32_t seg;
 };
 
+struct TdRec {                // table-direct lookup (probe.hip): a non-empty query position of the call
+    uint32_t prefix;          // call-wide index of the position's first hit (a table-direct call holds < 2^32 hits)
+    uint32_t qpos;            // query position (seed start)
+    uint64_t off;             // offset of the position's run in the neighbourhood table
+};
+
 struct ExtendArgs {
     const uint8_t* ref2;      // packed filter: 2-bit target, phase copy k at ref2 + k*ref2_stride, overlapped-line layout
     size_t ref2_stride;
@@ -88,9 +94,7 @@ struct ExtendArgs {
     // TD ("table direct", probe.hip): no hit list -- hit g of the call is entry g - td_prefix[m] of the run of the m-th
     // non-empty query position; the packed filter reads its anchors straight out of the neighbourhood table
     int td;
-    const uint64_t* td_prefix;  // [td_m + 1] call-wide index of each non-empty position's first hit; td_prefix[td_m] = num_hits
-    const uint64_t* td_off;     // [td_m] offset of the position's run in td_pos
-    const uint32_t* td_qpos;    // [td_m] query position (seed start)
+    const TdRec* td_rec;        // [td_m + 1] one record per NON-EMPTY query position, in query order; td_rec[td_m].prefix = num_hits
     uint32_t td_m;
     const uint32_t* td_pos;     // neighbourhood table runs: seed START positions in the target (+ seed_size = anchor, :220)
     uint32_t seed_size;

@@ -29,14 +29,14 @@ void launch_nbr_count(const uint32_t* bucket_start, uint32_t nkeys, uint32_t tma
 void launch_nbr_fill(const uint32_t* bucket_start, const uint32_t* pos_table, uint32_t nkeys, uint32_t tmask, int weight,
                      const uint64_t* nbr_start, uint32_t* nbr_pos, hipStream_t s);
 
-// position probe of n = end - start query positions; t_off/t_cnt: n entries of scratch; c_prefix: n + 1, c_off / c_qpos: n
+// position probe of n = end - start query positions; t_off/t_cnt: n entries of scratch; c_rec: n + 1 records
 size_t probe_partial_bytes(uint32_t n);
 size_t probe_bounds_bytes();
 void launch_probe_lookup(const uint8_t* query, uint32_t start, uint32_t n, SeedShape sh, const uint64_t* nbr_start, uint32_t nkeys,
                          uint64_t* t_off, uint32_t* t_cnt, void* partial_buf, hipStream_t s);
 void launch_probe_compact(uint32_t start, uint32_t n, const uint64_t* t_off, const uint32_t* t_cnt, void* partial_buf, void* bounds_buf,
-                          uint64_t* c_prefix, uint64_t* c_off, uint32_t* c_qpos, const TdBounds& bpos, hipStream_t s);
+                          TdRec* c_rec, const TdBounds& bpos, hipStream_t s);
 void launch_probe_plan(const uint8_t* query, SeedShape sh, uint32_t tmask, const uint32_t* bucket_start, const void* bounds_buf, int nchunks,
-                       const uint64_t* c_prefix, const uint32_t* c_qpos, TdPlan* plan, hipStream_t s);
+                       const TdRec* c_rec, TdPlan* plan, hipStream_t s);
 
 }  // namespace sa

@@ -18,8 +18,8 @@
 // Per call (positions [start, end) of one strand, up to SA_MAX_CHUNKS chunks):
 //   probe_kernel    position -> k-mer (kmer_dev.h) -> {run offset, run length}; per-block sums of (hits, non-empty, valid)
 //   probe_partials  exclusive scan of the block sums (one workgroup)
-//   probe_compact   order-preserving compaction of the NON-EMPTY positions: c_prefix (hit offset of the position's first
-//                   hit inside the call), c_off (run offset), c_qpos; prefix values at the chunk boundaries
+//   probe_compact   order-preserving compaction of the NON-EMPTY positions into 16-byte records {hit offset of the position's
+//                   first hit inside the call, query position, run offset}; prefix values at the chunk boundaries
 //   probe_plan      per chunk: number of hits, and the reference's iteration split (src/seed_filter.cu:718-745 for
 //                   num_hits < MAX_HITS: everything before the LAST HIT-BEARING SEED WORD / that word's hits) -- found from
 //                   the last non-empty position and the plain bucket sizes of its 13 words
@@ -164,8 +164,7 @@ __global__ __launch_bounds__(PR_THREADS) void probe_partials_kernel(Tri* __restr
 // bounds[c] = exclusive prefix (hits, non-empty, valid) at position bpos[c] - start, c = 0..nb-1 (a bound == n takes the total)
 __global__ __launch_bounds__(PR_THREADS) void probe_compact_kernel(uint32_t start, uint32_t n, const uint64_t* __restrict__ t_off,
                                                                    const uint32_t* __restrict__ t_cnt, const Tri* __restrict__ partial,
-                                                                   const Tri* __restrict__ total, uint64_t* __restrict__ c_prefix,
-                                                                   uint64_t* __restrict__ c_off, uint32_t* __restrict__ c_qpos,
+                                                                   const Tri* __restrict__ total, TdRec* __restrict__ c_rec,
                                                                    TdBounds bpos, Tri* __restrict__ bounds) {
     const uint32_t i0 = blockIdx.x * PR_TILE + threadIdx.x * PR_ITEMS;
     uint64_t off[PR_ITEMS];
@@ -194,9 +193,11 @@ __global__ __launch_bounds__(PR_THREADS) void probe_compact_kernel(uint32_t star
         for (int c = 0; c < TD_MAX_BOUNDS; c++)
             if (c < bpos.nb && bpos.pos[c] - start == i) bounds[c] = run;
         if (cnt[j]) {
-            c_prefix[run.ne] = run.hits;
-            c_off[run.ne] = off[j] & ~PR_VALID;
-            c_qpos[run.ne] = start + i;
+            TdRec r;
+            r.prefix = (uint32_t)run.hits;  // (a call with >= 2^32 hits is sent down the general path, engine.hip td_front)
+            r.qpos = start + i;
+            r.off = off[j] & ~PR_VALID;
+            c_rec[run.ne] = r;
         }
         run.hits += cnt[j];
         run.ne += cnt[j] ? 1u : 0u;
@@ -204,7 +205,11 @@ __global__ __launch_bounds__(PR_THREADS) void probe_compact_kernel(uint32_t star
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const Tri t = *total;
-        c_prefix[t.ne] = t.hits;  // sentinel: one past the last non-empty position
+        TdRec r;
+        r.prefix = (uint32_t)t.hits;  // sentinel: one past the last non-empty position
+        r.qpos = 0;
+        r.off = 0;
+        c_rec[t.ne] = r;
         for (int c = 0; c < bpos.nb; c++)
             if (bpos.pos[c] - start >= n) bounds[c] = t;
     }
@@ -212,8 +217,7 @@ __global__ __launch_bounds__(PR_THREADS) void probe_compact_kernel(uint32_t star
 
 // one lane per chunk
 __global__ void probe_plan_kernel(const uint8_t* __restrict__ query, SeedShape sh, uint32_t tmask, const uint32_t* __restrict__ bucket_start,
-                                  const Tri* __restrict__ bounds, int nchunks, const uint64_t* __restrict__ c_prefix,
-                                  const uint32_t* __restrict__ c_qpos, TdPlan* __restrict__ plan) {
+                                  const Tri* __restrict__ bounds, int nchunks, const TdRec* __restrict__ c_rec, TdPlan* __restrict__ plan) {
     const int c = threadIdx.x;
     if (c >= nchunks) return;
     const Tri lo = bounds[c], hi = bounds[c + 1];
@@ -229,7 +233,7 @@ __global__ void probe_plan_kernel(const uint8_t* __restrict__ query, SeedShape s
         // walk that position's words in emission order (seeder.cpp:60-69) over the PLAIN buckets
         const uint32_t m = hi.ne - 1;
         uint32_t key = 0;
-        kmer_at(query, c_qpos[m], sh, key);
+        kmer_at(query, c_rec[m].qpos, sh, key);
         uint64_t before = 0, before_last = 0;
         uint32_t n0 = bucket_len(bucket_start, key);
         if (n0) before_last = 0;
@@ -240,7 +244,7 @@ __global__ void probe_plan_kernel(const uint8_t* __restrict__ query, SeedShape s
                 if (nt) before_last = before;
                 before += nt;
             }
-        p.split = c_prefix[m] + before_last;  // iteration 0 = hits [hit_base, split), iteration 1 = [split, hit_base + num_hits)
+        p.split = (uint64_t)c_rec[m].prefix + before_last;  // iteration 0 = hits [hit_base, split), iteration 1 = [split, hit_base + num_hits)
     }
     plan[c] = p;
 }
@@ -256,18 +260,18 @@ void launch_probe_lookup(const uint8_t* query, uint32_t start, uint32_t n, SeedS
                        reinterpret_cast<Tri*>(partial_buf));
 }
 void launch_probe_compact(uint32_t start, uint32_t n, const uint64_t* t_off, const uint32_t* t_cnt, void* partial_buf, void* bounds_buf,
-                          uint64_t* c_prefix, uint64_t* c_off, uint32_t* c_qpos, const TdBounds& bpos, hipStream_t s) {
+                          TdRec* c_rec, const TdBounds& bpos, hipStream_t s) {
     Tri* partial = reinterpret_cast<Tri*>(partial_buf);
     const uint32_t nblocks = probe_blocks(n);
     Tri* total = partial + nblocks;
     hipLaunchKernelGGL(probe_partials_kernel, dim3(1), dim3(PR_THREADS), 0, s, partial, nblocks, total);
-    hipLaunchKernelGGL(probe_compact_kernel, dim3(nblocks), dim3(PR_THREADS), 0, s, start, n, t_off, t_cnt, partial, total, c_prefix, c_off,
-                       c_qpos, bpos, reinterpret_cast<Tri*>(bounds_buf));
+    hipLaunchKernelGGL(probe_compact_kernel, dim3(nblocks), dim3(PR_THREADS), 0, s, start, n, t_off, t_cnt, partial, total, c_rec, bpos,
+                       reinterpret_cast<Tri*>(bounds_buf));
 }
 void launch_probe_plan(const uint8_t* query, SeedShape sh, uint32_t tmask, const uint32_t* bucket_start, const void* bounds_buf, int nchunks,
-                       const uint64_t* c_prefix, const uint32_t* c_qpos, TdPlan* plan, hipStream_t s) {
+                       const TdRec* c_rec, TdPlan* plan, hipStream_t s) {
     hipLaunchKernelGGL(probe_plan_kernel, dim3(1), dim3(64), 0, s, query, sh, tmask, bucket_start, reinterpret_cast<const Tri*>(bounds_buf),
-                       nchunks, c_prefix, c_qpos, plan);
+                       nchunks, c_rec, plan);
 }
 
 }  // namespace sa

@@ -111,3 +111,23 @@ def test_multi_chunk_call_equals_one_call_per_chunk(small_case, rev):
             want, _ = c.oracle_saf(c.host_seeds(s, e, rev), rev)
             assert seg_equal(got[i], want), (rev, start, i, got[i][:3], want[:3])
             assert seg_equal(got[i], c.E.SeedAndFilterRange(s, e, rev, 0))
+
+
+def test_interval_entry_equals_drop_in_path_on_the_tail_interval(small_case):
+    """The reference seeder is handed q_len = block length - seed size (src/main.cpp:708), so on both strands every seed
+    window of the LAST interval ends inside the block (j + 18 <= len - 2).  The additive entries clamp seed starts to
+    j + span <= len; on the reference's own call pattern that clamp never binds: the interval entry equals the drop-in
+    path chunk by chunk, tail included."""
+    c, E = small_case, small_case.E
+    q_len = c.query.size - c.seed_size
+    iv = (q_len - 150000, q_len)  # the tail interval (1.5 chunks of 100 kbp)
+    fw, rc, st = E.SeedInterval(iv[0], iv[1], q_len, E.STRAND_BOTH, 0, 2)
+    for rev, got in ((False, fw), (True, rc)):
+        a, b = (iv[0], iv[1]) if not rev else (q_len - iv[1], q_len - iv[0])
+        parts = []
+        for s in range(a, b, c.chunk):
+            seeds = c.host_seeds(s, min(s + c.chunk, b), rev)
+            if seeds.size:
+                parts.append(E.SeedAndFilter(seeds, rev, 0)[1:])
+        want = np.concatenate(parts) if parts else np.zeros(0, dtype=fw.dtype)
+        assert np.array_equal(got, want), rev

@@ -184,6 +184,14 @@ void sa_set_count_examined(int on);
  * (7*max(M) <= xdrop), 3 = packed 2-bit/4-bit upper-bound filter. */
 int sa_get_filter_mode(void);
 
+/* Seed lookup path of the device-seeded entry points (sa_seed_and_filter_range / _chunks, sa_seed_interval,
+ * sa_rm_mask_interval) on device 0: 0 = general path (seed words -> find_num_hits / find_hits shape, also used by the drop-in
+ * sa_seed_and_filter), 1 = table-direct (neighbourhood table + position probe, no seed words, no hit list), 2 = table-direct
+ * with target context in the table (the X-drop filter streams 32-byte records).  Chosen by available HBM;
+ * SEGALIGN_AMD_NO_CTX=1 / SEGALIGN_AMD_NO_TD=1 force 1 / 0.  Results are identical on every path. */
+int sa_get_lookup_mode(void);
+uint64_t sa_get_neighbourhood_entries(void); /* run entries of the neighbourhood table (0 when not built) */
+
 /* Per-kernel HIP-event timing on the engine's own streams (bench.py's roofline leg). */
 void sa_profile_enable(int on);
 void sa_profile_reset(void);

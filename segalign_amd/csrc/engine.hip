@@ -208,7 +208,7 @@ struct Counters {  // device-side scalars of one slot
     uint32_t n_long;  // candidates the filter forwarded to the exact kernel (this batch)
     uint32_t n_ent;   // entropy candidates (this batch)
     uint32_t n_heads; // run heads of the chain shortcut (this batch)
-    uint32_t pad2;
+    uint32_t n_l2;    // hits the context filter handed to the second level (this batch)
 };
 
 struct Slot {
@@ -220,7 +220,7 @@ struct Slot {
     DevBuf<uint8_t> scan_temp, sort_temp;
     DevBuf<Hit> hits;
     DevBuf<HspRec> recA, recB;
-    DevBuf<CandRec> cand_list;
+    DevBuf<CandRec> cand_list, l2_list;
     DevBuf<CandRec> chain_tmp, chain_sorted;  // chain shortcut of the exact stage
     DevBuf<uint32_t> chain_is_head, chain_heads, chain_bucket_cnt, chain_bucket_start;
     DevBuf<EntRec> ent_list;
@@ -282,7 +282,8 @@ struct DevCtx {
     // neighbourhood table (probe.hip): per key the concatenation of the buckets of the key's seed words
     std::mutex nbr_mu;
     uint64_t* nbr_start = nullptr;       // nkeys + 1
-    uint32_t* nbr_pos = nullptr;         // == pos_table when no transition word exists (nbr_alias)
+    uint32_t* nbr_pos = nullptr;         // == pos_table when no transition word exists (nbr_alias); null when nbr_ctx is built
+    CtxRec* nbr_ctx = nullptr;           // the runs WITH their target context (32 B per entry): context filter, extend.hip 1c
     bool nbr_alias = false;
     uint64_t nbr_total = 0;
     uint32_t nbr_tmask = 0;
@@ -319,6 +320,7 @@ static int g_packed_filter = 0;   // derived in InitializeProcessor: the packed 
 static int g_chain_sort_threads = 512;  // SEGALIGN_AMD_CHAIN_SORT_THREADS
 static int g_chunks_per_call = SA_MAX_CHUNKS;  // SEGALIGN_AMD_CHUNKS_PER_CALL: chunks sa_seed_interval hands to one multi-chunk call
 static int g_no_small_dedup = 0;  // SEGALIGN_AMD_NO_SMALL_DEDUP=1: always use the library sorts
+static int g_ctx = 1;             // neighbourhood table with target context when it fits (SEGALIGN_AMD_NO_CTX=1: positions only)
 static int g_td = 1;              // table-direct lookup (neighbourhood table + position probe, probe.hip); SEGALIGN_AMD_NO_TD=1 turns it off
 static int g_chain = 1;           // chain shortcut of the exact stage (SEGALIGN_AMD_NO_CHAIN=1 turns it off)
 static uint32_t CHAIN_CAP = 1u << 20;  // candidates per batch the chain buffers hold (SEGALIGN_AMD_CHAIN_CAP); larger batches fall back
@@ -416,6 +418,7 @@ static void slot_destroy(Slot& s) {
     s.sort_temp.release("sort_temp"); s.hits.release("hits"); s.recA.release("recA"); s.recB.release("recB");
     s.out16.release("out16");
     s.cand_list.release("candidate list");
+    s.l2_list.release("second-level list");
     s.chain_tmp.release("chain"); s.chain_sorted.release("chain"); s.chain_is_head.release("chain");
     s.chain_heads.release("chain"); s.chain_bucket_cnt.release("chain"); s.chain_bucket_start.release("chain"); s.ent_list.release("entropy list");
     s.cov_diff.release("coverage"); s.cov_pre.release("coverage"); s.cov_is_start.release("coverage");
@@ -598,7 +601,10 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     ea.td_rec = sl->td_rec.p;
                     ea.td_m = sl->h_td_plan[K - 1].m_hi;
                     ea.td_pos = dc->nbr_pos;
+                    ea.td_ctx = dc->nbr_ctx;
                     ea.seed_size = g_seed_size;
+                    if (ea.td_ctx) sl->l2_list.ensure((size_t)std::max<uint64_t>(1u << 16, bh / 8), "second-level list");
+                    ea.l2_count = &sl->d_cnt->n_l2;
                 } else if (!ca.raw_hits) {
                     sl->hits.ensure((size_t)bh, "hits");
                     ProfScope p(sl, "expand_hits");
@@ -674,7 +680,19 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     ea.cand_cap_recs = (uint32_t)std::min<size_t>(sl->cand_list.cap, 0xFFFFFFFFu);
                     ea.ent_list = sl->ent_list.p;
                     ea.ent_cap_recs = (uint32_t)std::min<size_t>(sl->ent_list.cap, 0xFFFFFFFFu);
-                    { ProfScope p(sl, "extend_filter");  launch_extend_filter(ea, st); }
+                    if (ea.td && ea.td_ctx) {
+                        // context filter over the table's own 32-byte records, then the packed filter on what it could not decide
+                        ea.l2_list = sl->l2_list.p;
+                        ea.l2_cap = (uint32_t)std::min<size_t>(sl->l2_list.cap, 0xFFFFFFFFu);
+                        { ProfScope p(sl, "extend_filter"); launch_extend_filter_ctx(ea, st); }
+                        ExtendArgs e2 = ea;
+                        e2.td = 0;
+                        e2.src_cand = 1;
+                        { ProfScope p(sl, "extend_filter2"); launch_extend_filter(e2, st); }
+                    } else {
+                        ProfScope p(sl, "extend_filter");
+                        launch_extend_filter(ea, st);
+                    }
                     if (ea.chain_cap) {
                         check_memcpy(hipMemsetAsync(sl->chain_bucket_cnt.p, 0, chain_num_buckets() * sizeof(uint32_t), st), "chain buckets");
                         { ProfScope p(sl, "chain_group"); launch_chain_group(ea, st); }
@@ -698,7 +716,9 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                         check_sync(st, "extend (no chain)");
                     }
                     const Counters& c = *sl->h_cnt;
-                    if (c.survivors <= ea.out_cap && c.n_long <= ea.cand_cap_recs && c.n_ent <= ea.ent_cap_recs) break;
+                    const bool l2_ok = !(ea.td && ea.td_ctx) || c.n_l2 <= ea.l2_cap;
+                    if (c.survivors <= ea.out_cap && c.n_long <= ea.cand_cap_recs && c.n_ent <= ea.ent_cap_recs && l2_ok) break;
+                    if (!l2_ok) sl->l2_list.ensure((size_t)c.n_l2, "second-level list(grow)");  // (the later stages saw a truncated list)
                     // an overflowing long list also truncates what the later kernels saw: size everything from the
                     // counts of this attempt (upper bounds for the rerun: survivors <= hits, entropy candidates <= hits)
                     if (c.n_long > ea.cand_cap_recs) sl->cand_list.ensure((size_t)c.n_long, "candidate list(grow)");
@@ -936,8 +956,10 @@ __global__ void widen_u32_kernel(const uint32_t* __restrict__ in, uint64_t* __re
 static void nbr_release(DevCtx* dc) {
     dev_free(dc->nbr_start, "nbr_start");
     if (!dc->nbr_alias) dev_free(dc->nbr_pos, "nbr_pos");
+    dev_free(dc->nbr_ctx, "nbr_ctx");
     dc->nbr_start = nullptr;
     dc->nbr_pos = nullptr;
+    dc->nbr_ctx = nullptr;
     dc->nbr_alias = false;
     dc->nbr_total = 0;
     dc->nbr_state = 0;
@@ -957,41 +979,55 @@ static bool ensure_nbr(DevCtx* dc) {
     dc->nbr_state = -1;
     const uint32_t nkeys = dc->nkeys;
     dc->nbr_start = (uint64_t*)dev_malloc(((size_t)nkeys + 1) * sizeof(uint64_t), "nbr_start");
+    uint64_t total = dc->num_index;
     if (tmask == 0) {  // one word per position: the runs ARE the buckets
         hipLaunchKernelGGL(widen_u32_kernel, dim3(4096), dim3(256), 0, st, dc->bucket_start, dc->nbr_start, nkeys + 1);
         check_launch("nbr widen");
         check_sync(st, "nbr widen");
-        dc->nbr_pos = dc->pos_table;
-        dc->nbr_alias = true;
-        dc->nbr_total = dc->num_index;
-        dc->nbr_state = 1;
-        return true;
+    } else {
+        uint32_t* cnt = (uint32_t*)dev_malloc(((size_t)nkeys + 1) * sizeof(uint32_t), "nbr counts");
+        void* scan_tmp = dev_malloc(scan_temp_bytes(nkeys), "scan temp");
+        check_memcpy(hipMemsetAsync(cnt + nkeys, 0, sizeof(uint32_t), st), "nbr overflow flag");  // cnt[nkeys] doubles as the flag
+        launch_nbr_count(dc->bucket_start, nkeys, tmask, g_shape.weight, cnt, cnt + nkeys, st);
+        launch_exclusive_scan_u64(cnt, dc->nbr_start, nkeys, scan_tmp, st);
+        check_launch("nbr count/scan");
+        uint32_t overflow = 0;
+        check_memcpy(hipMemcpyAsync(&total, dc->nbr_start + nkeys, sizeof(uint64_t), hipMemcpyDeviceToHost, st), "nbr total");
+        check_memcpy(hipMemcpyAsync(&overflow, cnt + nkeys, sizeof(uint32_t), hipMemcpyDeviceToHost, st), "nbr overflow");
+        check_sync(st, "nbr count");
+        dev_free(cnt, "nbr counts");
+        dev_free(scan_tmp, "scan temp");
+        if (overflow) {
+            dev_free(dc->nbr_start, "nbr_start");
+            dc->nbr_start = nullptr;
+            return false;
+        }
     }
-    uint32_t* cnt = (uint32_t*)dev_malloc(((size_t)nkeys + 1) * sizeof(uint32_t), "nbr counts");
-    void* scan_tmp = dev_malloc(scan_temp_bytes(nkeys), "scan temp");
-    check_memcpy(hipMemsetAsync(cnt + nkeys, 0, sizeof(uint32_t), st), "nbr overflow flag");  // cnt[nkeys] doubles as the flag
-    launch_nbr_count(dc->bucket_start, nkeys, tmask, g_shape.weight, cnt, cnt + nkeys, st);
-    launch_exclusive_scan_u64(cnt, dc->nbr_start, nkeys, scan_tmp, st);
-    check_launch("nbr count/scan");
-    uint64_t total = 0;
-    uint32_t overflow = 0;
-    check_memcpy(hipMemcpyAsync(&total, dc->nbr_start + nkeys, sizeof(uint64_t), hipMemcpyDeviceToHost, st), "nbr total");
-    check_memcpy(hipMemcpyAsync(&overflow, cnt + nkeys, sizeof(uint32_t), hipMemcpyDeviceToHost, st), "nbr overflow");
-    check_sync(st, "nbr count");
-    dev_free(cnt, "nbr counts");
-    dev_free(scan_tmp, "scan temp");
     size_t free_b = 0, total_b = 0;
     hipMemGetInfo(&free_b, &total_b);
-    const size_t need = (size_t)std::max<uint64_t>(total, 1) * sizeof(uint32_t);
-    if (overflow || need + ((size_t)8 << 30) > free_b) {  // keep 8 GiB for the slots' work buffers
+    const size_t reserve = (size_t)8 << 30;  // keep 8 GiB for the slots' work buffers
+    const size_t need_ctx = (size_t)std::max<uint64_t>(total, 1) * sizeof(CtxRec);
+    const size_t need_pos = (size_t)std::max<uint64_t>(total, 1) * sizeof(uint32_t);
+    if (g_ctx && dc->ref2.base && need_ctx + reserve <= free_b) {
+        // runs with their target context: 32 bytes per entry (33 GB for a 100 Mbp block with transitions)
+        dc->nbr_ctx = (CtxRec*)dev_malloc(need_ctx, "nbr_ctx");
+        launch_nbr_fill_ctx(dc->bucket_start, dc->pos_table, nkeys, tmask, g_shape.weight, dc->nbr_start, dc->ref2.base, dc->ref2.stride,
+                            g_seed_size, dc->nbr_ctx, st);
+        check_launch("nbr fill ctx");
+        check_sync(st, "nbr fill ctx");
+    } else if (tmask == 0) {
+        dc->nbr_pos = dc->pos_table;
+        dc->nbr_alias = true;
+    } else if (need_pos + reserve <= free_b) {
+        dc->nbr_pos = (uint32_t*)dev_malloc(need_pos, "nbr_pos");
+        launch_nbr_fill(dc->bucket_start, dc->pos_table, nkeys, tmask, g_shape.weight, dc->nbr_start, dc->nbr_pos, st);
+        check_launch("nbr fill");
+        check_sync(st, "nbr fill");
+    } else {
         dev_free(dc->nbr_start, "nbr_start");
         dc->nbr_start = nullptr;
         return false;
     }
-    dc->nbr_pos = (uint32_t*)dev_malloc(need, "nbr_pos");
-    launch_nbr_fill(dc->bucket_start, dc->pos_table, nkeys, tmask, g_shape.weight, dc->nbr_start, dc->nbr_pos, st);
-    check_launch("nbr fill");
-    check_sync(st, "nbr fill");
     dc->nbr_total = total;
     dc->nbr_state = 1;
     return true;
@@ -1187,6 +1223,7 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
         if (getenv("SEGALIGN_AMD_NO_FAST_FILTER")) { g_fast_filter = 0; g_packed_filter = 0; }
         g_chain = getenv("SEGALIGN_AMD_NO_CHAIN") ? 0 : 1;
         g_td = getenv("SEGALIGN_AMD_NO_TD") ? 0 : 1;
+        g_ctx = getenv("SEGALIGN_AMD_NO_CTX") ? 0 : 1;
         g_chain_sort_threads = 512;
         if (const char* e = getenv("SEGALIGN_AMD_CHAIN_SORT_THREADS")) g_chain_sort_threads = std::max(64, std::min(512, atoi(e) & ~63));
         if (const char* e = getenv("SEGALIGN_AMD_CHAIN_CAP")) CHAIN_CAP = (uint32_t)std::max(1, atoi(e));
@@ -1871,6 +1908,14 @@ int sa_get_filter_mode(void) {  // which X-drop filter kernel the next plain (no
     if (g_count_examined) return g_fast_filter ? 1 : 0;
     return g_packed_filter ? 3 : g_fast_filter;
 }
+int sa_get_lookup_mode(void) {  // how device-seeded calls look seeds up on device 0 right now (builds the table if needed)
+    if (g_ndev <= 0 || !g_proc_init) return 0;
+    DevCtx* dc = g_dev[0];
+    check_set_device(dc->dev, "lookup mode");
+    if (!(g_td && g_packed_filter && !g_count_examined && dc->ref2.base && ensure_nbr(dc))) return 0;
+    return dc->nbr_ctx ? 2 : 1;
+}
+uint64_t sa_get_neighbourhood_entries(void) { return (g_ndev > 0 && g_dev[0]->nbr_state == 1) ? g_dev[0]->nbr_total : 0; }
 void sa_profile_enable(int on) { g_prof_on = on != 0; }
 void sa_profile_reset(void) {
     std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -439,15 +439,9 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 constexpr int PK_THREADS = 512;
 constexpr int PK_TAB = 4096;
 
-// TD = true: the anchors are not read from a hit list but straight out of the neighbourhood table (probe.hip): every wave
-// owns a CONTIGUOUS range of the call's hit indices, keeps the compacted position m0 that holds the first hit of its next
-// 64-hit buffer, loads the 64 following position prefixes with one coalesced load, finds every lane's position with six
-// shuffles and gathers the run entry.  No hit list is written or read (16*S + 4*H instead of 16*S + 12*H).
-template <bool TD>
-__global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(ExtendArgs a) {
-    __shared__ uint32_t s_pk[PK_TAB];
-    __shared__ CandRec s_cand[PK_THREADS / 64][STAGE_CAP];
-    for (int i = threadIdx.x; i < PK_TAB; i += PK_THREADS) {
+// ---- pair table: entry (4 target bits | query byte << 4) = {s0, s0 + s1} as two int16 (see above) ---------------------
+__device__ __forceinline__ void pk_table_init(uint32_t* __restrict__ s_pk, const int* __restrict__ sub_mat, int nthreads) {
+    for (int i = threadIdx.x; i < PK_TAB; i += nthreads) {
         const int rp = i & 15, qb = i >> 4;  // target bits select the LDS bank: they differ between lanes, query bytes rarely do
         const bool rev = (qb & 0x88) == 0x88;
         int q0 = qb & 7, q1 = (qb >> 4) & 7, r0 = rp & 3, r1 = rp >> 2;
@@ -457,14 +451,79 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
             r1 = ((r1 & 1) << 1) | (r1 >> 1);
         }
         auto score = [&](int r, int q) -> int {
-            int v = a.sub_mat[r * 8 + q];
+            int v = sub_mat[r * 8 + q];
             if (r == 0)  // row 0 also stands for every target code >= 4
-                for (int rr = 4; rr < 8; rr++) v = max(v, a.sub_mat[rr * 8 + q]);
+                for (int rr = 4; rr < 8; rr++) v = max(v, sub_mat[rr * 8 + q]);
             return max(v, -16383);
         };
         const int s0 = score(r0, q0), s1 = score(r1, q1);
         s_pk[i] = ((uint32_t)s0 & 0xffffu) | ((uint32_t)(s0 + s1) << 16);
     }
+}
+
+// ---- table-direct cursor (probe.hip): which run entry is hit g of the call? ------------------------------------------
+// A wave owns a CONTIGUOUS range of the call's hit indices and walks it in 64-hit buffers.  Invariant:
+// td_rec[m0].prefix <= g0 < td_rec[m0 + 1].prefix for the next buffer start g0.  The window -- records m0 .. m0 + 63, one
+// per lane, plus the prefix of record m0 + 64 in lane 0 -- is loaded ONE BUFFER AHEAD, so locate() never waits for memory:
+// six shuffles find every lane's record (every record holds >= 1 hit, so 64 records always cover 64 hits), three more
+// fetch its run offset and query position.
+struct TdCursor {
+    uint32_t m0;
+    TdRec win;
+    uint32_t win64;
+    __device__ __forceinline__ void load_window(const ExtendArgs& a, int lane) {
+        const uint32_t mi = m0 + (uint32_t)lane;
+        win = a.td_rec[mi < a.td_m ? mi : a.td_m];
+        if (mi > a.td_m) win.prefix = 0xFFFFFFFFu;  // past the sentinel
+        win64 = 0xFFFFFFFFu;
+        if (lane == 0 && m0 + 64u <= a.td_m) win64 = a.td_rec[m0 + 64u].prefix;
+    }
+    __device__ __forceinline__ void seek(const ExtendArgs& a, int lane, uint32_t g0) {
+        uint32_t lo = 0, hi = a.td_m;  // td_rec[0].prefix = 0 <= g0 < td_rec[td_m].prefix = num_hits
+        while (lo + 1 < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (a.td_rec[mid].prefix <= g0) lo = mid; else hi = mid;
+        }
+        m0 = lo;
+        load_window(a, lane);
+    }
+    // hit g0 + lane: entry = index of its run entry in the neighbourhood table, qpos = its query position (seed start);
+    // then advances the cursor to g0 + 64 and issues the load of the next window
+    __device__ __forceinline__ void locate(const ExtendArgs& a, int lane, uint32_t g0, uint64_t& entry, uint32_t& qpos) {
+        // R: first hit of the lane's record relative to g0; lanes >= 1 hold values >= 1 (invariant), lane 0 counts as 0;
+        // records past the sentinel as infinity
+        const uint32_t R = lane == 0 ? 0u : (win.prefix == 0xFFFFFFFFu ? 0xFFFFFFFFu : win.prefix - g0);
+        const uint32_t d0 = g0 - (uint32_t)__builtin_amdgcn_readfirstlane((int)win.prefix);  // hits of record m0 in earlier buffers
+        uint32_t lo = 0, rv = 0;  // largest window entry whose first hit is <= this lane's hit
+#pragma unroll
+        for (uint32_t step = 32; step >= 1; step >>= 1) {
+            const uint32_t cand = lo + step;
+            const uint32_t v = (uint32_t)__shfl((int)R, (int)(cand & 63u), 64);
+            if (cand < 64u && v <= (uint32_t)lane) { lo = cand; rv = v; }
+        }
+        const uint32_t o_lo = (uint32_t)__shfl((int)(uint32_t)win.off, (int)lo, 64);
+        const uint32_t o_hi = (uint32_t)__shfl((int)(uint32_t)(win.off >> 32), (int)lo, 64);
+        qpos = (uint32_t)__shfl((int)win.qpos, (int)lo, 64);
+        const uint32_t k = lo == 0u ? d0 + (uint32_t)lane : (uint32_t)lane - rv;
+        entry = (((uint64_t)o_hi << 32) | o_lo) + k;
+        // the record that holds hit g0 + 64: entries 1..63 by their lanes, entry 64 by lane 0
+        const bool adv = lane == 0 ? (win64 != 0xFFFFFFFFu && win64 - g0 <= 64u) : (R <= 64u);
+        m0 += (uint32_t)__popcll(__ballot(adv));
+        load_window(a, lane);
+    }
+};
+
+// SRC: where the anchors come from.  SRC_HITS: the hit list of the general path (64-hit buffers dealt round-robin to the
+// waves).  SRC_TD: straight out of the neighbourhood table runs -- no hit list is written or read (16*S + 4*H instead of
+// 16*S + 12*H).  SRC_CAND: the {ref_loc, query_loc, hidx} records the context filter (1c) could not decide.
+enum : int { SRC_HITS = 0, SRC_TD = 1, SRC_CAND = 2 };
+
+template <int SRC>
+__global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(ExtendArgs a) {
+    constexpr bool TD = SRC == SRC_TD;
+    __shared__ uint32_t s_pk[PK_TAB];
+    __shared__ CandRec s_cand[PK_THREADS / 64][STAGE_CAP];
+    pk_table_init(s_pk, a.sub_mat, PK_THREADS);
     __syncthreads();
     CandRec* stage = s_cand[threadIdx.x >> 6];
     int n_stage = 0;
@@ -477,7 +536,8 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
 
     // ---- the wave's queue of 64-hit buffers: round-robin over all waves of the grid (hit list), or one contiguous range
     //      per wave (TD) ----
-    const uint64_t num_buf = (a.num_hits + 63) >> 6;
+    const uint64_t total_hits = SRC == SRC_CAND ? (uint64_t)min(*a.l2_count, a.l2_cap) : a.num_hits;
+    const uint64_t num_buf = (total_hits + 63) >> 6;
     const uint64_t W = (uint64_t)gridDim.x * (PK_THREADS / 64);
     const uint64_t wid = (uint64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (PK_THREADS / 64) + (threadIdx.x >> 6)));
     const uint64_t G = TD ? 1ull : W;
@@ -486,70 +546,40 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
     uint64_t nxt_buf = cur_buf + G;
     auto buf_count = [&](uint64_t b) -> int {
         if (b >= buf_end) return 0;
-        uint64_t rem = a.num_hits - (b << 6);
+        uint64_t rem = total_hits - (b << 6);
         return rem >= 64 ? 64 : (int)rem;
     };
-    // TD state: td_rec[td_m0].prefix <= 64 * (next buffer to fetch) < td_rec[td_m0 + 1].prefix.  The window -- the records
-    // td_m0 .. td_m0 + 63, one per lane, plus the prefix of record td_m0 + 64 in lane 0 -- is loaded ONE FETCH AHEAD, so a
-    // fetch itself never waits for memory: it searches the window held in registers with shuffles, issues the gather of the
-    // run entries (consumed a whole buffer later) and the load of the next window.
-    uint32_t td_m0 = 0;
-    TdRec win = {0u, 0u, 0ull};
-    uint32_t win64 = 0;
-    auto load_window = [&]() {
-        const uint32_t mi = td_m0 + (uint32_t)lane;
-        win = a.td_rec[mi < a.td_m ? mi : a.td_m];
-        if (mi > a.td_m) win.prefix = 0xFFFFFFFFu;  // past the sentinel
-        win64 = 0xFFFFFFFFu;
-        if (lane == 0 && td_m0 + 64u <= a.td_m) win64 = a.td_rec[td_m0 + 64u].prefix;
-    };
-    if (TD && cur_buf < buf_end) {
-        const uint32_t g0 = (uint32_t)(cur_buf << 6);
-        uint32_t lo = 0, hi = a.td_m;  // td_rec[0].prefix = 0 <= g0 < td_rec[td_m].prefix = num_hits
-        while (lo + 1 < hi) {
-            const uint32_t mid = lo + ((hi - lo) >> 1);
-            if (a.td_rec[mid].prefix <= g0) lo = mid; else hi = mid;
-        }
-        td_m0 = lo;
-        load_window();
-    }
+    TdCursor cursor = {0u, {0u, 0u, 0ull}, 0u};
+    if (TD && cur_buf < buf_end) cursor.seek(a, lane, (uint32_t)(cur_buf << 6));
+    uint32_t f_idx = 0;  // SRC_CAND: the fetched record's own hit index
     auto fetch = [&](uint64_t b, int cnt) -> Hit {
         Hit h = {0u, 0u};
-        if (!TD) {
+        f_idx = (uint32_t)(b << 6) + (uint32_t)lane;
+        if (SRC == SRC_HITS) {
             if (lane < cnt) h = a.hits[(b << 6) + lane];
-            return h;
+        } else if (SRC == SRC_CAND) {
+            if (lane < cnt) {
+                const CandRec c = a.l2_list[(b << 6) + lane];
+                h.ref_loc = c.ref_loc;
+                h.query_loc = c.query_loc;
+                f_idx = c.hidx;
+            }
+        } else if (cnt > 0) {  // (wave-uniform)
+            uint64_t entry;
+            uint32_t qp;
+            cursor.locate(a, lane, (uint32_t)(b << 6), entry, qp);
+            if (lane < cnt) {
+                h.ref_loc = a.td_pos[entry] + a.seed_size;  // :220
+                h.query_loc = qp + a.seed_size;             // :204
+            }
         }
-        if (cnt == 0) return h;  // wave-uniform
-        const uint32_t g0 = (uint32_t)(b << 6);
-        // R: first hit of the lane's record relative to g0; lanes >= 1 hold values >= 1 (invariant), lane 0 counts as 0;
-        // records past the sentinel as infinity (prefix differences are < 2^32, the clamp keeps the order)
-        const uint32_t d = win.prefix - g0;
-        const uint32_t R = lane == 0 ? 0u : (win.prefix == 0xFFFFFFFFu ? 0xFFFFFFFFu : d);
-        const uint32_t d0 = g0 - (uint32_t)__builtin_amdgcn_readfirstlane((int)win.prefix);  // hits of record td_m0 in earlier buffers
-        uint32_t lo = 0, rv = 0;  // largest window entry whose first hit is <= this lane's hit
-#pragma unroll
-        for (uint32_t step = 32; step >= 1; step >>= 1) {
-            const uint32_t cand = lo + step;
-            const uint32_t v = (uint32_t)__shfl((int)R, (int)(cand & 63u), 64);
-            if (cand < 64u && v <= (uint32_t)lane) { lo = cand; rv = v; }
-        }
-        const uint32_t o_lo = (uint32_t)__shfl((int)(uint32_t)win.off, (int)lo, 64);
-        const uint32_t o_hi = (uint32_t)__shfl((int)(uint32_t)(win.off >> 32), (int)lo, 64);
-        const uint32_t qp = (uint32_t)__shfl((int)win.qpos, (int)lo, 64);
-        if (lane < cnt) {
-            const uint32_t k = lo == 0u ? d0 + (uint32_t)lane : (uint32_t)lane - rv;
-            h.ref_loc = a.td_pos[(((uint64_t)o_hi << 32) | o_lo) + k] + a.seed_size;  // :220
-            h.query_loc = qp + a.seed_size;                                          // :204
-        }
-        // advance to the record that holds hit g0 + 64: entries 1..63 by their lanes, entry 64 by lane 0; next window
-        const bool adv = lane == 0 ? (win64 != 0xFFFFFFFFu && win64 - g0 <= 64u) : (R <= 64u);
-        td_m0 += (uint32_t)__popcll(__ballot(adv));
-        load_window();
         return h;
     };
     int buf_cnt = buf_count(cur_buf), nxt_cnt = buf_count(nxt_buf), consumed = 0;
     Hit buf = fetch(cur_buf, buf_cnt);
+    uint32_t buf_idx = f_idx;
     Hit nxt = fetch(nxt_buf, nxt_cnt);
+    uint32_t nxt_idx = f_idx;
 
     // ---- per-lane state ----
     int phase = PH_FIN;
@@ -675,12 +705,14 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
                 if (avail <= 0) {
                     if (nxt_cnt == 0) break;  // queue exhausted
                     buf = nxt;
+                    buf_idx = nxt_idx;
                     buf_cnt = nxt_cnt;
                     cur_buf = nxt_buf;
                     consumed = 0;
                     nxt_buf += G;
                     nxt_cnt = buf_count(nxt_buf);
                     nxt = fetch(nxt_buf, nxt_cnt);
+                    nxt_idx = f_idx;
                     continue;
                 }
                 const int rank = __popcll(need & lane_lt);
@@ -688,10 +720,11 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
                 const int src = (consumed + rank) & 63;
                 const uint32_t hr = (uint32_t)__shfl((int)buf.ref_loc, src, 64);
                 const uint32_t hq = (uint32_t)__shfl((int)buf.query_loc, src, 64);
+                const uint32_t hi = SRC == SRC_CAND ? (uint32_t)__shfl((int)buf_idx, src, 64) : (uint32_t)(cur_buf << 6) + (uint32_t)src;
                 if (take) {
                     mine.ref_loc = hr;
                     mine.query_loc = hq;
-                    mine_idx = (uint32_t)(cur_buf << 6) + (uint32_t)src;
+                    mine_idx = hi;
                     got = true;
                 }
                 consumed += min(__popcll(need), avail);
@@ -726,6 +759,133 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
         if (__ballot(phase != PH_IDLE) == 0ull) break;
     }
     stage_flush(stage, n_stage, a.cand_list, a.cand_count, a.cand_cap_recs, lane);
+}
+
+// =====================================================================================================================
+// 1c. the X-drop filter on the CONTEXT table: the target bases travel with the seed table entry, no random target access
+// =====================================================================================================================
+// The packed filter (1b) is priced in random 128-byte target lines: one per hit, ~57 G lines/s on the whole chip (tools/micro/
+// gather_bw.hip) -- 52 M hits of a four-chunk call cannot take less than ~0.9 ms however little arithmetic they need.  With
+// 288 GB of HBM the neighbourhood table (probe.hip) can afford to carry, next to every seed position, the 2-bit target bases
+// the filter looks at: 48 to the right of the anchor and 64 to the left (CtxRec, 32 bytes).  The hits of a call are then ONE
+// SEQUENTIAL STREAM of 32-byte records, the query window of a wave's 64 hits is a couple of L1-resident lines, and the filter
+// becomes an arithmetic kernel.  Because every hit now costs the same (3 + 4 steps of 16 bases, no refill), the persistent-
+// lane machinery of 1b disappears: a wave walks its contiguous range of 64-hit buffers in lockstep.
+// Verdicts (all conservative -- the scores are the same upper bounds as in 1b):
+//   both sides dropped inside the context and bestR + bestL cannot pass (:608-633)  -> rejected here (~96 % of all hits)
+//   a side still alive at the end of its context (1.6 % right, 2.4 % left on random hits), or the bound passes
+//                                                          -> {ref_loc, query_loc, hidx} to the second level: kernel 1b on
+//                                                             that list (SRC_CAND), which decides between reject and the
+//                                                             exact kernels exactly as before.
+// one 16-base step: td = 16 target bases (2 bit each), q0 | q1 = 16 query bases (4 bit each), all in walking order
+__device__ __forceinline__ void pk_step16(const uint32_t* __restrict__ s_pk, uint32_t td, uint32_t q0, uint32_t q1, s16x2& T, s16x2& M) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t qd = j < 4 ? q0 : q1;
+        uint32_t qaddr;  // (query byte j) << 6 in one SDWA shift
+        switch (j & 3) {
+            case 0: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(qaddr) : "v"(6), "v"(qd)); break;
+            case 1: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(qaddr) : "v"(6), "v"(qd)); break;
+            case 2: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(qaddr) : "v"(6), "v"(qd)); break;
+            default: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(qaddr) : "v"(6), "v"(qd)); break;
+        }
+        const uint32_t rp = (td >> (4 * j)) & 15u;
+        const uint32_t addr = (rp << 2) | qaddr;  // byte address of entry rp | qbyte << 4
+        const s16x2 e = __builtin_bit_cast(s16x2, *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_pk) + addr));
+        const s16x2 Tb = T.yy;
+        T = __builtin_elementwise_add_sat(Tb, e);  // {t + s0, t + s0 + s1}
+        M = __builtin_elementwise_max(M, T);
+    }
+}
+
+__global__ __launch_bounds__(PK_THREADS) void extend_filter_ctx_kernel(ExtendArgs a) {
+    __shared__ uint32_t s_pk[PK_TAB];
+    __shared__ CandRec s_cand[PK_THREADS / 64][STAGE_CAP];
+    pk_table_init(s_pk, a.sub_mat, PK_THREADS);
+    __syncthreads();
+    CandRec* stage = s_cand[threadIdx.x >> 6];
+    int n_stage = 0;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    const int xdrop = a.xdrop;
+    const uint4* __restrict__ ctx = reinterpret_cast<const uint4*>(a.td_ctx);
+
+    const uint64_t num_buf = (a.num_hits + 63) >> 6;
+    const uint64_t W = (uint64_t)gridDim.x * (PK_THREADS / 64);
+    const uint64_t wid = (uint64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (PK_THREADS / 64) + (threadIdx.x >> 6)));
+    const uint64_t b_lo = (wid * num_buf) / W, b_hi = ((wid + 1) * num_buf) / W;
+    if (b_lo >= b_hi) return;
+    TdCursor cursor = {0u, {0u, 0u, 0ull}, 0u};
+    cursor.seek(a, lane, (uint32_t)(b_lo << 6));
+
+    for (uint64_t b = b_lo; b < b_hi; b++) {
+        const uint64_t rem = a.num_hits - (b << 6);
+        const int cnt = rem >= 64 ? 64 : (int)rem;
+        uint64_t entry;
+        uint32_t qp;
+        cursor.locate(a, lane, (uint32_t)(b << 6), entry, qp);
+        const bool valid = lane < cnt;
+        uint4 c0 = {0u, 0u, 0u, 0u}, c1 = {0u, 0u, 0u, 0u};
+        if (valid) {
+            c0 = ctx[2 * entry];      // pos, r0, r1, r2
+            c1 = ctx[2 * entry + 1];  // l0 .. l3
+        }
+        const uint32_t ref_loc = c0.x + a.seed_size;   // :220
+        const uint32_t query_loc = qp + a.seed_size;   // :204
+        // query windows: 48 bases from the anchor on, 64 bases before it (copy query_loc & 1 is byte aligned for both)
+        const uint8_t* qb = a.query4 + (size_t)(query_loc & 1u) * a.query4_stride + (query_loc >> 1);
+        uint4 qr0 = {0u, 0u, 0u, 0u}, qr1 = qr0, ql0 = qr0, ql1 = qr0;
+        if (valid) {
+            qr0 = load16u(qb);
+            qr1 = load16u(qb + 16);
+            ql0 = load16u(qb - 32);
+            ql1 = load16u(qb - 16);
+        }
+        bool skip = !valid;
+        if (a.rm) skip = skip || !(ref_loc >= a.rm_win_start && ref_loc <= a.rm_win_end);  // rm :239-244,:305-333: total stays 0
+        // ---- right side (:326-453): 3 steps ----
+        s16x2 T = {0, 0}, M = {0, 0};
+        bool alive = !skip;
+        int m = 0;
+#pragma unroll
+        for (int st = 0; st < 3; st++) {
+            if (alive) {
+                const uint32_t td = st == 0 ? c0.y : st == 1 ? c0.z : c0.w;
+                const uint32_t q0 = st == 0 ? qr0.x : st == 1 ? qr0.z : qr1.x;
+                const uint32_t q1 = st == 0 ? qr0.y : st == 1 ? qr0.w : qr1.y;
+                pk_step16(s_pk, td, q0, q1, T, M);
+                m = max((int)M.x, (int)M.y);
+                alive = (m - (int)T.y) <= xdrop;  // :374, looked at once per 16 bases
+            }
+        }
+        bool undecided = alive;  // still walking at the end of the context
+        const int bestR = m;
+        // ---- left side (:478-604): 4 steps on the pre-reversed context, query bytes reversed + flagged ----
+        T = (s16x2){0, 0};
+        M = (s16x2){0, 0};
+        alive = !skip;
+        m = 0;
+        {
+            const uint32_t RV = 0x00010203u, D = 0x88888888u;
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+                if (alive) {
+                    const uint32_t td = st == 0 ? c1.x : st == 1 ? c1.y : st == 2 ? c1.z : c1.w;
+                    const uint32_t a0 = st == 0 ? ql1.w : st == 1 ? ql1.y : st == 2 ? ql0.w : ql0.y;
+                    const uint32_t a1 = st == 0 ? ql1.z : st == 1 ? ql1.x : st == 2 ? ql0.z : ql0.x;
+                    pk_step16(s_pk, td, __builtin_amdgcn_perm(0u, a0, RV) | D, __builtin_amdgcn_perm(0u, a1, RV) | D, T, M);
+                    m = max((int)M.x, (int)M.y);
+                    alive = (m - (int)T.y) <= xdrop;  // :523
+                }
+            }
+        }
+        undecided = undecided || alive;
+        const bool fwd = !skip && (undecided || classify(a, bestR + m) != 0);
+        CandRec cr;
+        cr.ref_loc = ref_loc; cr.query_loc = query_loc; cr.hidx = (uint32_t)(b << 6) + (uint32_t)lane;
+        stage_append(stage, n_stage, fwd, cr, a.l2_list, a.l2_count, a.l2_cap, lane, lane_lt);
+    }
+    stage_flush(stage, n_stage, a.l2_list, a.l2_count, a.l2_cap, lane);
 }
 
 // =====================================================================================================================
@@ -1140,13 +1300,27 @@ void launch_extend_filter(const ExtendArgs& a, hipStream_t s) {
     const uint32_t blocks = (uint32_t)((waves + 3) / 4);
     if (!a.examined && a.fast_filter == 3) {
         const uint32_t pblocks = (uint32_t)((waves + PK_THREADS / 64 - 1) / (PK_THREADS / 64));
-        if (a.td) hipLaunchKernelGGL(extend_filter_packed_kernel<true>, dim3(pblocks), dim3(PK_THREADS), 0, s, a);
-        else hipLaunchKernelGGL(extend_filter_packed_kernel<false>, dim3(pblocks), dim3(PK_THREADS), 0, s, a);
+        if (a.src_cand) {  // second level behind the context filter: the count lives on the device, the grid is fixed
+            hipLaunchKernelGGL(extend_filter_packed_kernel<SRC_CAND>, dim3(256), dim3(PK_THREADS), 0, s, a);
+        } else if (a.td) hipLaunchKernelGGL(extend_filter_packed_kernel<SRC_TD>, dim3(pblocks), dim3(PK_THREADS), 0, s, a);
+        else hipLaunchKernelGGL(extend_filter_packed_kernel<SRC_HITS>, dim3(pblocks), dim3(PK_THREADS), 0, s, a);
         return;
     }
     if (a.examined) hipLaunchKernelGGL((extend_filter_kernel<true, false>), dim3(blocks), dim3(EXT_THREADS), 0, s, a);
     else if (a.fast_filter) hipLaunchKernelGGL((extend_filter_kernel<false, true>), dim3(blocks), dim3(EXT_THREADS), 0, s, a);
     else hipLaunchKernelGGL((extend_filter_kernel<false, false>), dim3(blocks), dim3(EXT_THREADS), 0, s, a);
+}
+
+// context filter (1c): table-direct calls whose neighbourhood table carries the target context; fills a.l2_list
+void launch_extend_filter_ctx(const ExtendArgs& a, hipStream_t s) {
+    if (a.num_hits == 0) return;
+    const uint64_t num_buf = (a.num_hits + 63) / 64;
+    uint64_t waves = num_buf / 4;  // every buffer costs the same: a few buffers per wave are enough to amortise the set-up
+    const uint64_t max_waves = a.max_waves ? a.max_waves : 8192u;
+    if (waves > max_waves) waves = max_waves;
+    if (waves < 8) waves = 8;
+    const uint32_t blocks = (uint32_t)((waves + PK_THREADS / 64 - 1) / (PK_THREADS / 64));
+    hipLaunchKernelGGL(extend_filter_ctx_kernel, dim3(blocks), dim3(PK_THREADS), 0, s, a);
 }
 
 void launch_chain_group(const ExtendArgs& a, hipStream_t s) {  // chain_bucket_cnt must be zero on entry

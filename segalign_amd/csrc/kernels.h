@@ -54,6 +54,12 @@ struct TdRec {                // table-direct lookup (probe.hip): a non-empty qu
     uint64_t off;             // offset of the position's run in the neighbourhood table
 };
 
+struct CtxRec {               // neighbourhood table WITH target context (probe.hip): the X-drop filter never touches the target
+    uint32_t pos;             // seed START position in the target (+ seed_size = anchor)
+    uint32_t r[3];            // 48 bases right of the anchor (anchor, anchor+1, ...), 2 bits per base, first base in the low bits
+    uint32_t l[4];            // 64 bases left of the anchor in WALKING order (anchor-1, anchor-2, ...), every dword bit-reversed
+};                            // (which also swaps the two bits of a code: the filter's pair table decodes that, extend.hip)
+
 struct ExtendArgs {
     const uint8_t* ref2;      // packed filter: 2-bit target, phase copy k at ref2 + k*ref2_stride, overlapped-line layout
     size_t ref2_stride;
@@ -97,6 +103,11 @@ struct ExtendArgs {
     const TdRec* td_rec;        // [td_m + 1] one record per NON-EMPTY query position, in query order; td_rec[td_m].prefix = num_hits
     uint32_t td_m;
     const uint32_t* td_pos;     // neighbourhood table runs: seed START positions in the target (+ seed_size = anchor, :220)
+    const CtxRec* td_ctx;       // != null: the runs carry their target context (then td_pos is unused): context filter + second level
+    CandRec* l2_list;           // hits the context filter could not decide (walk alive at the end of the context, or bound passes)
+    uint32_t* l2_count;
+    uint32_t l2_cap;
+    int src_cand;               // packed filter reads its anchors from l2_list / *l2_count instead of `hits`
     uint32_t seed_size;
     uint64_t num_hits;
     uint64_t hit_base;        // global index of hits[0] inside the call (segment boundaries are global)
@@ -164,6 +175,7 @@ void launch_plan(const uint64_t* hit_prefix_excl, uint32_t num_seeds, uint64_t m
 
 // ---- extend.hip ------------------------------------------------------------------------------------------------
 void launch_extend_filter(const ExtendArgs& a, hipStream_t s);   // hits -> candidates
+void launch_extend_filter_ctx(const ExtendArgs& a, hipStream_t s);  // table-direct hits + their target context -> l2_list
 void launch_extend_exact(const ExtendArgs& a, hipStream_t s);    // candidates -> survivors + entropy records
 // chain shortcut: keys -> (sort, dedup.hip) -> links/run heads -> one exact extension per run
 void launch_chain_group(const ExtendArgs& a, hipStream_t s);

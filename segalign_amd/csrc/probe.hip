@@ -68,6 +68,44 @@ __global__ __launch_bounds__(256) void nbr_fill_kernel(const uint32_t* __restric
     }
 }
 
+// The same fill, but every entry becomes a 32-byte CtxRec: the seed position plus the 2-bit target bases the X-drop filter
+// may look at -- 48 right of the anchor, 64 left of it -- cut out of the 2-bit phase copies of the target (encode.hip; the
+// anchor's [-64, +64) bases are 32 contiguous bytes of ONE overlapped line of copy `anchor & 3`).  13 x the positions x 32
+// bytes is what turns the filter's one-random-line-per-hit into a sequential stream.
+__global__ __launch_bounds__(256) void nbr_fill_ctx_kernel(const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ pos_table,
+                                                           uint32_t nkeys, uint32_t tmask, int weight, const uint64_t* __restrict__ nbr_start,
+                                                           const uint8_t* __restrict__ ref2, size_t ref2_stride, uint32_t seed_size,
+                                                           uint4* __restrict__ ctx /* 2 x uint4 per entry */) {
+    const uint32_t gl = threadIdx.x & (NBR_GROUP - 1);
+    const uint32_t groups = gridDim.x * (blockDim.x / NBR_GROUP);
+    for (uint32_t k = blockIdx.x * (blockDim.x / NBR_GROUP) + threadIdx.x / NBR_GROUP; k < nkeys; k += groups) {
+        uint64_t o = nbr_start[k];
+        for (int j = -1; j < weight; j++) {
+            if (j >= 0 && !((tmask >> j) & 1u)) continue;
+            const uint32_t kk = j < 0 ? k : (k ^ (2u << (2 * j)));
+            const uint32_t b = bucket_start[kk], n = bucket_start[kk + 1] - b;
+            for (uint32_t i = gl; i < n; i += NBR_GROUP) {
+                const uint32_t p = pos_table[b + i];
+                const uint32_t a = p + seed_size;                       // anchor (:220)
+                const uint32_t jj0 = (a >> 2) + (uint32_t)PACK2_BIAS;   // logical byte of the anchor's 4-base group in copy a & 3
+                const uint32_t line = (jj0 - 16u) / (uint32_t)PACK2_PAYLOAD;
+                const uint8_t* tp = ref2 + (size_t)(a & 3u) * ref2_stride + (jj0 + 32u * line);
+                const uint4 rw = load16u(tp), lw = load16u(tp - 16);
+                ctx[2 * (o + i)] = make_uint4(p, rw.x, rw.y, rw.z);
+                ctx[2 * (o + i) + 1] = make_uint4(__builtin_bitreverse32(lw.w), __builtin_bitreverse32(lw.z),
+                                                  __builtin_bitreverse32(lw.y), __builtin_bitreverse32(lw.x));
+            }
+            o += n;
+        }
+    }
+}
+
+void launch_nbr_fill_ctx(const uint32_t* bucket_start, const uint32_t* pos_table, uint32_t nkeys, uint32_t tmask, int weight,
+                         const uint64_t* nbr_start, const uint8_t* ref2, size_t ref2_stride, uint32_t seed_size, CtxRec* ctx, hipStream_t s) {
+    hipLaunchKernelGGL(nbr_fill_ctx_kernel, dim3(8192), dim3(256), 0, s, bucket_start, pos_table, nkeys, tmask, weight, nbr_start, ref2,
+                       ref2_stride, seed_size, reinterpret_cast<uint4*>(ctx));
+}
+
 void launch_nbr_count(const uint32_t* bucket_start, uint32_t nkeys, uint32_t tmask, int weight, uint32_t* cnt, uint32_t* overflow,
                       hipStream_t s) {
     hipLaunchKernelGGL(nbr_count_kernel, dim3(4096), dim3(256), 0, s, bucket_start, nkeys, tmask, weight, cnt, overflow);

@@ -36,6 +36,7 @@ C_ABI_SYMBOLS = [
     "sa_copy_query_codes", "sa_get_query_len", "sa_device_make_seeds", "sa_version",
     "sa_rm_mask_interval", "sa_rm_coverage_intervals", "sa_free_intervals", "sa_get_filter_mode",
     "sa_seed_interval", "sa_seed_and_filter_chunks", "sa_max_chunks_per_call", "sa_extend_hits",
+    "sa_get_lookup_mode", "sa_get_neighbourhood_entries",
 ]
 IVL_DTYPE = np.dtype([("query_start", "<u4"), ("len", "<u4")])  # struct Segment, repeat_masker_src/graph.h:32-35
 STRAND_PLUS, STRAND_MINUS, STRAND_BOTH = 1, 2, 3
@@ -111,6 +112,7 @@ def lib():
     L.sa_device_make_seeds.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t]
     L.sa_extend_hits.restype = C.c_size_t
     L.sa_extend_hits.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.sa_get_neighbourhood_entries.restype = C.c_uint64
     L.sa_version.restype = C.c_char_p
     _lib = L
     return L
@@ -299,6 +301,15 @@ def last_call_stats():
     st = CallStats()
     lib().sa_get_last_call_stats(C.byref(st))
     return {k: getattr(st, k) for k, _ in CallStats._fields_}
+
+
+def lookup_mode():
+    """0 general (seed words), 1 table-direct, 2 table-direct with target context (see sa_get_lookup_mode)."""
+    return int(lib().sa_get_lookup_mode())
+
+
+def neighbourhood_entries():
+    return int(lib().sa_get_neighbourhood_entries())
 
 
 def filter_mode():

@@ -1,0 +1,101 @@
+"""GPU: the three seed-lookup paths of the device-seeded entry points give the oracle's result bit for bit:
+  2  table-direct with target context (neighbourhood table of 32-byte records, context filter + second level; default)
+  1  table-direct, positions only (SEGALIGN_AMD_NO_CTX=1; what a target block too large for the context table gets)
+  0  general path: seed words -> bucket lookup -> hit list (SEGALIGN_AMD_NO_TD=1; also every drop-in call)
+src/seed_filter.cu:157-230 + :682-828 (lookup, iteration plan, hits) on every path; repeat-masker variant included."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import Case, seg_equal
+from segalign_amd import synth
+from test_gpu_rm_mask import as_list, model_mask_interval
+
+pytestmark = pytest.mark.gpu
+
+MODES = [(2, {}), (1, {"SEGALIGN_AMD_NO_CTX": "1"}), (0, {"SEGALIGN_AMD_NO_TD": "1"})]
+
+
+def with_env(env):
+    for k in ("SEGALIGN_AMD_NO_CTX", "SEGALIGN_AMD_NO_TD"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+
+
+@pytest.fixture
+def clean(engine):
+    yield engine
+    engine.ShutdownProcessor()
+    engine.set_max_hits(0)
+    with_env({})
+
+
+@pytest.mark.parametrize("mode,env", MODES)
+@pytest.mark.parametrize("transition", [True, False])
+def test_every_lookup_path_equals_the_oracle(oracle, clean, mode, env, transition):
+    with_env(env)
+    t, q = synth.make_pair(400000, 41, 42, sub_rate=0.09, mask_frac=0.15, records=3, indel_every=450, n_runs=2)
+    c = Case(t, q, chunk=60000, transition=transition).oracle_setup(oracle).engine_setup(clean)
+    E = c.E
+    assert E.lookup_mode() == mode
+    if mode:
+        words = 13 if transition else 1
+        assert E.neighbourhood_entries() == words * c.o_pos.size  # every bucket appears once per seed word that maps to it
+    q_len = q.size - c.seed_size
+    per = {False: [], True: []}
+    for rev in (False, True):
+        wants = []
+        for (s, e) in c.chunks():
+            want, st = c.oracle_saf(c.host_seeds(s, e, rev), rev)
+            assert seg_equal(E.SeedAndFilterRange(s, e, rev, 0), want), (mode, rev, s, e)
+            assert E.last_call_stats()["num_hits"] == st["num_hits"]
+            wants.append(want)
+            per[rev].append(want[1:])
+        ch = c.chunks()
+        for g in range(0, len(ch), 4):  # multi-chunk calls: own plan / dedup scope / vector per chunk
+            outs = E.SeedAndFilterChunks(ch[g][0], ch[min(g + 3, len(ch) - 1)][1], rev, 0)
+            for j, w in enumerate(wants[g:g + 4]):
+                assert seg_equal(outs[j], w), (mode, rev, g, j)
+    fw, rc, st = E.SeedInterval(0, q_len, q_len, E.STRAND_BOTH, 0, 3)
+    assert np.array_equal(fw, np.concatenate(per[False])) and np.array_equal(rc, np.concatenate(per[True]))
+    assert fw.size + rc.size > 100
+
+
+@pytest.mark.parametrize("mode,env", MODES)
+def test_lookup_paths_under_a_max_hits_split(oracle, clean, mode, env):
+    """num_hits >= MAX_HITS (hazard H4): more than two reference iterations -- a table-direct call must hand the chunk to the
+    general path (the plan then needs per-seed-word prefixes); below the limit it keeps the two-iteration split."""
+    with_env(env)
+    t, q = synth.make_pair(150000, 51, 52, sub_rate=0.07, mask_frac=0.1)
+    c = Case(t, q, chunk=50000).oracle_setup(oracle).engine_setup(clean)
+    for mh in (3000, 40000, 1 << 30):
+        c.E.set_max_hits(mh)
+        for rev in (False, True):
+            for (s, e) in c.chunks():
+                want, st = c.oracle_saf(c.host_seeds(s, e, rev), rev, max_hits=mh)
+                assert seg_equal(c.E.SeedAndFilterRange(s, e, rev, 0), want), (mode, mh, rev, s, e)
+    c.E.set_max_hits(0)
+
+
+@pytest.mark.parametrize("mode,env", MODES)
+def test_lookup_paths_repeat_masker(oracle, clean, mode, env):
+    with_env(env)
+    unit = synth.random_dna(600, 77)
+    t = synth.random_dna(200000, 15)
+    rng = np.random.default_rng(3)
+    for i in range(90):
+        p = int(rng.integers(0, t.size - 700))
+        cp = synth.mutate(unit, 500 + i, 0.05)
+        t[p:p + cp.size] = cp if i % 3 else synth.reverse_complement(cp)
+    t = synth.soft_mask(t, 5, 0.04)
+    c = Case(t, t, chunk=30000).oracle_setup(oracle).engine_setup(clean)
+    c.E.RmSendQueryWriteRequest()
+    assert c.E.lookup_mode() == mode
+    L = t.size
+    for (s, e, ws, we, strands) in ((0, L - 19, 0, L, 3), (40000, 130000, 20000, 150000, 3), (100000, 160000, 0, 90000, 1),
+                                    (0, 70000, 120000, L, 2)):
+        want, wt = model_mask_interval(c, oracle, s, e, ws, we, strands, 1)
+        got, gt = c.E.RmMaskInterval(s, e, ws, we, strands, 1)
+        assert as_list(got) == as_list(want) and gt == wt, (mode, s, e, ws, we, strands)
+    c.E.RmClearQuery()

@@ -161,114 +161,107 @@ __global__ __launch_bounds__(256) void strip_kernel(const HspRec* __restrict__ i
     }
 }
 
-// ---- the whole chain for a SMALL survivor set in one workgroup -----------------------------------------------------
-// After the chain shortcut a call leaves a few hundred survivors; three library sorts + unique + strip then cost ~65 us of
-// pure launch latency and one extra host sync.  For n <= DEDUP_SMALL_MAX one workgroup does
-//   stable sort by LessDiag -> adjacent-pair unique (hsp_contained, H3) -> stable sort by LessLastz -> 16-byte records
-// in LDS (src/seed_filter.cu:776-782, all iterations -- and all chunks of a multi-chunk call -- at once through `seg`).
-constexpr int DEDUP_SMALL_MAX = 1024;  // one record per thread in the unique step
-constexpr int DEDUP_SMALL_THREADS = 1024;
+constexpr int DEDUP_SMALL_SEGS = 16;  // distinct segment ids (reference iterations x chunks of a call) the LDS path handles
 
-constexpr int DEDUP_SMALL_SEGS = 16;  // distinct segment ids (reference iterations x chunks of a call) the small path handles
+// ---- the whole chain in LDS, ONE WORKGROUP PER SEGMENT -----------------------------------------------------------------
+// After the chain shortcut a call leaves a few hundred to a few thousand survivors; three library sorts + unique + strip then
+// cost ~65 us of pure launch latency and an extra host sync (src/seed_filter.cu:776-782 per iteration).
+// A multi-chunk call carries up to 8 segments (4 chunks x 2 reference iterations) whose chains are independent (:776-782 run
+// per iteration).  One workgroup per segment id picks its records out of the survivor list, runs sort -> unique -> sort in
+// LDS and writes its result into the slot range the segment's INPUT records would occupy (offset = number of survivors in
+// lower segments); the host closes the gaps while it splits the output per chunk anyway.  Eight small workgroups on eight
+// CUs instead of one 1024-thread workgroup walking all records: the stage's latency drops from ~200 us (500 us next to a
+// running filter kernel) to ~20 us, and the limit rises from 1024 survivors per call to 1024 per segment.
+constexpr int DEDUP_SEG_THREADS = 256;
+constexpr int DEDUP_SEG_MAX = 1024;      // records per segment
+constexpr int DEDUP_SEG_TOTAL = 16384;   // survivors per call (every workgroup scans the whole list once)
 
-// Stable sort of a[0..n) by `Less` (segment id first) in LDS, result back in a[]; tmp[] is scratch of the same size.
-// Two steps: (1) group the records by segment (counting sort over <= DEDUP_SMALL_SEGS ids), (2) RANK sort inside every
-// segment: rank(i) = #{j in the segment : rec[j] < rec[i]} + #{j < i : rec[j] equivalent to rec[i]} is exactly the
-// position a stable sort gives element i.  O(n * segment size) comparisons spread over the workgroup (the threads are
-// split into `parts` groups that each count over a slice of the segment), no barrier chain.  Ends with a barrier.
 template <class Less>
-__device__ __forceinline__ void seg_rank_sort_lds(HspRec* __restrict__ a, HspRec* __restrict__ tmp, uint32_t n,
-                                                  uint32_t* __restrict__ s_rank, uint32_t* __restrict__ s_seg /*[2*SEGS+1]*/) {
+__device__ __forceinline__ void rank_sort_lds(const HspRec* __restrict__ src, HspRec* __restrict__ dst, uint32_t m) {
     Less less;
-    uint32_t* s_cnt = s_seg;                       // [SEGS] records per segment, then running cursors
-    uint32_t* s_beg = s_seg + DEDUP_SMALL_SEGS;    // [SEGS+1] first slot of every segment
-    if (threadIdx.x < DEDUP_SMALL_SEGS) s_cnt[threadIdx.x] = 0;
-    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) s_rank[k] = 0;
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) atomicAdd(&s_cnt[a[k].seg & (DEDUP_SMALL_SEGS - 1)], 1u);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int g = 0; g < DEDUP_SMALL_SEGS; g++) { s_beg[g] = run; run += s_cnt[g]; s_cnt[g] = s_beg[g]; }
-        s_beg[DEDUP_SMALL_SEGS] = run;
-    }
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
-        const HspRec r = a[k];
-        tmp[atomicAdd(&s_cnt[r.seg & (DEDUP_SMALL_SEGS - 1)], 1u)] = r;  // order inside a segment is arbitrary here:
-    }                                                                   // records that compare equal are identical
-    __syncthreads();
-    const uint32_t nceil = (n + 63u) & ~63u;                  // elements padded to whole waves
-    const uint32_t parts = nceil ? blockDim.x / nceil : 1u;    // >= 1 because n <= blockDim.x
-    const uint32_t i = threadIdx.x % (nceil ? nceil : 1u), p = threadIdx.x / (nceil ? nceil : 1u);
-    if (i < n && p < parts) {
-        const HspRec me = tmp[i];
-        const uint32_t g = me.seg & (DEDUP_SMALL_SEGS - 1);
-        const uint32_t b0 = s_beg[g], m = s_beg[g + 1] - b0;
-        const uint32_t j0 = b0 + (uint32_t)((uint64_t)m * p / parts), j1 = b0 + (uint32_t)((uint64_t)m * (p + 1) / parts);
-        uint32_t rank = p == 0 ? b0 : 0u;
-        for (uint32_t j = j0; j < j1; j++) {
-            const HspRec o = tmp[j];
-            rank += (less(o, me) || (j < i && !less(me, o))) ? 1u : 0u;
+    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+        const HspRec me = src[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < m; j++) {
+            const HspRec o = src[j];
+            rank += (less(o, me) || (j < i && !less(me, o))) ? 1u : 0u;  // #smaller + #equivalent before = the stable position
         }
-        atomicAdd(&s_rank[i], rank);
+        dst[rank] = me;
     }
-    __syncthreads();
-    if (threadIdx.x < n) a[s_rank[threadIdx.x]] = tmp[threadIdx.x];
     __syncthreads();
 }
 
-__global__ __launch_bounds__(DEDUP_SMALL_THREADS) void dedup_small_kernel(const HspRec* __restrict__ in, uint32_t n,
-                                                                          uint4* __restrict__ out, uint32_t* __restrict__ out_seg,
-                                                                          uint32_t* __restrict__ out_count) {
-    __shared__ HspRec s_a[DEDUP_SMALL_MAX];
-    __shared__ HspRec s_b[DEDUP_SMALL_MAX];
-    __shared__ uint32_t s_rank[DEDUP_SMALL_MAX];
-    __shared__ uint32_t s_seg[2 * DEDUP_SMALL_SEGS + 1];
-    __shared__ uint32_t s_wave[DEDUP_SMALL_THREADS / 64];
-    __shared__ uint32_t s_m;
+__global__ __launch_bounds__(DEDUP_SEG_THREADS) void dedup_seg_kernel(const HspRec* __restrict__ in, uint32_t n, uint4* __restrict__ out,
+                                                                      uint32_t* __restrict__ seg_info /* [2 * SEGS + 1] */) {
+    __shared__ HspRec s_a[DEDUP_SEG_MAX];
+    __shared__ HspRec s_b[DEDUP_SEG_MAX];
+    __shared__ uint32_t s_cnt[DEDUP_SMALL_SEGS];
+    __shared__ uint32_t s_m, s_wave[DEDUP_SEG_THREADS / 64];
+    const uint32_t g = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_a[i] = in[i];
+    if (threadIdx.x < DEDUP_SMALL_SEGS) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_m = 0;
     __syncthreads();
-    seg_rank_sort_lds<LessDiag>(s_a, s_b, n, s_rank, s_seg);  // :776
-    // adjacent-pair unique on the sorted INPUT sequence (:778-780), order preserving; one element per thread
-    {
-        const uint32_t i = threadIdx.x;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const HspRec r = in[i];
+        const uint32_t sg = r.seg & (DEDUP_SMALL_SEGS - 1);
+        atomicAdd(&s_cnt[sg], 1u);
+        if (sg == g) {
+            const uint32_t k = atomicAdd(&s_m, 1u);
+            if (k < DEDUP_SEG_MAX) s_a[k] = r;  // order inside the segment is arbitrary here: equal records are identical
+        }
+    }
+    __syncthreads();
+    uint32_t off = 0;
+    for (uint32_t t = 0; t < g; t++) off += s_cnt[t];
+    const uint32_t m = s_m;
+    if (m > DEDUP_SEG_MAX) {  // the host falls back to the library sorts
+        if (threadIdx.x == 0) { seg_info[2 * DEDUP_SMALL_SEGS] = 1u; seg_info[g] = 0; seg_info[DEDUP_SMALL_SEGS + g] = off; }
+        return;
+    }
+    rank_sort_lds<LessDiag>(s_a, s_b, m);  // :776
+    // adjacent-pair unique on the sorted sequence (:778-780, hazard H3), order preserving
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < m; base += blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
         bool keep = false;
         HspRec me;
         me.ref_start = me.query_start = me.len = 0; me.score = 0; me.seg = 0;
-        if (i < n) {
-            me = s_a[i];
-            keep = i == 0 || s_a[i - 1].seg != me.seg || !hsp_contained(s_a[i - 1], me);
+        if (i < m) {
+            me = s_b[i];
+            keep = i == 0 || !hsp_contained(s_b[i - 1], me);
         }
         const unsigned long long mask = __ballot(keep);
         if (lane == 0) s_wave[wave] = (uint32_t)__popcll(mask);
         __syncthreads();
-        uint32_t base = 0, total = 0;
-        for (int w = 0; w < DEDUP_SMALL_THREADS / 64; w++) {
+        uint32_t pre = 0, tot = 0;
+        for (int w = 0; w < DEDUP_SEG_THREADS / 64; w++) {
             const uint32_t c = s_wave[w];
-            if (w < wave) base += c;
-            total += c;
+            if (w < wave) pre += c;
+            tot += c;
         }
-        if (keep) s_b[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = me;
-        if (threadIdx.x == 0) s_m = total;
+        if (keep) s_a[carry + pre + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = me;
+        carry += tot;
         __syncthreads();
     }
-    const uint32_t m = s_m;
-    seg_rank_sort_lds<LessLastz>(s_b, s_a, m, s_rank, s_seg);  // :782
-    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+    const uint32_t m2 = carry;
+    rank_sort_lds<LessLastz>(s_a, s_b, m2);  // :782
+    for (uint32_t i = threadIdx.x; i < m2; i += blockDim.x) {
         const HspRec r = s_b[i];
-        out[i] = make_uint4(r.ref_start, r.query_start, r.len, (uint32_t)r.score);
-        if (out_seg) out_seg[i] = r.seg;
+        out[off + i] = make_uint4(r.ref_start, r.query_start, r.len, (uint32_t)r.score);
     }
-    if (threadIdx.x == 0) *out_count = m;
+    if (threadIdx.x == 0) { seg_info[g] = m2; seg_info[DEDUP_SMALL_SEGS + g] = off; }
 }
 
-uint32_t dedup_small_max() { return DEDUP_SMALL_MAX; }
-uint32_t dedup_small_max_segs() { return DEDUP_SMALL_SEGS; }
-void launch_dedup_small(const HspRec* in, uint32_t n, void* out_segment_pairs, uint32_t* out_seg, uint32_t* out_count, hipStream_t s) {
-    hipLaunchKernelGGL(dedup_small_kernel, dim3(1), dim3(DEDUP_SMALL_THREADS), 0, s, in, n, reinterpret_cast<uint4*>(out_segment_pairs), out_seg, out_count);
+uint32_t dedup_seg_max_total() { return DEDUP_SEG_TOTAL; }
+uint32_t dedup_seg_info_words() { return 2 * DEDUP_SMALL_SEGS + 1; }
+// seg_info[g] = records of segment g after the chain, seg_info[SEGS + g] = their first slot in out; seg_info[2 * SEGS] != 0:
+// a segment held more than DEDUP_SEG_MAX records (nothing usable was written); must be zero on entry
+void launch_dedup_seg(const HspRec* in, uint32_t n, uint32_t nsegs, void* out_segment_pairs, uint32_t* seg_info, hipStream_t s) {
+    hipLaunchKernelGGL(dedup_seg_kernel, dim3(nsegs), dim3(DEDUP_SEG_THREADS), 0, s, in, n, reinterpret_cast<uint4*>(out_segment_pairs), seg_info);
 }
+
+uint32_t dedup_small_max_segs() { return DEDUP_SMALL_SEGS; }
 
 void launch_unique(const HspRec* in, HspRec* out, uint32_t n, int exact, uint32_t* out_count, hipStream_t s) {
     hipLaunchKernelGGL(unique_kernel, dim3(1), dim3(UNQ_THREADS), 0, s, in, out, n, exact, out_count);

@@ -240,6 +240,8 @@ struct Slot {
     IterPlan* d_plan = nullptr;       // SA_MAX_CHUNKS plans (one per chunk of a multi-chunk call)
     Counters* d_cnt = nullptr;
     DevBuf<uint32_t> out_seg;         // segment id of every final record (multi-chunk calls split their output by it)
+    uint32_t* d_seg_info = nullptr;   // per-segment counts / offsets of the LDS dedup (dedup.hip)
+    uint32_t* h_seg_info = nullptr;   // pinned
     uint32_t* h_seg = nullptr;        // pinned
     size_t h_seg_cap = 0;
     uint32_t* h_bounds = nullptr;     // pinned: flag-prefix values at the chunk boundaries of a multi-chunk call
@@ -314,10 +316,12 @@ static int g_bufs_per_wave = 8;   // SEGALIGN_AMD_BUFS_PER_WAVE
 static int g_long_cap = 128;      // SEGALIGN_AMD_LONG_CAP: bases per side before a hit goes to the long kernel
 static int g_long_blocks = 1792;  // SEGALIGN_AMD_LONG_BLOCKS: grid of the long kernel (4 waves per block)
 static int g_packed_waves = 4096; // SEGALIGN_AMD_PACKED_WAVES: waves of the packed filter (2 workgroups of 8 waves per CU measured best: 3072 +16 %, 6144 +20 %, 8192 +14 %)
+static int g_ctx_waves = 6144;    // SEGALIGN_AMD_CTX_WAVES: waves of the context filter (8 per SIMD: the kernel is a software-pipelined stream)
+static int g_l2_blocks = 256;     // SEGALIGN_AMD_L2_BLOCKS: workgroups of the second-level packed filter
 static int g_max_waves = 4096;    // SEGALIGN_AMD_MAX_WAVES: waves of the filter kernel (4 per SIMD saturate instruction issue)
 static int g_fast_filter = 0;     // derived in InitializeProcessor: xdrop >= 0 && 7*max(M) <= xdrop
 static int g_packed_filter = 0;   // derived in InitializeProcessor: the packed upper-bound filter may be used
-static int g_chain_sort_threads = 512;  // SEGALIGN_AMD_CHAIN_SORT_THREADS
+static int g_chain_sort_threads = 256;  // SEGALIGN_AMD_CHAIN_SORT_THREADS
 static int g_chunks_per_call = SA_MAX_CHUNKS;  // SEGALIGN_AMD_CHUNKS_PER_CALL: chunks sa_seed_interval hands to one multi-chunk call
 static int g_no_small_dedup = 0;  // SEGALIGN_AMD_NO_SMALL_DEDUP=1: always use the library sorts
 static int g_ctx = 1;             // neighbourhood table with target context when it fits (SEGALIGN_AMD_NO_CTX=1: positions only)
@@ -402,11 +406,13 @@ static void slot_init(Slot& s, int dev) {
     s.d_cnt = (Counters*)dev_malloc(sizeof(Counters), "counters");
     s.d_cov_range = (uint32_t*)dev_malloc(2 * sizeof(uint32_t), "coverage range");
     s.d_td_bounds = dev_malloc(probe_bounds_bytes(), "probe bounds");
+    s.d_seg_info = (uint32_t*)dev_malloc(dedup_seg_info_words() * sizeof(uint32_t), "segment info");
     s.d_td_plan = (TdPlan*)dev_malloc(sizeof(TdPlan) * SA_MAX_CHUNKS, "probe plan");
     if (hipHostMalloc((void**)&s.h_cov, 8 * sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc((void**)&s.h_bounds, (SA_MAX_CHUNKS + 2) * sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc((void**)&s.h_plan, sizeof(IterPlan) * SA_MAX_CHUNKS) != hipSuccess ||
         hipHostMalloc((void**)&s.h_td_plan, sizeof(TdPlan) * SA_MAX_CHUNKS) != hipSuccess ||
+        hipHostMalloc((void**)&s.h_seg_info, dedup_seg_info_words() * sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc((void**)&s.h_cnt, sizeof(Counters)) != hipSuccess) {
         fprintf(stderr, "Error: hipHostMalloc for slot staging failed\n");
         exit(12);
@@ -424,8 +430,10 @@ static void slot_destroy(Slot& s) {
     s.cov_diff.release("coverage"); s.cov_pre.release("coverage"); s.cov_is_start.release("coverage");
     s.cov_is_end.release("coverage"); s.cov_sidx.release("coverage"); s.cov_eidx.release("coverage"); s.cov_pairs.release("coverage");
     s.td_toff.release("probe"); s.td_tcnt.release("probe"); s.td_rec.release("probe"); s.td_partial.release("probe");
-    dev_free(s.d_td_bounds, "probe bounds"); dev_free(s.d_td_plan, "probe plan");
-    s.d_td_bounds = nullptr; s.d_td_plan = nullptr;
+    dev_free(s.d_td_bounds, "probe bounds"); dev_free(s.d_td_plan, "probe plan"); dev_free(s.d_seg_info, "segment info");
+    s.d_td_bounds = nullptr; s.d_td_plan = nullptr; s.d_seg_info = nullptr;
+    if (s.h_seg_info) hipHostFree(s.h_seg_info);
+    s.h_seg_info = nullptr;
     if (s.h_td_plan) hipHostFree(s.h_td_plan);
     s.h_td_plan = nullptr;
     dev_free(s.d_plan, "plan"); dev_free(s.d_cnt, "counters"); dev_free(s.d_cov_range, "coverage range");
@@ -605,6 +613,8 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     ea.seed_size = g_seed_size;
                     if (ea.td_ctx) sl->l2_list.ensure((size_t)std::max<uint64_t>(1u << 16, bh / 8), "second-level list");
                     ea.l2_count = &sl->d_cnt->n_l2;
+                    ea.ctx_waves = (uint32_t)g_ctx_waves;
+                    ea.l2_blocks = (uint32_t)g_l2_blocks;
                 } else if (!ca.raw_hits) {
                     sl->hits.ensure((size_t)bh, "hits");
                     ProfScope p(sl, "expand_hits");
@@ -771,22 +781,36 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                 size_t tb = sort_temp_bytes(survivors);
                 sl->sort_temp.ensure(tb, "sort temp");
                 HspRec* fin = nullptr;
-                const bool small = !ca.rm && survivors <= dedup_small_max() && segs.size() <= dedup_small_max_segs() && !g_no_small_dedup;
-                if (small) {  // the whole chain in one workgroup, one D2H of count + records
+                bool done = false;
+                if (!ca.rm && survivors <= dedup_seg_max_total() && segs.size() <= dedup_small_max_segs() && !g_no_small_dedup) {
+                    // the whole chain in LDS, one workgroup per segment; one D2H of the (gapped) records + the segment counts
+                    const uint32_t words = dedup_seg_info_words();
                     sl->out16.ensure(survivors, "out16");
                     ensure_host_out(survivors);
-                    if (K > 1) { sl->out_seg.ensure(survivors, "out seg"); ensure_host_seg(survivors); }
-                    { ProfScope p(sl, "dedup_small"); launch_dedup_small(sl->recA.p, survivors, sl->out16.p, K > 1 ? sl->out_seg.p : nullptr, &sl->d_cnt->uniq, st); }
-                    check_launch("dedup small");
-                    check_memcpy(hipMemcpyAsync(sl->h_cnt, sl->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st), "counters");
-                    if (K > 1) {
-                        check_memcpy(hipMemcpyAsync(sl->h_seg, sl->out_seg.p, (size_t)survivors * sizeof(uint32_t), hipMemcpyDeviceToHost, st), "hsp segs");
-                        have_seg = true;
-                    }
+                    ensure_host_seg(std::max<size_t>(survivors, words));
+                    check_memcpy(hipMemsetAsync(sl->d_seg_info, 0, words * sizeof(uint32_t), st), "segment info");
+                    { ProfScope p(sl, "dedup_seg"); launch_dedup_seg(sl->recA.p, survivors, (uint32_t)segs.size(), sl->out16.p, sl->d_seg_info, st); }
+                    check_launch("dedup seg");
+                    check_memcpy(hipMemcpyAsync(sl->h_seg_info, sl->d_seg_info, words * sizeof(uint32_t), hipMemcpyDeviceToHost, st), "segment info");
                     check_memcpy(hipMemcpyAsync(sl->h_out, sl->out16.p, (size_t)survivors * sizeof(sa_segment_pair),
                                                 hipMemcpyDeviceToHost, st), "hsp_output");  // :788
                     check_sync(st, "hsp_output");
-                    n_final = sl->h_cnt->uniq;
+                    if (sl->h_seg_info[words - 1] == 0) {  // (else a segment was too large for LDS: library sorts below)
+                        const uint32_t S = dedup_small_max_segs();
+                        size_t pos = 0;
+                        for (uint32_t g = 0; g < (uint32_t)segs.size(); g++) {  // close the gaps the unique step left
+                            const uint32_t m2 = sl->h_seg_info[g], off = sl->h_seg_info[S + g];
+                            if (m2 && pos != off) memmove(sl->h_out + pos, sl->h_out + off, (size_t)m2 * sizeof(sa_segment_pair));
+                            for (uint32_t i = 0; i < m2; i++) sl->h_seg[pos + i] = g;
+                            pos += m2;
+                        }
+                        n_final = (uint32_t)pos;
+                        have_seg = true;
+                        done = true;
+                    }
+                }
+                if (done) {
+                    // nothing left to do on the device
                 } else if (!ca.rm) {
                     { ProfScope p(sl, "sort_diag");  launch_sort(sl->recA.p, sl->recB.p, survivors, ORDER_DIAG, sl->sort_temp.p, sl->sort_temp.cap, st); }
                     { ProfScope p(sl, "unique");     launch_unique(sl->recB.p, sl->recA.p, survivors, 0, &sl->d_cnt->uniq, st); }
@@ -1197,6 +1221,8 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
     if (const char* e = getenv("SEGALIGN_AMD_LONG_BLOCKS")) g_long_blocks = std::max(1, atoi(e));
     if (const char* e = getenv("SEGALIGN_AMD_MAX_WAVES")) g_max_waves = std::max(4, atoi(e));
     if (const char* e = getenv("SEGALIGN_AMD_PACKED_WAVES")) g_packed_waves = std::max(8, atoi(e));
+    if (const char* e = getenv("SEGALIGN_AMD_CTX_WAVES")) g_ctx_waves = std::max(8, atoi(e));
+    if (const char* e = getenv("SEGALIGN_AMD_L2_BLOCKS")) g_l2_blocks = std::max(1, atoi(e));
     if (xdrop >= (1 << 25) || xdrop <= -(1 << 25)) {
         fprintf(stderr, "Error: |xdrop| must be below 2^25\n");
         exit(1);
@@ -1224,7 +1250,7 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
         g_chain = getenv("SEGALIGN_AMD_NO_CHAIN") ? 0 : 1;
         g_td = getenv("SEGALIGN_AMD_NO_TD") ? 0 : 1;
         g_ctx = getenv("SEGALIGN_AMD_NO_CTX") ? 0 : 1;
-        g_chain_sort_threads = 512;
+        g_chain_sort_threads = 256;
         if (const char* e = getenv("SEGALIGN_AMD_CHAIN_SORT_THREADS")) g_chain_sort_threads = std::max(64, std::min(512, atoi(e) & ~63));
         if (const char* e = getenv("SEGALIGN_AMD_CHAIN_CAP")) CHAIN_CAP = (uint32_t)std::max(1, atoi(e));
         else CHAIN_CAP = 1u << 20;

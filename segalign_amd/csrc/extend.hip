@@ -818,29 +818,45 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_ctx_kernel(ExtendArg
     TdCursor cursor = {0u, {0u, 0u, 0ull}, 0u};
     cursor.seek(a, lane, (uint32_t)(b_lo << 6));
 
-    for (uint64_t b = b_lo; b < b_hi; b++) {
+    // software pipeline: the records and query windows of buffer b + 1 are requested before buffer b is scored, so the HBM
+    // latency of the stream is covered by ~2000 cycles of arithmetic instead of by occupancy alone
+    struct Loaded { uint4 c0, c1, qr0, ql0, ql1; uint2 qr1; uint32_t qp; };
+    auto request = [&](uint64_t b) -> Loaded {
+        Loaded L;
+        L.c0 = L.c1 = L.qr0 = L.ql0 = L.ql1 = make_uint4(0u, 0u, 0u, 0u);
+        L.qr1 = make_uint2(0u, 0u);
+        L.qp = 0;
+        if (b >= b_hi) return L;  // (wave-uniform)
         const uint64_t rem = a.num_hits - (b << 6);
         const int cnt = rem >= 64 ? 64 : (int)rem;
         uint64_t entry;
-        uint32_t qp;
-        cursor.locate(a, lane, (uint32_t)(b << 6), entry, qp);
+        cursor.locate(a, lane, (uint32_t)(b << 6), entry, L.qp);
+        if (lane < cnt) {
+            L.c0 = ctx[2 * entry];      // pos, r0, r1, r2
+            L.c1 = ctx[2 * entry + 1];  // l0 .. l3
+            // query windows: 48 bases from the anchor on, 64 bases before it (copy query_loc & 1 is byte aligned for both)
+            const uint32_t query_loc = L.qp + a.seed_size;  // :204
+            const uint8_t* qb = a.query4 + (size_t)(query_loc & 1u) * a.query4_stride + (query_loc >> 1);
+            L.qr0 = load16u(qb);
+            uint2 t;
+            __builtin_memcpy(&t, qb + 16, 8);
+            L.qr1 = t;
+            L.ql0 = load16u(qb - 32);
+            L.ql1 = load16u(qb - 16);
+        }
+        return L;
+    };
+    Loaded nxt = request(b_lo);
+    for (uint64_t b = b_lo; b < b_hi; b++) {
+        const uint64_t rem = a.num_hits - (b << 6);
+        const int cnt = rem >= 64 ? 64 : (int)rem;
+        const Loaded cur = nxt;
+        nxt = request(b + 1);
         const bool valid = lane < cnt;
-        uint4 c0 = {0u, 0u, 0u, 0u}, c1 = {0u, 0u, 0u, 0u};
-        if (valid) {
-            c0 = ctx[2 * entry];      // pos, r0, r1, r2
-            c1 = ctx[2 * entry + 1];  // l0 .. l3
-        }
-        const uint32_t ref_loc = c0.x + a.seed_size;   // :220
-        const uint32_t query_loc = qp + a.seed_size;   // :204
-        // query windows: 48 bases from the anchor on, 64 bases before it (copy query_loc & 1 is byte aligned for both)
-        const uint8_t* qb = a.query4 + (size_t)(query_loc & 1u) * a.query4_stride + (query_loc >> 1);
-        uint4 qr0 = {0u, 0u, 0u, 0u}, qr1 = qr0, ql0 = qr0, ql1 = qr0;
-        if (valid) {
-            qr0 = load16u(qb);
-            qr1 = load16u(qb + 16);
-            ql0 = load16u(qb - 32);
-            ql1 = load16u(qb - 16);
-        }
+        const uint4 c0 = cur.c0, c1 = cur.c1, qr0 = cur.qr0, ql0 = cur.ql0, ql1 = cur.ql1;
+        const uint2 qr1 = cur.qr1;
+        const uint32_t ref_loc = c0.x + a.seed_size;       // :220
+        const uint32_t query_loc = cur.qp + a.seed_size;   // :204
         bool skip = !valid;
         if (a.rm) skip = skip || !(ref_loc >= a.rm_win_start && ref_loc <= a.rm_win_end);  // rm :239-244,:305-333: total stays 0
         // ---- right side (:326-453): 3 steps ----
@@ -1063,7 +1079,7 @@ constexpr uint32_t CHAIN_WALK_EXTRA = 96; // bases walked past the predecessor's
 // quadratic rank sort is a few microseconds; all buckets together are the candidate list with every diagonal's
 // candidates contiguous and ordered by position -- exactly what the link test needs.  No host involvement.
 constexpr uint32_t CHAIN_BUCKETS = 4096;
-constexpr uint32_t CHAIN_SORT_MAX = 4096;  // entries a bucket may hold and still be sorted (LDS); larger: left unsorted,
+constexpr uint32_t CHAIN_SORT_MAX = 1024;  // entries a bucket may hold and still be sorted (8 KB of LDS); larger: left unsorted,
                                            // which only makes link tests fail, i.e. costs extensions, never correctness
 
 // A bucket = hash of (iteration, diagonal, 512-position window): one diagonal can carry every candidate of a call (a
@@ -1301,7 +1317,7 @@ void launch_extend_filter(const ExtendArgs& a, hipStream_t s) {
     if (!a.examined && a.fast_filter == 3) {
         const uint32_t pblocks = (uint32_t)((waves + PK_THREADS / 64 - 1) / (PK_THREADS / 64));
         if (a.src_cand) {  // second level behind the context filter: the count lives on the device, the grid is fixed
-            hipLaunchKernelGGL(extend_filter_packed_kernel<SRC_CAND>, dim3(256), dim3(PK_THREADS), 0, s, a);
+            hipLaunchKernelGGL(extend_filter_packed_kernel<SRC_CAND>, dim3(a.l2_blocks ? a.l2_blocks : 256), dim3(PK_THREADS), 0, s, a);
         } else if (a.td) hipLaunchKernelGGL(extend_filter_packed_kernel<SRC_TD>, dim3(pblocks), dim3(PK_THREADS), 0, s, a);
         else hipLaunchKernelGGL(extend_filter_packed_kernel<SRC_HITS>, dim3(pblocks), dim3(PK_THREADS), 0, s, a);
         return;
@@ -1316,7 +1332,7 @@ void launch_extend_filter_ctx(const ExtendArgs& a, hipStream_t s) {
     if (a.num_hits == 0) return;
     const uint64_t num_buf = (a.num_hits + 63) / 64;
     uint64_t waves = num_buf / 4;  // every buffer costs the same: a few buffers per wave are enough to amortise the set-up
-    const uint64_t max_waves = a.max_waves ? a.max_waves : 8192u;
+    const uint64_t max_waves = a.ctx_waves ? a.ctx_waves : 8192u;
     if (waves > max_waves) waves = max_waves;
     if (waves < 8) waves = 8;
     const uint32_t blocks = (uint32_t)((waves + PK_THREADS / 64 - 1) / (PK_THREADS / 64));
@@ -1328,7 +1344,7 @@ void launch_chain_group(const ExtendArgs& a, hipStream_t s) {  // chain_bucket_c
     hipLaunchKernelGGL(chain_count_kernel, dim3(256), dim3(256), 0, s, a);
     hipLaunchKernelGGL(chain_scan_kernel, dim3(1), dim3(256), 0, s, a);
     hipLaunchKernelGGL(chain_scatter_kernel, dim3(256), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(chain_bucket_sort_kernel, dim3(CHAIN_BUCKETS), dim3(a.chain_sort_threads ? a.chain_sort_threads : 512), 0, s, a);
+    hipLaunchKernelGGL(chain_bucket_sort_kernel, dim3(CHAIN_BUCKETS), dim3(a.chain_sort_threads ? a.chain_sort_threads : 256), 0, s, a);
 }
 uint32_t chain_num_buckets() { return CHAIN_BUCKETS; }
 void launch_chain_link(const ExtendArgs& a, hipStream_t s) {

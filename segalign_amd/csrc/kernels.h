@@ -108,6 +108,8 @@ struct ExtendArgs {
     uint32_t* l2_count;
     uint32_t l2_cap;
     int src_cand;               // packed filter reads its anchors from l2_list / *l2_count instead of `hits`
+    uint32_t ctx_waves;         // wave budget of the context filter; l2_blocks: grid of the second level (count known on the device only)
+    uint32_t l2_blocks;
     uint32_t seed_size;
     uint64_t num_hits;
     uint64_t hit_base;        // global index of hits[0] inside the call (segment boundaries are global)
@@ -192,11 +194,12 @@ void launch_sort(const HspRec* in, HspRec* out, size_t n, SortOrder order, void*
 // exact = 0: hspEqual of seed_filter.cu:47-52 ; exact = 1: field equality (repeat masker :80-85)
 void launch_unique(const HspRec* in, HspRec* out, uint32_t n, int exact, uint32_t* out_count, hipStream_t s);
 void launch_strip(const HspRec* in, uint32_t n, void* out_segment_pairs, uint32_t* out_seg /*nullable*/, hipStream_t s);
-// sort(diag) -> unique -> sort(lastz) -> 16-byte records for n <= dedup_small_max() survivors in ONE workgroup
-uint32_t dedup_small_max();
 uint32_t dedup_small_max_segs();
-void launch_dedup_small(const HspRec* in, uint32_t n, void* out_segment_pairs, uint32_t* out_seg /*nullable*/,
-                        uint32_t* out_count, hipStream_t s);
+// sort(diag) -> unique -> sort(lastz) -> 16-byte records in LDS, one workgroup per segment id (< dedup_small_max_segs());
+// the results land at the segments' input offsets
+uint32_t dedup_seg_max_total();
+uint32_t dedup_seg_info_words();
+void launch_dedup_seg(const HspRec* in, uint32_t n, uint32_t nsegs, void* out_segment_pairs, uint32_t* seg_info, hipStream_t s);
 
 // ---- coverage.hip (repeat-masker post-processing, repeat_masker_src/seeder.cpp:153-188) ------------------------
 struct SegPair16 { uint32_t ref_start, query_start, len; int32_t score; };  // layout of sa_segment_pair / segmentPair

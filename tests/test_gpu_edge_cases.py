@@ -70,11 +70,12 @@ def test_single_hit_bearing_seed_and_all_hits_in_seed0(oracle, engine_clean):
         assert seg_equal(c.E.SeedAndFilter(vec, False, 0), want)
 
 
-@pytest.mark.parametrize("max_hits", [5000, 700, 150])
-def test_max_hits_iteration_split(oracle, engine_clean, max_hits):
-    """Hazard H4: per-iteration dedup; small MAX_HITS -> many iterations (more than one extension batch of 8 segments)."""
-    t, q = synth.make_pair(80000, 5, 6, sub_rate=0.08, mask_frac=0.05, records=2)
-    c = Case(t, q, chunk=40000).oracle_setup(oracle).engine_setup(engine_clean)
+@pytest.mark.parametrize("max_hits,size", [(5000, 80000), (700, 50000), (150, 24000)])
+def test_max_hits_iteration_split(oracle, engine_clean, max_hits, size):
+    """Hazard H4: per-iteration dedup; small MAX_HITS -> many iterations (more than one extension batch of 8 segments;
+    hundreds of iterations per call in the last case, sized so that it still runs in seconds)."""
+    t, q = synth.make_pair(size, 5, 6, sub_rate=0.08, mask_frac=0.05, records=2)
+    c = Case(t, q, chunk=size // 2).oracle_setup(oracle).engine_setup(engine_clean)
     c.E.set_max_hits(max_hits)
     assert c.E.get_max_hits() == max_hits
     n = run_all_chunks(c, max_hits=max_hits)

@@ -441,6 +441,17 @@ constexpr int PK_TAB = 4096;
 
 // ---- pair table: entry (4 target bits | query byte << 4) = {s0, s0 + s1} as two int16 (see above) ---------------------
 __device__ __forceinline__ void pk_table_init(uint32_t* __restrict__ s_pk, const int* __restrict__ sub_mat, int nthreads) {
+    // the 64 matrix entries go through LDS first (the 4096 pair entries read ~10 of them each): the row-0 maximum over
+    // the rows {A, L, N, X, E} is folded in there, scores are raised to -16383
+    __shared__ int s_m[64];
+    if (threadIdx.x < 64) {
+        const int r = threadIdx.x >> 3, q = threadIdx.x & 7;
+        int v = sub_mat[threadIdx.x];
+        if (r == 0)  // row 0 also stands for every target code >= 4
+            for (int rr = 4; rr < 8; rr++) v = max(v, sub_mat[rr * 8 + q]);
+        s_m[threadIdx.x] = max(v, -16383);
+    }
+    __syncthreads();
     for (int i = threadIdx.x; i < PK_TAB; i += nthreads) {
         const int rp = i & 15, qb = i >> 4;  // target bits select the LDS bank: they differ between lanes, query bytes rarely do
         const bool rev = (qb & 0x88) == 0x88;
@@ -450,13 +461,7 @@ __device__ __forceinline__ void pk_table_init(uint32_t* __restrict__ s_pk, const
             r0 = ((r0 & 1) << 1) | (r0 >> 1);
             r1 = ((r1 & 1) << 1) | (r1 >> 1);
         }
-        auto score = [&](int r, int q) -> int {
-            int v = sub_mat[r * 8 + q];
-            if (r == 0)  // row 0 also stands for every target code >= 4
-                for (int rr = 4; rr < 8; rr++) v = max(v, sub_mat[rr * 8 + q]);
-            return max(v, -16383);
-        };
-        const int s0 = score(r0, q0), s1 = score(r1, q1);
+        const int s0 = s_m[r0 * 8 + q0], s1 = s_m[r1 * 8 + q1];
         s_pk[i] = ((uint32_t)s0 & 0xffffu) | ((uint32_t)(s0 + s1) << 16);
     }
 }
@@ -777,20 +782,28 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
 //                                                          -> {ref_loc, query_loc, hidx} to the second level: kernel 1b on
 //                                                             that list (SRC_CAND), which decides between reject and the
 //                                                             exact kernels exactly as before.
-// one 16-base step: td = 16 target bases (2 bit each), q0 | q1 = 16 query bases (4 bit each), all in walking order
-__device__ __forceinline__ void pk_step16(const uint32_t* __restrict__ s_pk, uint32_t td, uint32_t q0, uint32_t q1, s16x2& T, s16x2& M) {
+// one 16-base step: td = 16 target bases (2 bit each) in walking order; qa | qb = the 16 query bases (4 bit each) as they lie
+// in memory -- REV = false: walking order (right side); REV = true: the bytes run against the walk (left side; qa holds the
+// first four pairs in bytes 3..0) and every byte must carry the 0x88 "reversed" flags of the pair table.
+// Address of a pair's table entry = (query byte << 6) | (target nibble << 2) = (query byte << 8 | target nibble << 4) >> 2:
+// the target nibbles of the step are spread into the high nibbles of two dwords (even / odd pairs: 3 ops), four byte
+// permutes zip them with the query bytes into 16-bit fields, and one SDWA shift per pair turns a field into the address --
+// 15 VALU ops of address arithmetic per 8 pairs instead of 24.
+template <bool REV>
+__device__ __forceinline__ void pk_step16(const uint32_t* __restrict__ s_pk, uint32_t td, uint32_t qa, uint32_t qb, s16x2& T, s16x2& M) {
+    const uint32_t ev = (td << 4) & 0xF0F0F0F0u;  // pairs 0, 2, 4, 6
+    const uint32_t od = td & 0xF0F0F0F0u;         // pairs 1, 3, 5, 7
+    // fields: low word = (query byte << 8) | nibble of the earlier pair, high word = the pair two steps later
+    const uint32_t f02 = __builtin_amdgcn_perm(qa, ev, REV ? 0x05010700u : 0x06010400u);
+    const uint32_t f13 = __builtin_amdgcn_perm(qa, od, REV ? 0x04010600u : 0x07010500u);
+    const uint32_t f46 = __builtin_amdgcn_perm(qb, ev, REV ? 0x05030702u : 0x06030402u);
+    const uint32_t f57 = __builtin_amdgcn_perm(qb, od, REV ? 0x04030602u : 0x07030502u);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const uint32_t qd = j < 4 ? q0 : q1;
-        uint32_t qaddr;  // (query byte j) << 6 in one SDWA shift
-        switch (j & 3) {
-            case 0: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(qaddr) : "v"(6), "v"(qd)); break;
-            case 1: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(qaddr) : "v"(6), "v"(qd)); break;
-            case 2: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(qaddr) : "v"(6), "v"(qd)); break;
-            default: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(qaddr) : "v"(6), "v"(qd)); break;
-        }
-        const uint32_t rp = (td >> (4 * j)) & 15u;
-        const uint32_t addr = (rp << 2) | qaddr;  // byte address of entry rp | qbyte << 4
+        const uint32_t f = j == 0 || j == 2 ? f02 : j == 1 || j == 3 ? f13 : j == 4 || j == 6 ? f46 : f57;
+        uint32_t addr;
+        if ((j & 2) == 0) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(addr) : "v"(2), "v"(f));
+        else asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(addr) : "v"(2), "v"(f));
         const s16x2 e = __builtin_bit_cast(s16x2, *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_pk) + addr));
         const s16x2 Tb = T.yy;
         T = __builtin_elementwise_add_sat(Tb, e);  // {t + s0, t + s0 + s1}
@@ -819,39 +832,31 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_ctx_kernel(ExtendArg
     cursor.seek(a, lane, (uint32_t)(b_lo << 6));
 
     // software pipeline: the records and query windows of buffer b + 1 are requested before buffer b is scored, so the HBM
-    // latency of the stream is covered by ~2000 cycles of arithmetic instead of by occupancy alone
+    // latency of the stream is covered by ~2000 cycles of arithmetic instead of by occupancy alone.  The loop is unrolled by
+    // two over a pair of register sets (no register-to-register copies between iterations).
     struct Loaded { uint4 c0, c1, qr0, ql0, ql1; uint2 qr1; uint32_t qp; };
-    auto request = [&](uint64_t b) -> Loaded {
-        Loaded L;
-        L.c0 = L.c1 = L.qr0 = L.ql0 = L.ql1 = make_uint4(0u, 0u, 0u, 0u);
-        L.qr1 = make_uint2(0u, 0u);
-        L.qp = 0;
-        if (b >= b_hi) return L;  // (wave-uniform)
+    auto request = [&](uint64_t b, Loaded& L) {
+        if (b >= b_hi) return;  // (wave-uniform)
         const uint64_t rem = a.num_hits - (b << 6);
         const int cnt = rem >= 64 ? 64 : (int)rem;
         uint64_t entry;
         cursor.locate(a, lane, (uint32_t)(b << 6), entry, L.qp);
-        if (lane < cnt) {
-            L.c0 = ctx[2 * entry];      // pos, r0, r1, r2
-            L.c1 = ctx[2 * entry + 1];  // l0 .. l3
-            // query windows: 48 bases from the anchor on, 64 bases before it (copy query_loc & 1 is byte aligned for both)
-            const uint32_t query_loc = L.qp + a.seed_size;  // :204
-            const uint8_t* qb = a.query4 + (size_t)(query_loc & 1u) * a.query4_stride + (query_loc >> 1);
-            L.qr0 = load16u(qb);
-            uint2 t;
-            __builtin_memcpy(&t, qb + 16, 8);
-            L.qr1 = t;
-            L.ql0 = load16u(qb - 32);
-            L.ql1 = load16u(qb - 16);
-        }
-        return L;
+        if (lane >= cnt) return;  // the lane sits out this buffer; its registers keep stale (unused) values
+        L.c0 = ctx[2 * entry];      // pos, r0, r1, r2
+        L.c1 = ctx[2 * entry + 1];  // l0 .. l3
+        // query windows: 48 bases from the anchor on, 64 bases before it (copy query_loc & 1 is byte aligned for both)
+        const uint32_t query_loc = L.qp + a.seed_size;  // :204
+        const uint8_t* qb = a.query4 + (size_t)(query_loc & 1u) * a.query4_stride + (query_loc >> 1);
+        L.qr0 = load16u(qb);
+        uint2 t;
+        __builtin_memcpy(&t, qb + 16, 8);
+        L.qr1 = t;
+        L.ql0 = load16u(qb - 32);
+        L.ql1 = load16u(qb - 16);
     };
-    Loaded nxt = request(b_lo);
-    for (uint64_t b = b_lo; b < b_hi; b++) {
+    auto score = [&](uint64_t b, const Loaded& cur) {
         const uint64_t rem = a.num_hits - (b << 6);
         const int cnt = rem >= 64 ? 64 : (int)rem;
-        const Loaded cur = nxt;
-        nxt = request(b + 1);
         const bool valid = lane < cnt;
         const uint4 c0 = cur.c0, c1 = cur.c1, qr0 = cur.qr0, ql0 = cur.ql0, ql1 = cur.ql1;
         const uint2 qr1 = cur.qr1;
@@ -869,27 +874,27 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_ctx_kernel(ExtendArg
                 const uint32_t td = st == 0 ? c0.y : st == 1 ? c0.z : c0.w;
                 const uint32_t q0 = st == 0 ? qr0.x : st == 1 ? qr0.z : qr1.x;
                 const uint32_t q1 = st == 0 ? qr0.y : st == 1 ? qr0.w : qr1.y;
-                pk_step16(s_pk, td, q0, q1, T, M);
+                pk_step16<false>(s_pk, td, q0, q1, T, M);
                 m = max((int)M.x, (int)M.y);
                 alive = (m - (int)T.y) <= xdrop;  // :374, looked at once per 16 bases
             }
         }
         bool undecided = alive;  // still walking at the end of the context
         const int bestR = m;
-        // ---- left side (:478-604): 4 steps on the pre-reversed context, query bytes reversed + flagged ----
+        // ---- left side (:478-604): 4 steps on the pre-reversed context; the query bytes run against the walk ----
         T = (s16x2){0, 0};
         M = (s16x2){0, 0};
         alive = !skip;
         m = 0;
         {
-            const uint32_t RV = 0x00010203u, D = 0x88888888u;
+            const uint32_t D = 0x88888888u;
 #pragma unroll
             for (int st = 0; st < 4; st++) {
                 if (alive) {
                     const uint32_t td = st == 0 ? c1.x : st == 1 ? c1.y : st == 2 ? c1.z : c1.w;
                     const uint32_t a0 = st == 0 ? ql1.w : st == 1 ? ql1.y : st == 2 ? ql0.w : ql0.y;
                     const uint32_t a1 = st == 0 ? ql1.z : st == 1 ? ql1.x : st == 2 ? ql0.z : ql0.x;
-                    pk_step16(s_pk, td, __builtin_amdgcn_perm(0u, a0, RV) | D, __builtin_amdgcn_perm(0u, a1, RV) | D, T, M);
+                    pk_step16<true>(s_pk, td, a0 | D, a1 | D, T, M);
                     m = max((int)M.x, (int)M.y);
                     alive = (m - (int)T.y) <= xdrop;  // :523
                 }
@@ -900,6 +905,18 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_ctx_kernel(ExtendArg
         CandRec cr;
         cr.ref_loc = ref_loc; cr.query_loc = query_loc; cr.hidx = (uint32_t)(b << 6) + (uint32_t)lane;
         stage_append(stage, n_stage, fwd, cr, a.l2_list, a.l2_count, a.l2_cap, lane, lane_lt);
+    };
+    Loaded A, B;
+    A.c0 = A.c1 = A.qr0 = A.ql0 = A.ql1 = make_uint4(0u, 0u, 0u, 0u);
+    A.qr1 = make_uint2(0u, 0u);
+    A.qp = 0;
+    B = A;
+    request(b_lo, A);
+    for (uint64_t b = b_lo; b < b_hi; b += 2) {
+        request(b + 1, B);
+        score(b, A);
+        request(b + 2, A);
+        if (b + 1 < b_hi) score(b + 1, B);
     }
     stage_flush(stage, n_stage, a.l2_list, a.l2_count, a.l2_cap, lane);
 }

@@ -67,9 +67,9 @@ def test_lookup_paths_under_a_max_hits_split(oracle, clean, mode, env):
     """num_hits >= MAX_HITS (hazard H4): more than two reference iterations -- a table-direct call must hand the chunk to the
     general path (the plan then needs per-seed-word prefixes); below the limit it keeps the two-iteration split."""
     with_env(env)
-    t, q = synth.make_pair(150000, 51, 52, sub_rate=0.07, mask_frac=0.1)
+    t, q = synth.make_pair(100000, 51, 52, sub_rate=0.07, mask_frac=0.1)
     c = Case(t, q, chunk=50000).oracle_setup(oracle).engine_setup(clean)
-    for mh in (3000, 40000, 1 << 30):
+    for mh in (8000, 40000, 1 << 30):
         c.E.set_max_hits(mh)
         for rev in (False, True):
             for (s, e) in c.chunks():

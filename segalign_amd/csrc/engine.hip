@@ -233,6 +233,7 @@ struct Slot {
     DevBuf<uint64_t> td_toff;
     DevBuf<uint32_t> td_tcnt;
     DevBuf<TdRec> td_rec;
+    DevBuf<uint32_t> td_chunk;
     DevBuf<uint8_t> td_partial;
     void* d_td_bounds = nullptr;
     TdPlan* d_td_plan = nullptr;
@@ -316,7 +317,6 @@ static int g_bufs_per_wave = 8;   // SEGALIGN_AMD_BUFS_PER_WAVE
 static int g_long_cap = 128;      // SEGALIGN_AMD_LONG_CAP: bases per side before a hit goes to the long kernel
 static int g_long_blocks = 1792;  // SEGALIGN_AMD_LONG_BLOCKS: grid of the long kernel (4 waves per block)
 static int g_packed_waves = 4096; // SEGALIGN_AMD_PACKED_WAVES: waves of the packed filter (2 workgroups of 8 waves per CU measured best: 3072 +16 %, 6144 +20 %, 8192 +14 %)
-static int g_ctx_waves = 6144;    // SEGALIGN_AMD_CTX_WAVES: waves of the context filter (8 per SIMD: the kernel is a software-pipelined stream)
 static int g_l2_blocks = 256;     // SEGALIGN_AMD_L2_BLOCKS: workgroups of the second-level packed filter
 static int g_max_waves = 4096;    // SEGALIGN_AMD_MAX_WAVES: waves of the filter kernel (4 per SIMD saturate instruction issue)
 static int g_fast_filter = 0;     // derived in InitializeProcessor: xdrop >= 0 && 7*max(M) <= xdrop
@@ -429,7 +429,7 @@ static void slot_destroy(Slot& s) {
     s.chain_heads.release("chain"); s.chain_bucket_cnt.release("chain"); s.chain_bucket_start.release("chain"); s.ent_list.release("entropy list");
     s.cov_diff.release("coverage"); s.cov_pre.release("coverage"); s.cov_is_start.release("coverage");
     s.cov_is_end.release("coverage"); s.cov_sidx.release("coverage"); s.cov_eidx.release("coverage"); s.cov_pairs.release("coverage");
-    s.td_toff.release("probe"); s.td_tcnt.release("probe"); s.td_rec.release("probe"); s.td_partial.release("probe");
+    s.td_toff.release("probe"); s.td_tcnt.release("probe"); s.td_rec.release("probe"); s.td_chunk.release("probe"); s.td_partial.release("probe");
     dev_free(s.d_td_bounds, "probe bounds"); dev_free(s.d_td_plan, "probe plan"); dev_free(s.d_seg_info, "segment info");
     s.d_td_bounds = nullptr; s.d_td_plan = nullptr; s.d_seg_info = nullptr;
     if (s.h_seg_info) hipHostFree(s.h_seg_info);
@@ -607,13 +607,13 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                 if (ca.td) {
                     ea.td = 1;
                     ea.td_rec = sl->td_rec.p;
+                    ea.td_chunk = sl->td_chunk.p;
                     ea.td_m = sl->h_td_plan[K - 1].m_hi;
                     ea.td_pos = dc->nbr_pos;
                     ea.td_ctx = dc->nbr_ctx;
                     ea.seed_size = g_seed_size;
                     if (ea.td_ctx) sl->l2_list.ensure((size_t)std::max<uint64_t>(1u << 16, bh / 8), "second-level list");
                     ea.l2_count = &sl->d_cnt->n_l2;
-                    ea.ctx_waves = (uint32_t)g_ctx_waves;
                     ea.l2_blocks = (uint32_t)g_l2_blocks;
                 } else if (!ca.raw_hits) {
                     sl->hits.ensure((size_t)bh, "hits");
@@ -1079,6 +1079,7 @@ static uint32_t td_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, int K, con
     sl->td_toff.ensure(n, "probe scratch");
     sl->td_tcnt.ensure(n, "probe scratch");
     sl->td_rec.ensure((size_t)n + 1, "probe records");
+    sl->td_chunk.ensure(TD_CHUNK_CAP, "probe chunk starts");
     sl->td_partial.ensure(probe_partial_bytes(n), "probe partials");
     TdBounds tb;
     tb.nb = K + 1;
@@ -1089,7 +1090,7 @@ static uint32_t td_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, int K, con
     }
     {
         ProfScope p(sl, "probe_compact");
-        launch_probe_compact(start, n, sl->td_toff.p, sl->td_tcnt.p, sl->td_partial.p, sl->d_td_bounds, sl->td_rec.p, tb, st);
+        launch_probe_compact(start, n, sl->td_toff.p, sl->td_tcnt.p, sl->td_partial.p, sl->d_td_bounds, sl->td_rec.p, sl->td_chunk.p, TD_CHUNK_CAP, tb, st);
     }
     {
         ProfScope p(sl, "iteration_plan");
@@ -1221,7 +1222,6 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
     if (const char* e = getenv("SEGALIGN_AMD_LONG_BLOCKS")) g_long_blocks = std::max(1, atoi(e));
     if (const char* e = getenv("SEGALIGN_AMD_MAX_WAVES")) g_max_waves = std::max(4, atoi(e));
     if (const char* e = getenv("SEGALIGN_AMD_PACKED_WAVES")) g_packed_waves = std::max(8, atoi(e));
-    if (const char* e = getenv("SEGALIGN_AMD_CTX_WAVES")) g_ctx_waves = std::max(8, atoi(e));
     if (const char* e = getenv("SEGALIGN_AMD_L2_BLOCKS")) g_l2_blocks = std::max(1, atoi(e));
     if (xdrop >= (1 << 25) || xdrop <= -(1 << 25)) {
         fprintf(stderr, "Error: |xdrop| must be below 2^25\n");

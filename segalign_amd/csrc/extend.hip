@@ -823,13 +823,16 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_ctx_kernel(ExtendArg
     const int xdrop = a.xdrop;
     const uint4* __restrict__ ctx = reinterpret_cast<const uint4*>(a.td_ctx);
 
+    // one chunk of TD_CHUNK_HITS hits (32 buffers) per wave: short-lived workgroups, so that the small kernels of the call
+    // running on the other slot find free CUs while this one streams; the chunk's first record was noted by the probe
     const uint64_t num_buf = (a.num_hits + 63) >> 6;
-    const uint64_t W = (uint64_t)gridDim.x * (PK_THREADS / 64);
     const uint64_t wid = (uint64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (PK_THREADS / 64) + (threadIdx.x >> 6)));
-    const uint64_t b_lo = (wid * num_buf) / W, b_hi = ((wid + 1) * num_buf) / W;
+    const uint64_t b_lo = wid * (TD_CHUNK_HITS / 64);
+    const uint64_t b_hi = min(b_lo + TD_CHUNK_HITS / 64, num_buf);
     if (b_lo >= b_hi) return;
     TdCursor cursor = {0u, {0u, 0u, 0ull}, 0u};
-    cursor.seek(a, lane, (uint32_t)(b_lo << 6));
+    cursor.m0 = a.td_chunk[wid];
+    cursor.load_window(a, lane);
 
     // software pipeline: the records and query windows of buffer b + 1 are requested before buffer b is scored, so the HBM
     // latency of the stream is covered by ~2000 cycles of arithmetic instead of by occupancy alone.  The loop is unrolled by
@@ -1347,11 +1350,7 @@ void launch_extend_filter(const ExtendArgs& a, hipStream_t s) {
 // context filter (1c): table-direct calls whose neighbourhood table carries the target context; fills a.l2_list
 void launch_extend_filter_ctx(const ExtendArgs& a, hipStream_t s) {
     if (a.num_hits == 0) return;
-    const uint64_t num_buf = (a.num_hits + 63) / 64;
-    uint64_t waves = num_buf / 4;  // every buffer costs the same: a few buffers per wave are enough to amortise the set-up
-    const uint64_t max_waves = a.ctx_waves ? a.ctx_waves : 8192u;
-    if (waves > max_waves) waves = max_waves;
-    if (waves < 8) waves = 8;
+    const uint64_t waves = (a.num_hits + TD_CHUNK_HITS - 1) / TD_CHUNK_HITS;  // one chunk per wave
     const uint32_t blocks = (uint32_t)((waves + PK_THREADS / 64 - 1) / (PK_THREADS / 64));
     hipLaunchKernelGGL(extend_filter_ctx_kernel, dim3(blocks), dim3(PK_THREADS), 0, s, a);
 }

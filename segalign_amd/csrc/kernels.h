@@ -48,6 +48,9 @@ struct EntRec {               // finished hit with hspthresh <= total <= 3*hspth
     uint32_t seg;
 };
 
+constexpr uint32_t TD_CHUNK_HITS = 2048;  // hits one wave of the context filter handles (32 buffers of 64)
+constexpr uint32_t TD_CHUNK_CAP = 1u << 21;  // chunk starts a call can record: 2^21 * 2048 = 2^32 hits, the table-direct limit
+
 struct TdRec {                // table-direct lookup (probe.hip): a non-empty query position of the call
     uint32_t prefix;          // call-wide index of the position's first hit (a table-direct call holds < 2^32 hits)
     uint32_t qpos;            // query position (seed start)
@@ -100,6 +103,7 @@ struct ExtendArgs {
     // TD ("table direct", probe.hip): no hit list -- hit g of the call is entry g - td_prefix[m] of the run of the m-th
     // non-empty query position; the packed filter reads its anchors straight out of the neighbourhood table
     int td;
+    const uint32_t* td_chunk;   // [ceil(num_hits / TD_CHUNK_HITS)] record that holds the first hit of every chunk
     const TdRec* td_rec;        // [td_m + 1] one record per NON-EMPTY query position, in query order; td_rec[td_m].prefix = num_hits
     uint32_t td_m;
     const uint32_t* td_pos;     // neighbourhood table runs: seed START positions in the target (+ seed_size = anchor, :220)
@@ -108,8 +112,7 @@ struct ExtendArgs {
     uint32_t* l2_count;
     uint32_t l2_cap;
     int src_cand;               // packed filter reads its anchors from l2_list / *l2_count instead of `hits`
-    uint32_t ctx_waves;         // wave budget of the context filter; l2_blocks: grid of the second level (count known on the device only)
-    uint32_t l2_blocks;
+    uint32_t l2_blocks;         // grid of the second level (its hit count is known on the device only)
     uint32_t seed_size;
     uint64_t num_hits;
     uint64_t hit_base;        // global index of hits[0] inside the call (segment boundaries are global)

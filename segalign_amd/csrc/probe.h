@@ -37,8 +37,9 @@ size_t probe_partial_bytes(uint32_t n);
 size_t probe_bounds_bytes();
 void launch_probe_lookup(const uint8_t* query, uint32_t start, uint32_t n, SeedShape sh, const uint64_t* nbr_start, uint32_t nkeys,
                          uint64_t* t_off, uint32_t* t_cnt, void* partial_buf, hipStream_t s);
+// chunk_rec[k] (k < chunk_cap) = index of the record that holds hit k * TD_CHUNK_HITS of the call
 void launch_probe_compact(uint32_t start, uint32_t n, const uint64_t* t_off, const uint32_t* t_cnt, void* partial_buf, void* bounds_buf,
-                          TdRec* c_rec, const TdBounds& bpos, hipStream_t s);
+                          TdRec* c_rec, uint32_t* chunk_rec, uint32_t chunk_cap, const TdBounds& bpos, hipStream_t s);
 void launch_probe_plan(const uint8_t* query, SeedShape sh, uint32_t tmask, const uint32_t* bucket_start, const void* bounds_buf, int nchunks,
                        const TdRec* c_rec, TdPlan* plan, hipStream_t s);
 

@@ -203,6 +203,7 @@ __global__ __launch_bounds__(PR_THREADS) void probe_partials_kernel(Tri* __restr
 __global__ __launch_bounds__(PR_THREADS) void probe_compact_kernel(uint32_t start, uint32_t n, const uint64_t* __restrict__ t_off,
                                                                    const uint32_t* __restrict__ t_cnt, const Tri* __restrict__ partial,
                                                                    const Tri* __restrict__ total, TdRec* __restrict__ c_rec,
+                                                                   uint32_t* __restrict__ chunk_rec, uint32_t chunk_cap,
                                                                    TdBounds bpos, Tri* __restrict__ bounds) {
     const uint32_t i0 = blockIdx.x * PR_TILE + threadIdx.x * PR_ITEMS;
     uint64_t off[PR_ITEMS];
@@ -236,6 +237,9 @@ __global__ __launch_bounds__(PR_THREADS) void probe_compact_kernel(uint32_t star
             r.qpos = start + i;
             r.off = off[j] & ~PR_VALID;
             c_rec[run.ne] = r;
+            // which record holds hit k * TD_CHUNK_HITS?  (the context filter's waves start there without searching)
+            for (uint64_t k = (run.hits + TD_CHUNK_HITS - 1) / TD_CHUNK_HITS; k * TD_CHUNK_HITS < run.hits + cnt[j] && k < chunk_cap; k++)
+                chunk_rec[k] = run.ne;
         }
         run.hits += cnt[j];
         run.ne += cnt[j] ? 1u : 0u;
@@ -298,13 +302,13 @@ void launch_probe_lookup(const uint8_t* query, uint32_t start, uint32_t n, SeedS
                        reinterpret_cast<Tri*>(partial_buf));
 }
 void launch_probe_compact(uint32_t start, uint32_t n, const uint64_t* t_off, const uint32_t* t_cnt, void* partial_buf, void* bounds_buf,
-                          TdRec* c_rec, const TdBounds& bpos, hipStream_t s) {
+                          TdRec* c_rec, uint32_t* chunk_rec, uint32_t chunk_cap, const TdBounds& bpos, hipStream_t s) {
     Tri* partial = reinterpret_cast<Tri*>(partial_buf);
     const uint32_t nblocks = probe_blocks(n);
     Tri* total = partial + nblocks;
     hipLaunchKernelGGL(probe_partials_kernel, dim3(1), dim3(PR_THREADS), 0, s, partial, nblocks, total);
-    hipLaunchKernelGGL(probe_compact_kernel, dim3(nblocks), dim3(PR_THREADS), 0, s, start, n, t_off, t_cnt, partial, total, c_rec, bpos,
-                       reinterpret_cast<Tri*>(bounds_buf));
+    hipLaunchKernelGGL(probe_compact_kernel, dim3(nblocks), dim3(PR_THREADS), 0, s, start, n, t_off, t_cnt, partial, total, c_rec, chunk_rec,
+                       chunk_cap, bpos, reinterpret_cast<Tri*>(bounds_buf));
 }
 void launch_probe_plan(const uint8_t* query, SeedShape sh, uint32_t tmask, const uint32_t* bucket_start, const void* bounds_buf, int nchunks,
                        const TdRec* c_rec, TdPlan* plan, hipStream_t s) {

@@ -172,7 +172,7 @@ constexpr int DEDUP_SMALL_SEGS = 16;  // distinct segment ids (reference iterati
 // lower segments); the host closes the gaps while it splits the output per chunk anyway.  Eight small workgroups on eight
 // CUs instead of one 1024-thread workgroup walking all records: the stage's latency drops from ~200 us (500 us next to a
 // running filter kernel) to ~20 us, and the limit rises from 1024 survivors per call to 1024 per segment.
-constexpr int DEDUP_SEG_THREADS = 256;
+constexpr int DEDUP_SEG_THREADS = 1024;
 constexpr int DEDUP_SEG_MAX = 1024;      // records per segment
 constexpr int DEDUP_SEG_TOTAL = 16384;   // survivors per call (every workgroup scans the whole list once)
 

@@ -823,7 +823,7 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_ctx_kernel(ExtendArg
     const int xdrop = a.xdrop;
     const uint4* __restrict__ ctx = reinterpret_cast<const uint4*>(a.td_ctx);
 
-    // one chunk of TD_CHUNK_HITS hits (32 buffers) per wave: short-lived workgroups, so that the small kernels of the call
+    // one chunk of TD_CHUNK_HITS hits (64 buffers) per wave: short-lived workgroups, so that the small kernels of the call
     // running on the other slot find free CUs while this one streams; the chunk's first record was noted by the probe
     const uint64_t num_buf = (a.num_hits + 63) >> 6;
     const uint64_t wid = (uint64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (PK_THREADS / 64) + (threadIdx.x >> 6)));

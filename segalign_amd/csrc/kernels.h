@@ -48,8 +48,8 @@ struct EntRec {               // finished hit with hspthresh <= total <= 3*hspth
     uint32_t seg;
 };
 
-constexpr uint32_t TD_CHUNK_HITS = 2048;  // hits one wave of the context filter handles (32 buffers of 64)
-constexpr uint32_t TD_CHUNK_CAP = 1u << 21;  // chunk starts a call can record: 2^21 * 2048 = 2^32 hits, the table-direct limit
+constexpr uint32_t TD_CHUNK_HITS = 4096;  // hits one wave of the context filter handles (64 buffers of 64)
+constexpr uint32_t TD_CHUNK_CAP = 1u << 20;  // chunk starts a call can record: 2^20 * 4096 = 2^32 hits, the table-direct limit
 
 struct TdRec {                // table-direct lookup (probe.hip): a non-empty query position of the call
     uint32_t prefix;          // call-wide index of the position's first hit (a table-direct call holds < 2^32 hits)

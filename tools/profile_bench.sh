@@ -6,7 +6,8 @@
 # SQ 8 / TCC 4 / GRBM 2 per pass; FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2 -> one pass each).
 set -u
 TAG=$1; shift
-PMC_ARGS=${PMC_ARGS:---steps 2 --warmup 0 --no-cpu-baseline}
+PMC_ARGS=${PMC_ARGS:---steps 1 --warmup 0 --no-cpu-baseline}
+WORKLOAD=${WORKLOAD:-ce11cb4}; TARGET_MBP=${TARGET_MBP:-100.0}; CHUNK=${CHUNK:-250000}   # key of the profiled workload shape
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
@@ -14,6 +15,7 @@ RAW=/tmp/prof_raw_$TAG
 rm -rf $RAW; mkdir -p $OUT $RAW
 cd $R
 echo "stats pass: python bench.py $*" > $OUT/commands.txt
+python -c "import json,sys; json.dump({'workload': sys.argv[1], 'target_mbp': float(sys.argv[2]), 'chunk': int(sys.argv[3])}, open(sys.argv[4], 'w'))" $WORKLOAD $TARGET_MBP $CHUNK $OUT/workload.json   # bench.py quotes traffic.json only for this shape
 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/stats -o r -- python bench.py "$@" > $OUT/bench_under_stats.log 2>&1
 python tools/prof_summary.py $RAW/stats --out $OUT/kernel_stats.txt
 grep "^{\"metric\"" $OUT/bench_under_stats.log | tail -1 > $OUT/bench_line_under_stats.json

@@ -119,7 +119,7 @@ void launch_nbr_fill(const uint32_t* bucket_start, const uint32_t* pos_table, ui
 // probe: positions -> runs
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int PR_THREADS = 256;
-constexpr int PR_ITEMS = 4;                       // consecutive positions per thread
+constexpr int PR_ITEMS = 1;                       // positions per thread (one 16-byte gather each: parallelism hides its latency)
 constexpr int PR_TILE = PR_THREADS * PR_ITEMS;    // positions per workgroup
 
 struct Tri { uint64_t hits; uint32_t ne, valid; };  // (hits, non-empty positions, valid positions)
@@ -187,16 +187,19 @@ __global__ __launch_bounds__(PR_THREADS) void probe_kernel(const uint8_t* __rest
 }
 
 __global__ __launch_bounds__(PR_THREADS) void probe_partials_kernel(Tri* __restrict__ partial, uint32_t nblocks, Tri* __restrict__ total_out) {
-    Tri carry = {0, 0, 0};
-    for (uint32_t base = 0; base < nblocks; base += PR_THREADS) {
-        const uint32_t i = base + threadIdx.x;
-        const Tri v = i < nblocks ? partial[i] : Tri{0, 0, 0};
-        Tri total;
-        const Tri ex = block_excl_scan(v, total);
-        if (i < nblocks) partial[i] = tri_add(carry, ex);
-        carry = tri_add(carry, total);
+    // one workgroup: every thread owns a contiguous slice of the block sums (serial sum, ONE workgroup scan, serial write-back)
+    const uint32_t per = (nblocks + PR_THREADS - 1) / PR_THREADS;
+    const uint32_t lo = min(threadIdx.x * per, nblocks), hi = min(lo + per, nblocks);
+    Tri mine = {0, 0, 0};
+    for (uint32_t i = lo; i < hi; i++) mine = tri_add(mine, partial[i]);
+    Tri total;
+    Tri run = block_excl_scan(mine, total);
+    for (uint32_t i = lo; i < hi; i++) {
+        const Tri v = partial[i];
+        partial[i] = run;
+        run = tri_add(run, v);
     }
-    if (threadIdx.x == 0) *total_out = carry;
+    if (threadIdx.x == 0) *total_out = total;
 }
 
 // bounds[c] = exclusive prefix (hits, non-empty, valid) at position bpos[c] - start, c = 0..nb-1 (a bound == n takes the total)

@@ -440,6 +440,7 @@ constexpr int PK_THREADS = 512;
 constexpr int PK_TAB = 4096;
 
 // ---- pair table: entry (4 target bits | query byte << 4) = {s0, s0 + s1} as two int16 (see above) ---------------------
+template <bool WIDE>  // WIDE: 8-byte entries {s0 + s1, max(s0, s0 + s1)} as two int32 (context filter); else {s0, s0 + s1} as two int16
 __device__ __forceinline__ void pk_table_init(uint32_t* __restrict__ s_pk, const int* __restrict__ sub_mat, int nthreads) {
     // the 64 matrix entries go through LDS first (the 4096 pair entries read ~10 of them each): the row-0 maximum over
     // the rows {A, L, N, X, E} is folded in there, scores are raised to -16383
@@ -462,7 +463,12 @@ __device__ __forceinline__ void pk_table_init(uint32_t* __restrict__ s_pk, const
             r1 = ((r1 & 1) << 1) | (r1 >> 1);
         }
         const int s0 = s_m[r0 * 8 + q0], s1 = s_m[r1 * 8 + q1];
-        s_pk[i] = ((uint32_t)s0 & 0xffffu) | ((uint32_t)(s0 + s1) << 16);
+        if (WIDE) {
+            s_pk[2 * i] = (uint32_t)(s0 + s1);
+            s_pk[2 * i + 1] = (uint32_t)max(s0, s0 + s1);
+        } else {
+            s_pk[i] = ((uint32_t)s0 & 0xffffu) | ((uint32_t)(s0 + s1) << 16);
+        }
     }
 }
 
@@ -528,7 +534,7 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
     constexpr bool TD = SRC == SRC_TD;
     __shared__ uint32_t s_pk[PK_TAB];
     __shared__ CandRec s_cand[PK_THREADS / 64][STAGE_CAP];
-    pk_table_init(s_pk, a.sub_mat, PK_THREADS);
+    pk_table_init<false>(s_pk, a.sub_mat, PK_THREADS);
     __syncthreads();
     CandRec* stage = s_cand[threadIdx.x >> 6];
     int n_stage = 0;
@@ -778,6 +784,7 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
 // lane machinery of 1b disappears: a wave walks its contiguous range of 64-hit buffers in lockstep.
 // Verdicts (all conservative -- the scores are the same upper bounds as in 1b):
 //   both sides dropped inside the context and bestR + bestL cannot pass (:608-633)  -> rejected here (~96 % of all hits)
+//   (scores are int32 here: the int16 limits of 1b do not apply to this level)
 //   a side still alive at the end of its context (1.6 % right, 2.4 % left on random hits), or the bound passes
 //                                                          -> {ref_loc, query_loc, hidx} to the second level: kernel 1b on
 //                                                             that list (SRC_CAND), which decides between reject and the
@@ -785,12 +792,16 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
 // one 16-base step: td = 16 target bases (2 bit each) in walking order; qa | qb = the 16 query bases (4 bit each) as they lie
 // in memory -- REV = false: walking order (right side); REV = true: the bytes run against the walk (left side; qa holds the
 // first four pairs in bytes 3..0) and every byte must carry the 0x88 "reversed" flags of the pair table.
-// Address of a pair's table entry = (query byte << 6) | (target nibble << 2) = (query byte << 8 | target nibble << 4) >> 2:
-// the target nibbles of the step are spread into the high nibbles of two dwords (even / odd pairs: 3 ops), four byte
-// permutes zip them with the query bytes into 16-bit fields, and one SDWA shift per pair turns a field into the address --
-// 15 VALU ops of address arithmetic per 8 pairs instead of 24.
+// Instruction choice follows tools/micro/valu_rate.hip: on gfx950 plain 32-bit VOP2 ops (v_add_u32, v_max_i32, v_and_b32,
+// shifts) issue in ~2.8 cycles per wave, everything packed / SDWA / VOP3 (v_pk_add_i16, v_pk_max_i16, v_perm_b32, v_bfe)
+// in ~4.6.  So the context filter scores in int32 -- table entries are 8 bytes {sum = s0 + s1, mx = max(s0, s0 + s1)}, per
+// pair M = max(M, T + mx); T += sum: three full-rate ops, no saturation, no int16 limits -- and only the address
+// arithmetic uses the slow forms: byte address of a pair's entry = (query byte << 7) | (target nibble << 3)
+// = (query byte << 8 | target nibble << 4) >> 1; the 8 target nibbles of the step are spread into the high nibbles of two
+// dwords (even / odd pairs: 3 ops), four byte permutes zip them with the query bytes into 16-bit fields, one SDWA shift per
+// pair turns a field into the address.
 template <bool REV>
-__device__ __forceinline__ void pk_step16(const uint32_t* __restrict__ s_pk, uint32_t td, uint32_t qa, uint32_t qb, s16x2& T, s16x2& M) {
+__device__ __forceinline__ void ctx_step16(const uint32_t* __restrict__ s_tab, uint32_t td, uint32_t qa, uint32_t qb, int& T, int& M) {
     const uint32_t ev = (td << 4) & 0xF0F0F0F0u;  // pairs 0, 2, 4, 6
     const uint32_t od = td & 0xF0F0F0F0u;         // pairs 1, 3, 5, 7
     // fields: low word = (query byte << 8) | nibble of the earlier pair, high word = the pair two steps later
@@ -802,19 +813,18 @@ __device__ __forceinline__ void pk_step16(const uint32_t* __restrict__ s_pk, uin
     for (int j = 0; j < 8; j++) {
         const uint32_t f = j == 0 || j == 2 ? f02 : j == 1 || j == 3 ? f13 : j == 4 || j == 6 ? f46 : f57;
         uint32_t addr;
-        if ((j & 2) == 0) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(addr) : "v"(2), "v"(f));
-        else asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(addr) : "v"(2), "v"(f));
-        const s16x2 e = __builtin_bit_cast(s16x2, *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_pk) + addr));
-        const s16x2 Tb = T.yy;
-        T = __builtin_elementwise_add_sat(Tb, e);  // {t + s0, t + s0 + s1}
-        M = __builtin_elementwise_max(M, T);
+        if ((j & 2) == 0) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(addr) : "v"(1), "v"(f));
+        else asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(addr) : "v"(1), "v"(f));
+        const uint2 e = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(s_tab) + addr);  // one ds_read_b64
+        M = max(M, T + (int)e.y);
+        T += (int)e.x;
     }
 }
 
 __global__ __launch_bounds__(PK_THREADS) void extend_filter_ctx_kernel(ExtendArgs a) {
-    __shared__ uint32_t s_pk[PK_TAB];
+    __shared__ uint32_t s_pk[2 * PK_TAB];  // 8-byte entries {sum, max prefix} (32 KB)
     __shared__ CandRec s_cand[PK_THREADS / 64][STAGE_CAP];
-    pk_table_init(s_pk, a.sub_mat, PK_THREADS);
+    pk_table_init<true>(s_pk, a.sub_mat, PK_THREADS);
     __syncthreads();
     CandRec* stage = s_cand[threadIdx.x >> 6];
     int n_stage = 0;
@@ -868,27 +878,24 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_ctx_kernel(ExtendArg
         bool skip = !valid;
         if (a.rm) skip = skip || !(ref_loc >= a.rm_win_start && ref_loc <= a.rm_win_end);  // rm :239-244,:305-333: total stays 0
         // ---- right side (:326-453): 3 steps ----
-        s16x2 T = {0, 0}, M = {0, 0};
+        int T = 0, M = 0;  // running score, best score of the side (upper bounds, see 1b)
         bool alive = !skip;
-        int m = 0;
 #pragma unroll
         for (int st = 0; st < 3; st++) {
             if (alive) {
                 const uint32_t td = st == 0 ? c0.y : st == 1 ? c0.z : c0.w;
                 const uint32_t q0 = st == 0 ? qr0.x : st == 1 ? qr0.z : qr1.x;
                 const uint32_t q1 = st == 0 ? qr0.y : st == 1 ? qr0.w : qr1.y;
-                pk_step16<false>(s_pk, td, q0, q1, T, M);
-                m = max((int)M.x, (int)M.y);
-                alive = (m - (int)T.y) <= xdrop;  // :374, looked at once per 16 bases
+                ctx_step16<false>(s_pk, td, q0, q1, T, M);
+                alive = (M - T) <= xdrop;  // :374, looked at once per 16 bases
             }
         }
         bool undecided = alive;  // still walking at the end of the context
-        const int bestR = m;
+        const int bestR = M;
         // ---- left side (:478-604): 4 steps on the pre-reversed context; the query bytes run against the walk ----
-        T = (s16x2){0, 0};
-        M = (s16x2){0, 0};
+        T = 0;
+        M = 0;
         alive = !skip;
-        m = 0;
         {
             const uint32_t D = 0x88888888u;
 #pragma unroll
@@ -897,14 +904,13 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_ctx_kernel(ExtendArg
                     const uint32_t td = st == 0 ? c1.x : st == 1 ? c1.y : st == 2 ? c1.z : c1.w;
                     const uint32_t a0 = st == 0 ? ql1.w : st == 1 ? ql1.y : st == 2 ? ql0.w : ql0.y;
                     const uint32_t a1 = st == 0 ? ql1.z : st == 1 ? ql1.x : st == 2 ? ql0.z : ql0.x;
-                    pk_step16<true>(s_pk, td, a0 | D, a1 | D, T, M);
-                    m = max((int)M.x, (int)M.y);
-                    alive = (m - (int)T.y) <= xdrop;  // :523
+                    ctx_step16<true>(s_pk, td, a0 | D, a1 | D, T, M);
+                    alive = (M - T) <= xdrop;  // :523
                 }
             }
         }
         undecided = undecided || alive;
-        const bool fwd = !skip && (undecided || classify(a, bestR + m) != 0);
+        const bool fwd = !skip && (undecided || classify(a, bestR + M) != 0);
         CandRec cr;
         cr.ref_loc = ref_loc; cr.query_loc = query_loc; cr.hidx = (uint32_t)(b << 6) + (uint32_t)lane;
         stage_append(stage, n_stage, fwd, cr, a.l2_list, a.l2_count, a.l2_cap, lane, lane_lt);

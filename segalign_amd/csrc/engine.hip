@@ -144,10 +144,10 @@ struct PackedBuf {  // phase copies of a packed sequence (packed X-drop filter):
         }
         const uint32_t nbytes = len / 2 + 1;
         stride = ((size_t)nbytes + 2 * PACK_PAD + 127) & ~(size_t)127;
-        reserve(stride * 2, tag);
+        reserve(stride * PACK4_COPIES, tag);
         // pads read as code 7 in both nibbles (any content keeps the filter's scores upper bounds; this makes a walk that
         // leaves the block die quickly under the default matrices)
-        check_memcpy(hipMemsetAsync(alloc, 0x77, stride * 2, s), tag);
+        check_memcpy(hipMemsetAsync(alloc, 0x77, stride * PACK4_COPIES, s), tag);
         base = alloc + PACK_PAD;
         launch_pack4_phases(codes, len, base, stride, nbytes, s);
     }

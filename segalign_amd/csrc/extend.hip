@@ -857,9 +857,11 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_ctx_kernel(ExtendArg
         if (lane >= cnt) return;  // the lane sits out this buffer; its registers keep stale (unused) values
         L.c0 = ctx[2 * entry];      // pos, r0, r1, r2
         L.c1 = ctx[2 * entry + 1];  // l0 .. l3
-        // query windows: 48 bases from the anchor on, 64 bases before it (copy query_loc & 1 is byte aligned for both)
+        // query windows: 48 bases from the anchor on, 64 bases before it, from the 4-bit copy in which both are DWORD aligned
+        // (encode.hip: byte-aligned 16-byte loads take the slow path of the texture addresser)
         const uint32_t query_loc = L.qp + a.seed_size;  // :204
-        const uint8_t* qb = a.query4 + (size_t)(query_loc & 1u) * a.query4_stride + (query_loc >> 1);
+        const uint32_t o = query_loc >> 1, sh = o & 3u;  // first byte of the right window in copy (query_loc & 1, 0)
+        const uint8_t* qb = a.query4 + (size_t)((query_loc & 1u) + 2u * sh) * a.query4_stride + (o - sh);  // dword aligned
         L.qr0 = load16u(qb);
         uint2 t;
         __builtin_memcpy(&t, qb + 16, 8);

@@ -66,7 +66,7 @@ struct CtxRec {               // neighbourhood table WITH target context (probe.
 struct ExtendArgs {
     const uint8_t* ref2;      // packed filter: 2-bit target, phase copy k at ref2 + k*ref2_stride, overlapped-line layout
     size_t ref2_stride;
-    const uint8_t* query4;    // packed filter: 4-bit query of this call's strand, phase copy k at query4 + k*query4_stride
+    const uint8_t* query4;    // filters: 4-bit query of this call's strand, copy (base phase k, byte shift s) at query4 + (k + 2*s)*query4_stride
     size_t query4_stride;
     const uint8_t* ref8;      // ROW-CODED target: byte = code << 3 (points past the front pad)
     const uint8_t* query;     // encoded query, fwd or rc
@@ -137,6 +137,7 @@ void launch_rev_comp_codes(const uint8_t* codes, uint8_t* codes_rc, uint32_t len
 void launch_row_code(const uint8_t* codes, uint8_t* out, uint32_t len, hipStream_t s);
 // phase copies for the packed filter: out + k*copy_stride is copy k (4 copies at 2 bit/base, 2 copies at 4 bit/base)
 constexpr int PACK_PAD = 64;  // pad bytes in front of / behind every 4-bit copy
+constexpr int PACK4_COPIES = 8;  // 4-bit copies: 2 base phases x 4 byte shifts (encode.hip)
 // 2-bit copies use overlapped 128-byte lines (encode.hip): 96 new bytes + the first 32 of the next line; logical byte =
 // PACK2_BIAS + group index, physical byte of logical jj in the line chosen for logical jb = jj + 32 * (jb / 96)
 constexpr int PACK2_PAYLOAD = 96;

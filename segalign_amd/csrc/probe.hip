@@ -119,7 +119,7 @@ void launch_nbr_fill(const uint32_t* bucket_start, const uint32_t* pos_table, ui
 // probe: positions -> runs
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int PR_THREADS = 256;
-constexpr int PR_ITEMS = 1;                       // positions per thread (one 16-byte gather each: parallelism hides its latency)
+constexpr int PR_ITEMS = 4;                       // positions per thread: one ALIGNED group of four (kmer4_at)
 constexpr int PR_TILE = PR_THREADS * PR_ITEMS;    // positions per workgroup
 
 struct Tri { uint64_t hits; uint32_t ne, valid; };  // (hits, non-empty positions, valid positions)
@@ -157,29 +157,36 @@ __device__ __forceinline__ Tri block_excl_scan(Tri v, Tri& total) {
 
 constexpr uint64_t PR_VALID = 1ull << 63;  // flag inside t_off: the window at this position is a valid k-mer
 
+// The position grid of probe_kernel / probe_compact_kernel is aligned to multiples of four: element e of the grid is query
+// position (start & ~3) + e, i.e. index i = e - (start & 3) of the call (elements outside [0, n) are skipped).
 __global__ __launch_bounds__(PR_THREADS) void probe_kernel(const uint8_t* __restrict__ query, uint32_t start, uint32_t n, SeedShape sh,
                                                            const uint64_t* __restrict__ nbr_start, uint32_t nkeys,
                                                            uint64_t* __restrict__ t_off, uint32_t* __restrict__ t_cnt,
                                                            Tri* __restrict__ partial) {
-    const uint32_t i0 = blockIdx.x * PR_TILE + threadIdx.x * PR_ITEMS;
+    const uint32_t skew = start & 3u;
+    const uint32_t e0 = blockIdx.x * PR_TILE + threadIdx.x * PR_ITEMS;  // first grid element of the thread (multiple of 4)
     Tri mine = {0, 0, 0};
+    if (e0 < n + skew) {
+        uint32_t key[4];
+        const uint32_t valid = kmer4_at(query, (start - skew) + e0, sh, key);
 #pragma unroll
-    for (int j = 0; j < PR_ITEMS; j++) {
-        const uint32_t i = i0 + j;
-        if (i >= n) break;
-        uint32_t key;
-        uint64_t off = 0;
-        uint32_t cnt = 0;
-        if (kmer_at(query, start + i, sh, key) && key < nkeys) {
-            const uint64_t b = nbr_start[key], e = nbr_start[key + 1];  // adjacent: one 16-byte extent per POSITION
-            off = b | PR_VALID;
-            cnt = (uint32_t)(e - b);
-            mine.valid++;
-            mine.ne += cnt ? 1u : 0u;
-            mine.hits += cnt;
+        for (int j = 0; j < PR_ITEMS; j++) {
+            const uint32_t e = e0 + j;
+            if (e < skew || e - skew >= n) continue;
+            const uint32_t i = e - skew;
+            uint64_t off = 0;
+            uint32_t cnt = 0;
+            if (((valid >> j) & 1u) && key[j] < nkeys) {
+                const uint64_t b = nbr_start[key[j]], en = nbr_start[key[j] + 1];  // adjacent: one 16-byte extent per POSITION
+                off = b | PR_VALID;
+                cnt = (uint32_t)(en - b);
+                mine.valid++;
+                mine.ne += cnt ? 1u : 0u;
+                mine.hits += cnt;
+            }
+            t_off[i] = off;
+            t_cnt[i] = cnt;
         }
-        t_off[i] = off;
-        t_cnt[i] = cnt;
     }
     Tri total;
     block_excl_scan(mine, total);
@@ -208,7 +215,8 @@ __global__ __launch_bounds__(PR_THREADS) void probe_compact_kernel(uint32_t star
                                                                    const Tri* __restrict__ total, TdRec* __restrict__ c_rec,
                                                                    uint32_t* __restrict__ chunk_rec, uint32_t chunk_cap,
                                                                    TdBounds bpos, Tri* __restrict__ bounds) {
-    const uint32_t i0 = blockIdx.x * PR_TILE + threadIdx.x * PR_ITEMS;
+    const uint32_t skew = start & 3u;
+    const uint32_t i0 = blockIdx.x * PR_TILE + threadIdx.x * PR_ITEMS - skew;  // (wraps below 0 for the first elements: i >= n then)
     uint64_t off[PR_ITEMS];
     uint32_t cnt[PR_ITEMS];
     Tri mine = {0, 0, 0};
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(PR_THREADS) void probe_compact_kernel(uint32_t star
 #pragma unroll
     for (int j = 0; j < PR_ITEMS; j++) {
         const uint32_t i = i0 + j;
-        if (i >= n) break;
+        if (i >= n) continue;
 #pragma unroll
         for (int c = 0; c < TD_MAX_BOUNDS; c++)
             if (c < bpos.nb && bpos.pos[c] - start == i) bounds[c] = run;
@@ -294,20 +302,20 @@ __global__ void probe_plan_kernel(const uint8_t* __restrict__ query, SeedShape s
     plan[c] = p;
 }
 
-size_t probe_partial_bytes(uint32_t n) { return ((size_t)(n + PR_TILE - 1) / PR_TILE + 2) * sizeof(Tri); }
+size_t probe_partial_bytes(uint32_t n) { return ((size_t)(n + 3 + PR_TILE - 1) / PR_TILE + 2) * sizeof(Tri); }
 size_t probe_bounds_bytes() { return (size_t)TD_MAX_BOUNDS * sizeof(Tri); }
 
-static inline uint32_t probe_blocks(uint32_t n) { return (n + PR_TILE - 1) / PR_TILE; }
+static inline uint32_t probe_blocks(uint32_t start, uint32_t n) { return (n + (start & 3u) + PR_TILE - 1) / PR_TILE; }
 
 void launch_probe_lookup(const uint8_t* query, uint32_t start, uint32_t n, SeedShape sh, const uint64_t* nbr_start, uint32_t nkeys,
                          uint64_t* t_off, uint32_t* t_cnt, void* partial_buf, hipStream_t s) {
-    hipLaunchKernelGGL(probe_kernel, dim3(probe_blocks(n)), dim3(PR_THREADS), 0, s, query, start, n, sh, nbr_start, nkeys, t_off, t_cnt,
+    hipLaunchKernelGGL(probe_kernel, dim3(probe_blocks(start, n)), dim3(PR_THREADS), 0, s, query, start, n, sh, nbr_start, nkeys, t_off, t_cnt,
                        reinterpret_cast<Tri*>(partial_buf));
 }
 void launch_probe_compact(uint32_t start, uint32_t n, const uint64_t* t_off, const uint32_t* t_cnt, void* partial_buf, void* bounds_buf,
                           TdRec* c_rec, uint32_t* chunk_rec, uint32_t chunk_cap, const TdBounds& bpos, hipStream_t s) {
     Tri* partial = reinterpret_cast<Tri*>(partial_buf);
-    const uint32_t nblocks = probe_blocks(n);
+    const uint32_t nblocks = probe_blocks(start, n);
     Tri* total = partial + nblocks;
     hipLaunchKernelGGL(probe_partials_kernel, dim3(1), dim3(PR_THREADS), 0, s, partial, nblocks, total);
     hipLaunchKernelGGL(probe_compact_kernel, dim3(nblocks), dim3(PR_THREADS), 0, s, start, n, t_off, t_cnt, partial, total, c_rec, chunk_rec,

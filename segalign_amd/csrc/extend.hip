@@ -833,15 +833,18 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_ctx_kernel(ExtendArg
     const int xdrop = a.xdrop;
     const uint4* __restrict__ ctx = reinterpret_cast<const uint4*>(a.td_ctx);
 
-    // one chunk of TD_CHUNK_HITS hits (64 buffers) per wave: short-lived workgroups, so that the small kernels of the call
-    // running on the other slot find free CUs while this one streams; the chunk's first record was noted by the probe
+    // a wave takes a contiguous range of TD_CHUNK_HITS-hit chunks (64 buffers each); the record that holds a chunk's first hit
+    // was noted by the probe (td_chunk), so no wave has to search for its starting point
     const uint64_t num_buf = (a.num_hits + 63) >> 6;
+    const uint64_t n_chunks = (a.num_hits + TD_CHUNK_HITS - 1) / TD_CHUNK_HITS;
+    const uint64_t W = (uint64_t)gridDim.x * (PK_THREADS / 64);
     const uint64_t wid = (uint64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (PK_THREADS / 64) + (threadIdx.x >> 6)));
-    const uint64_t b_lo = wid * (TD_CHUNK_HITS / 64);
-    const uint64_t b_hi = min(b_lo + TD_CHUNK_HITS / 64, num_buf);
+    const uint64_t c_lo = (wid * n_chunks) / W, c_hi = ((wid + 1) * n_chunks) / W;
+    const uint64_t b_lo = c_lo * (TD_CHUNK_HITS / 64);
+    const uint64_t b_hi = min(c_hi * (TD_CHUNK_HITS / 64), num_buf);
     if (b_lo >= b_hi) return;
     TdCursor cursor = {0u, {0u, 0u, 0ull}, 0u};
-    cursor.m0 = a.td_chunk[wid];
+    cursor.m0 = a.td_chunk[c_lo];
     cursor.load_window(a, lane);
 
     // software pipeline: the records and query windows of buffer b + 1 are requested before buffer b is scored, so the HBM
@@ -1358,7 +1361,8 @@ void launch_extend_filter(const ExtendArgs& a, hipStream_t s) {
 // context filter (1c): table-direct calls whose neighbourhood table carries the target context; fills a.l2_list
 void launch_extend_filter_ctx(const ExtendArgs& a, hipStream_t s) {
     if (a.num_hits == 0) return;
-    const uint64_t waves = (a.num_hits + TD_CHUNK_HITS - 1) / TD_CHUNK_HITS;  // one chunk per wave
+    uint64_t waves = (a.num_hits + TD_CHUNK_HITS - 1) / TD_CHUNK_HITS;  // at most one wave per chunk
+    if (a.ctx_waves && waves > a.ctx_waves) waves = a.ctx_waves;         // resident waves each walk a contiguous range of chunks
     const uint32_t blocks = (uint32_t)((waves + PK_THREADS / 64 - 1) / (PK_THREADS / 64));
     hipLaunchKernelGGL(extend_filter_ctx_kernel, dim3(blocks), dim3(PK_THREADS), 0, s, a);
 }

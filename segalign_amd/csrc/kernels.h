@@ -112,6 +112,7 @@ struct ExtendArgs {
     uint32_t* l2_count;
     uint32_t l2_cap;
     int src_cand;               // packed filter reads its anchors from l2_list / *l2_count instead of `hits`
+    uint32_t ctx_waves;         // wave budget of the context filter (0: one chunk of TD_CHUNK_HITS hits per wave)
     uint32_t l2_blocks;         // grid of the second level (its hit count is known on the device only)
     uint32_t seed_size;
     uint64_t num_hits;

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -287,6 +288,8 @@ struct DevCtx {
     uint64_t* nbr_start = nullptr;       // nkeys + 1
     uint32_t* nbr_pos = nullptr;         // == pos_table when no transition word exists (nbr_alias); null when nbr_ctx is built
     CtxRec* nbr_ctx = nullptr;           // the runs WITH their target context (32 B per entry): context filter, extend.hip 1c
+    CtxRec* nbr_ctx_alloc = nullptr;     // its allocation outlives a target block (hipMalloc of 150 GB takes ~4 s): grow-only
+    size_t nbr_ctx_cap = 0;              // bytes
     bool nbr_alias = false;
     uint64_t nbr_total = 0;
     uint32_t nbr_tmask = 0;
@@ -982,10 +985,9 @@ __global__ void widen_u32_kernel(const uint32_t* __restrict__ in, uint64_t* __re
 static void nbr_release(DevCtx* dc) {
     dev_free(dc->nbr_start, "nbr_start");
     if (!dc->nbr_alias) dev_free(dc->nbr_pos, "nbr_pos");
-    dev_free(dc->nbr_ctx, "nbr_ctx");
     dc->nbr_start = nullptr;
     dc->nbr_pos = nullptr;
-    dc->nbr_ctx = nullptr;
+    dc->nbr_ctx = nullptr;  // (the allocation stays: nbr_ctx_alloc)
     dc->nbr_alias = false;
     dc->nbr_total = 0;
     dc->nbr_state = 0;
@@ -1029,22 +1031,43 @@ static bool ensure_nbr(DevCtx* dc) {
             return false;
         }
     }
+    const bool dbg = getenv("SEGALIGN_AMD_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_a = now();
     size_t free_b = 0, total_b = 0;
     hipMemGetInfo(&free_b, &total_b);
     const size_t reserve = (size_t)8 << 30;  // keep 8 GiB for the slots' work buffers
     const size_t need_ctx = (size_t)std::max<uint64_t>(total, 1) * sizeof(CtxRec);
     const size_t need_pos = (size_t)std::max<uint64_t>(total, 1) * sizeof(uint32_t);
-    if (g_ctx && dc->ref2.base && need_ctx + reserve <= free_b) {
+    if (g_ctx && dc->ref2.base && need_ctx + reserve <= free_b + dc->nbr_ctx_cap) {
         // runs with their target context: 32 bytes per entry (33 GB for a 100 Mbp block with transitions)
-        dc->nbr_ctx = (CtxRec*)dev_malloc(need_ctx, "nbr_ctx");
+        if (dc->nbr_ctx_cap < need_ctx) {
+            dev_free(dc->nbr_ctx_alloc, "nbr_ctx");
+            dc->nbr_ctx_alloc = nullptr;
+            dc->nbr_ctx_cap = 0;
+            dc->nbr_ctx_alloc = (CtxRec*)dev_malloc(need_ctx, "nbr_ctx");
+            dc->nbr_ctx_cap = need_ctx;
+        }
+        dc->nbr_ctx = dc->nbr_ctx_alloc;
+        if (dbg) fprintf(stderr, "neighbourhood table: %.1f M entries, hipMalloc of %.1f GB took %.1f ms\n", total / 1e6, need_ctx / 1e9, now() - t_a);
+        const double t_b = now();
         launch_nbr_fill_ctx(dc->bucket_start, dc->pos_table, nkeys, tmask, g_shape.weight, dc->nbr_start, dc->ref2.base, dc->ref2.stride,
                             g_seed_size, dc->nbr_ctx, st);
         check_launch("nbr fill ctx");
         check_sync(st, "nbr fill ctx");
+        if (dbg) fprintf(stderr, "neighbourhood table: context fill took %.1f ms\n", now() - t_b);
     } else if (tmask == 0) {
         dc->nbr_pos = dc->pos_table;
         dc->nbr_alias = true;
-    } else if (need_pos + reserve <= free_b) {
+    } else if ([&] {  // positions only: a context allocation kept from an earlier (smaller) block gives its memory back first
+                   if (dc->nbr_ctx_alloc) {
+                       dev_free(dc->nbr_ctx_alloc, "nbr_ctx");
+                       dc->nbr_ctx_alloc = nullptr;
+                       dc->nbr_ctx_cap = 0;
+                       hipMemGetInfo(&free_b, &total_b);
+                   }
+                   return need_pos + reserve <= free_b;
+               }()) {
         dc->nbr_pos = (uint32_t*)dev_malloc(need_pos, "nbr_pos");
         launch_nbr_fill(dc->bucket_start, dc->pos_table, nkeys, tmask, g_shape.weight, dc->nbr_start, dc->nbr_pos, st);
         check_launch("nbr fill");
@@ -1292,6 +1315,9 @@ static void release_device_state(DevCtx* dc) {
     dc->ref4_rc.release("d_seq_rc 4-bit");
     dc->ref_host_ptr = nullptr;
     nbr_release(dc);
+    dev_free(dc->nbr_ctx_alloc, "nbr_ctx");
+    dc->nbr_ctx_alloc = nullptr;
+    dc->nbr_ctx_cap = 0;
     dev_free(dc->bucket_start, "d_index_table");
     dev_free(dc->pos_table, "d_pos_table");
     dc->bucket_start = dc->pos_table = nullptr;

@@ -662,9 +662,11 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                 ea.max_waves = (uint32_t)(ea.fast_filter == 3 ? g_packed_waves : g_max_waves);
                 ea.ent_blocks = 64;
                 sl->cand_list.ensure((size_t)std::max<uint64_t>(1u << 16, bh / 16), "candidate list");
-                // chain shortcut: valid for the plain X-drop recurrence (xdrop >= 0), not for the repeat masker's window
-                // skip, needs the 29-bit position field of its sort key, and is off while E is being counted
-                const bool chain = g_chain && !ca.rm && g_xdrop >= 0 && ca.query_len < (1u << 29) && !g_count_examined;
+                // chain shortcut: valid for the plain X-drop recurrence (xdrop >= 0), needs the 29-bit position field of its
+                // sort key, and is off while E is being counted.  The repeat masker takes it too: its window only decides WHICH
+                // hits are extended (all candidates lie inside it), and its chain starts with an exact-duplicate unique
+                // (rm :819-823), so the duplicates the shortcut never produces would be removed there anyway
+                const bool chain = g_chain && g_xdrop >= 0 && ca.query_len < (1u << 29) && !g_count_examined;
                 ea.chain_cap = chain ? CHAIN_CAP : 0u;
                 ea.chain_sort_threads = (uint32_t)g_chain_sort_threads;
                 if (chain) {

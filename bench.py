@@ -217,8 +217,17 @@ def main():
         return it[1] - it[0], int(fw.size + rc.size)
 
     def run_step(k, collect=None, threads=None):
+        todo = my_intervals(items, rank, k)
+        nt = max(1, threads or args.host_threads)
+        if wl["rm"] and nt > 1:
+            # sa_rm_mask_interval walks the chunks of ONE interval on one engine slot; intervals are independent
+            # (repeat_masker_src/main.cpp hands them to parallel seeder bodies): keep `nt` of them in flight
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(nt) as pool:
+                res = list(pool.map(lambda it: run_item(it, collect, threads), todo))
+            return sum(r[0] for r in res), sum(r[1] for r in res)
         b = h = 0
-        for it in my_intervals(items, rank, k):
+        for it in todo:
             bb, hh = run_item(it, collect, threads)
             b += bb
             h += hh

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(DEDUP_SEG_THREADS) void dedup_seg_kernel(const HspR
         if (lane == 0) s_wave[wave] = (uint32_t)__popcll(mask);
         __syncthreads();
         uint32_t pre = 0, tot = 0;
-        for (int w = 0; w < DEDUP_SEG_THREADS / 64; w++) {
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) {
             const uint32_t c = s_wave[w];
             if (w < wave) pre += c;
             tot += c;
@@ -257,8 +257,10 @@ uint32_t dedup_seg_max_total() { return DEDUP_SEG_TOTAL; }
 uint32_t dedup_seg_info_words() { return 2 * DEDUP_SMALL_SEGS + 1; }
 // seg_info[g] = records of segment g after the chain, seg_info[SEGS + g] = their first slot in out; seg_info[2 * SEGS] != 0:
 // a segment held more than DEDUP_SEG_MAX records (nothing usable was written); must be zero on entry
-void launch_dedup_seg(const HspRec* in, uint32_t n, uint32_t nsegs, void* out_segment_pairs, uint32_t* seg_info, hipStream_t s) {
-    hipLaunchKernelGGL(dedup_seg_kernel, dim3(nsegs), dim3(DEDUP_SEG_THREADS), 0, s, in, n, reinterpret_cast<uint4*>(out_segment_pairs), seg_info);
+// threads: workgroup size (0 = DEDUP_SEG_THREADS)
+void launch_dedup_seg(const HspRec* in, uint32_t n, uint32_t nsegs, void* out_segment_pairs, uint32_t* seg_info, uint32_t threads, hipStream_t s) {
+    threads = threads ? std::min<uint32_t>(DEDUP_SEG_THREADS, std::max<uint32_t>(64, threads & ~63u)) : (uint32_t)DEDUP_SEG_THREADS;
+    hipLaunchKernelGGL(dedup_seg_kernel, dim3(nsegs), dim3(threads), 0, s, in, n, reinterpret_cast<uint4*>(out_segment_pairs), seg_info);
 }
 
 uint32_t dedup_small_max_segs() { return DEDUP_SMALL_SEGS; }

@@ -321,6 +321,8 @@ static int g_long_cap = 128;      // SEGALIGN_AMD_LONG_CAP: bases per side befor
 static int g_long_blocks = 1792;  // SEGALIGN_AMD_LONG_BLOCKS: grid of the long kernel (4 waves per block)
 static int g_packed_waves = 4096; // SEGALIGN_AMD_PACKED_WAVES: waves of the packed filter (2 workgroups of 8 waves per CU measured best: 3072 +16 %, 6144 +20 %, 8192 +14 %)
 static int g_ctx_waves = 0;       // SEGALIGN_AMD_CTX_WAVES: wave budget of the context filter; 0 = one 4096-hit chunk per wave (measured best)
+static int g_ctx_threads = 0;     // SEGALIGN_AMD_CTX_THREADS: workgroup size of the context filter (0 = kernel default)
+static int g_dedup_threads = 0;   // SEGALIGN_AMD_DEDUP_THREADS: workgroup size of the per-segment LDS chain (0 = 1024)
 static int g_l2_blocks = 256;     // SEGALIGN_AMD_L2_BLOCKS: workgroups of the second-level packed filter
 static int g_max_waves = 4096;    // SEGALIGN_AMD_MAX_WAVES: waves of the filter kernel (4 per SIMD saturate instruction issue)
 static int g_fast_filter = 0;     // derived in InitializeProcessor: xdrop >= 0 && 7*max(M) <= xdrop
@@ -620,6 +622,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     ea.l2_count = &sl->d_cnt->n_l2;
                     ea.l2_blocks = (uint32_t)g_l2_blocks;
                     ea.ctx_waves = (uint32_t)g_ctx_waves;
+                    ea.ctx_threads = (uint32_t)g_ctx_threads;
                 } else if (!ca.raw_hits) {
                     sl->hits.ensure((size_t)bh, "hits");
                     ProfScope p(sl, "expand_hits");
@@ -796,7 +799,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     ensure_host_out(survivors);
                     ensure_host_seg(std::max<size_t>(survivors, words));
                     check_memcpy(hipMemsetAsync(sl->d_seg_info, 0, words * sizeof(uint32_t), st), "segment info");
-                    { ProfScope p(sl, "dedup_seg"); launch_dedup_seg(sl->recA.p, survivors, (uint32_t)segs.size(), sl->out16.p, sl->d_seg_info, st); }
+                    { ProfScope p(sl, "dedup_seg"); launch_dedup_seg(sl->recA.p, survivors, (uint32_t)segs.size(), sl->out16.p, sl->d_seg_info, (uint32_t)g_dedup_threads, st); }
                     check_launch("dedup seg");
                     check_memcpy(hipMemcpyAsync(sl->h_seg_info, sl->d_seg_info, words * sizeof(uint32_t), hipMemcpyDeviceToHost, st), "segment info");
                     check_memcpy(hipMemcpyAsync(sl->h_out, sl->out16.p, (size_t)survivors * sizeof(sa_segment_pair),
@@ -1251,6 +1254,8 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
     if (const char* e = getenv("SEGALIGN_AMD_PACKED_WAVES")) g_packed_waves = std::max(8, atoi(e));
     if (const char* e = getenv("SEGALIGN_AMD_L2_BLOCKS")) g_l2_blocks = std::max(1, atoi(e));
     if (const char* e = getenv("SEGALIGN_AMD_CTX_WAVES")) g_ctx_waves = std::max(0, atoi(e));
+    if (const char* e = getenv("SEGALIGN_AMD_CTX_THREADS")) g_ctx_threads = std::max(0, atoi(e));
+    if (const char* e = getenv("SEGALIGN_AMD_DEDUP_THREADS")) g_dedup_threads = std::max(0, atoi(e));
     if (xdrop >= (1 << 25) || xdrop <= -(1 << 25)) {
         fprintf(stderr, "Error: |xdrop| must be below 2^25\n");
         exit(1);

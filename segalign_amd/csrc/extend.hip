@@ -821,12 +821,17 @@ __device__ __forceinline__ void ctx_step16(const uint32_t* __restrict__ s_tab, u
     }
 }
 
-__global__ __launch_bounds__(PK_THREADS) void extend_filter_ctx_kernel(ExtendArgs a) {
+// Workgroup size: 512 threads (three workgroups per CU = the 6 waves per SIMD the 77 VGPRs allow).  384 / 640 / 768 / 1024
+// threads -- which leave more LDS and wave slots to the tail kernels of the other streams -- measured 2-3 % slower on the
+// whole bench (tools/sweep_threads.sh)
+constexpr int CTX_THREADS = 512;      // default; ExtendArgs::ctx_threads (SEGALIGN_AMD_CTX_THREADS) overrides it per launch
+constexpr int CTX_THREADS_MAX = 1024;
+__global__ __launch_bounds__(CTX_THREADS_MAX) void extend_filter_ctx_kernel(ExtendArgs a) {
     __shared__ uint32_t s_pk[2 * PK_TAB];  // 8-byte entries {sum, max prefix} (32 KB)
-    __shared__ CandRec s_cand[PK_THREADS / 64][STAGE_CAP];
-    pk_table_init<true>(s_pk, a.sub_mat, PK_THREADS);
+    extern __shared__ CandRec s_cand_dyn[];  // [waves of the workgroup][STAGE_CAP]
+    pk_table_init<true>(s_pk, a.sub_mat, (int)blockDim.x);
     __syncthreads();
-    CandRec* stage = s_cand[threadIdx.x >> 6];
+    CandRec* stage = s_cand_dyn + (threadIdx.x >> 6) * STAGE_CAP;
     int n_stage = 0;
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
@@ -837,8 +842,8 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_ctx_kernel(ExtendArg
     // was noted by the probe (td_chunk), so no wave has to search for its starting point
     const uint64_t num_buf = (a.num_hits + 63) >> 6;
     const uint64_t n_chunks = (a.num_hits + TD_CHUNK_HITS - 1) / TD_CHUNK_HITS;
-    const uint64_t W = (uint64_t)gridDim.x * (PK_THREADS / 64);
-    const uint64_t wid = (uint64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (PK_THREADS / 64) + (threadIdx.x >> 6)));
+    const uint64_t W = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint64_t wid = (uint64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     const uint64_t c_lo = (wid * n_chunks) / W, c_hi = ((wid + 1) * n_chunks) / W;
     const uint64_t b_lo = c_lo * (TD_CHUNK_HITS / 64);
     const uint64_t b_hi = min(c_hi * (TD_CHUNK_HITS / 64), num_buf);
@@ -1363,8 +1368,11 @@ void launch_extend_filter_ctx(const ExtendArgs& a, hipStream_t s) {
     if (a.num_hits == 0) return;
     uint64_t waves = (a.num_hits + TD_CHUNK_HITS - 1) / TD_CHUNK_HITS;  // at most one wave per chunk
     if (a.ctx_waves && waves > a.ctx_waves) waves = a.ctx_waves;         // resident waves each walk a contiguous range of chunks
-    const uint32_t blocks = (uint32_t)((waves + PK_THREADS / 64 - 1) / (PK_THREADS / 64));
-    hipLaunchKernelGGL(extend_filter_ctx_kernel, dim3(blocks), dim3(PK_THREADS), 0, s, a);
+    uint32_t threads = a.ctx_threads ? a.ctx_threads : (uint32_t)CTX_THREADS;
+    threads = std::min<uint32_t>(CTX_THREADS_MAX, std::max<uint32_t>(64, threads & ~63u));
+    const uint32_t wpb = threads / 64;
+    const uint32_t blocks = (uint32_t)((waves + wpb - 1) / wpb);
+    hipLaunchKernelGGL(extend_filter_ctx_kernel, dim3(blocks), dim3(threads), wpb * STAGE_CAP * sizeof(CandRec), s, a);
 }
 
 void launch_chain_group(const ExtendArgs& a, hipStream_t s) {  // chain_bucket_cnt must be zero on entry

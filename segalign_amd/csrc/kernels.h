@@ -113,6 +113,7 @@ struct ExtendArgs {
     uint32_t l2_cap;
     int src_cand;               // packed filter reads its anchors from l2_list / *l2_count instead of `hits`
     uint32_t ctx_waves;         // wave budget of the context filter (0: one chunk of TD_CHUNK_HITS hits per wave)
+    uint32_t ctx_threads;       // workgroup size of the context filter (0: its default)
     uint32_t l2_blocks;         // grid of the second level (its hit count is known on the device only)
     uint32_t seed_size;
     uint64_t num_hits;
@@ -204,7 +205,7 @@ uint32_t dedup_small_max_segs();
 // the results land at the segments' input offsets
 uint32_t dedup_seg_max_total();
 uint32_t dedup_seg_info_words();
-void launch_dedup_seg(const HspRec* in, uint32_t n, uint32_t nsegs, void* out_segment_pairs, uint32_t* seg_info, hipStream_t s);
+void launch_dedup_seg(const HspRec* in, uint32_t n, uint32_t nsegs, void* out_segment_pairs, uint32_t* seg_info, uint32_t threads, hipStream_t s);
 
 // ---- coverage.hip (repeat-masker post-processing, repeat_masker_src/seeder.cpp:153-188) ------------------------
 struct SegPair16 { uint32_t ref_start, query_start, len; int32_t score; };  // layout of sa_segment_pair / segmentPair

@@ -51,9 +51,12 @@ SCOPE_KERNELS = {
     "expand_hits": ["expand_hits_kernel"], "extend_filter": ["extend_filter_packed_kernel"],  # (the default, packed filter)
     "chain_group": ["chain_count_kernel", "chain_scan_kernel", "chain_scatter_kernel", "chain_bucket_sort_kernel"],
     "chain_link": ["chain_link_kernel"], "extend_exact_chain": ["extend_exact_chain_kernel"],
-    "extend_exact": ["extend_exact_kernel"], "extend_entropy": ["extend_entropy_kernel"], "dedup_small": ["dedup_small_kernel"],
+    "extend_exact": ["extend_exact_kernel"], "extend_entropy": ["extend_entropy_kernel"], "dedup_seg": ["dedup_seg_kernel"],
 }
-EXTENSION_SCOPES = ["extend_filter", "chain_group", "chain_link", "extend_exact_chain", "extend_exact", "extend_entropy"]
+# context-table calls (lookup mode 2): the filter is two kernels -- level 1 on the context records, level 2 (the packed kernel)
+# on the few hits level 1 could not decide
+CTX_SCOPE_KERNELS = {"extend_filter": ["extend_filter_ctx_kernel"], "extend_filter2": ["extend_filter_packed_kernel"]}
+EXTENSION_SCOPES = ["extend_filter", "extend_filter2", "chain_group", "chain_link", "extend_exact_chain", "extend_exact", "extend_entropy"]
 
 
 def parse():
@@ -337,6 +340,9 @@ def roofline(args, E, wl, prof, call_stats, run_step, run_item, items):
     H, A, S, Cn = totals(call_stats)
     sH, sA, sS, sC = totals(solo_stats)
     table_direct = "seed_probe" in prof
+    ctx_filter = "extend_filter2" in prof   # context-table calls: filter = level 1 (context records) + level 2 (packed kernel)
+    scope_kernels = dict(SCOPE_KERNELS, **(CTX_SCOPE_KERNELS if ctx_filter else {}))
+    filter_scopes = ["extend_filter", "extend_filter2"] if ctx_filter else ["extend_filter"]
     # algorithmic bytes (restated per kernel in DESIGN.md 4):
     #   seed lookup                      : 16*S            (8 B seed word + 8 B bucket extent per seed word)
     #   lookup + expansion               : 16*S + 12*H     (hit list materialised)   /  16*S + 4*H  (fused into extension)
@@ -368,13 +374,20 @@ def roofline(args, E, wl, prof, call_stats, run_step, run_item, items):
                for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
     gpu_ms = sum(v[0] for v in prof.values())
     name, (ms, launches) = max(prof.items(), key=lambda kv: kv[1][0])
+    if name == "extend_filter" and ctx_filter:
+        # 4*H + 2*E_filter + 12*C is the work of the WHOLE filter stage (every hit scored until it drops), so it is divided by
+        # the time of both levels: level 1 alone only looks at the 48 + 64 context bases of a hit
+        ms = ms_of(prof, filter_scopes)
     per_scope_bytes = {"extend_filter": ("extend_filter", "%g*H + 2*E_filter + 12*C" % hin), lookup_scope: ("seed_lookup", "16*S"),
                        "expand_hits": ("expand_hits", "12*H")}
     key, formula = per_scope_bytes.get(name, (None, None))
     achieved = rate(alg_t[key], ms) if key else None
     traffic_db, traffic_src, kstats = committed_profile(args, E)
-    check = profile_check(prof, solo, kstats, args)
-    symbol = FILTER_KERNELS.get(E.filter_mode()) if name == "extend_filter" else (SCOPE_KERNELS.get(name) or [None])[0]
+    check = profile_check(prof, solo, kstats, args, scope_kernels)
+    if name == "extend_filter":
+        symbol = "extend_filter_ctx_kernel" if ctx_filter else FILTER_KERNELS.get(E.filter_mode())
+    else:
+        symbol = (scope_kernels.get(name) or [None])[0]
 
     def traffic_of(sym, launches_in_scope=1):
         if not traffic_db or not sym or sym not in traffic_db or not check["ok"]:
@@ -385,7 +398,7 @@ def roofline(args, E, wl, prof, call_stats, run_step, run_item, items):
         """a kernel of its own standing: algorithmic fraction (timed region + single stream) and measured-traffic ratio"""
         if scope not in prof or not prof[scope][1]:
             return None
-        sym = SCOPE_KERNELS[scope][0]
+        sym = scope_kernels[scope][0]
         n_t, n_s = prof[scope][1], max(solo.get(scope, (0, 0))[1], 1)
         a_t = rate(alg_t[alg_key], prof[scope][0])
         a_s = rate(alg_s[alg_key], solo[scope][0]) if scope in solo else None
@@ -398,14 +411,20 @@ def roofline(args, E, wl, prof, call_stats, run_step, run_item, items):
                 "traffic": tr, "traffic_ratio": round(tr / abl, 3) if (tr and abl) else None}
 
     traffic = traffic_of(symbol)
-    s_avg_us = 1e3 * solo[name][0] / max(solo[name][1], 1) if name in solo else None
+    solo_ms = (ms_of(solo, filter_scopes) if (name == "extend_filter" and ctx_filter) else solo[name][0]) if name in solo else None
+    s_avg_us = 1e3 * solo_ms / max(solo[name][1], 1) if name in solo else None
     single = None
     if key and name in solo and solo[name][1]:
-        sg = rate(alg_s[key], solo[name][0])
+        sg = rate(alg_s[key], solo_ms)
         single = {"avg_launch_us": round(s_avg_us, 2), "achieved": round(sg, 1), "frac": round(sg / HBM_PEAK_GBS, 4),
                   "note": "same kernel, one call in flight (no overlap with a second stream); untimed extra pass"}
     return {
         "bound": "hbm", "kernel": name, "kernel_symbol": symbol, "bytes": formula,
+        "kernel_scopes": filter_scopes if name == "extend_filter" else [name],
+        "note": ("context-table filter: the bytes are the algorithmic figure of the whole filter stage (1 byte per examined base and "
+                 "sequence), the duration is level 1 + level 2; the kernel itself streams 32-byte context records + 4-bit query "
+                 "windows (measured traffic below the algorithmic bytes) and is bound by VALU / LDS / address path, not HBM -- DESIGN.md 4"
+                 ) if (name == "extend_filter" and ctx_filter) else None,
         "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
         "traffic": traffic, "traffic_source": traffic_src, "profile_check": check,
@@ -460,7 +479,7 @@ def committed_profile(args, E):
     return None, None, None
 
 
-def profile_check(prof, solo, kstats, args):
+def profile_check(prof, solo, kstats, args, scope_kernels=SCOPE_KERNELS):
     """Does the committed rocprofv3 collection describe the kernels of THIS run?  Per scope, the committed
     --kernel-trace --stats average (sum over the scope's kernels) is compared with the average this run's own HIP events
     predict for the same command: warmup + timed launches at the timed region's (concurrent) duration and the single-stream
@@ -469,10 +488,10 @@ def profile_check(prof, solo, kstats, args):
     if not kstats:
         return {"ok": False, "reason": "no committed kernel_stats for this workload"}
     out, ok = {}, True
-    for scope in ("extend_filter", "seed_probe", "seed_lookup", "expand_hits"):
+    for scope in ("extend_filter", "extend_filter2", "seed_probe", "seed_lookup", "expand_hits"):
         if scope not in prof or not prof[scope][1]:
             continue
-        committed = sum(kstats[k][1] for k in SCOPE_KERNELS[scope] if k in kstats)
+        committed = sum(kstats[k][1] for k in scope_kernels[scope] if k in kstats)
         scale = (args.steps + args.warmup) / max(args.steps, 1)
         s_ms, s_n = solo.get(scope, (0.0, 0))
         ev = 1e3 * (prof[scope][0] * scale + s_ms) / (prof[scope][1] * scale + s_n)

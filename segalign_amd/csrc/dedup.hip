@@ -191,8 +191,15 @@ __device__ __forceinline__ void rank_sort_lds(const HspRec* __restrict__ src, Hs
     __syncthreads();
 }
 
-__global__ __launch_bounds__(DEDUP_SEG_THREADS) void dedup_seg_kernel(const HspRec* __restrict__ in, uint32_t n, uint4* __restrict__ out,
-                                                                      uint32_t* __restrict__ seg_info /* [2 * SEGS + 1] */) {
+__global__ __launch_bounds__(DEDUP_SEG_THREADS) void dedup_seg_kernel(const HspRec* __restrict__ in, uint32_t n, const uint32_t* __restrict__ n_dev,
+                                                                      uint4* __restrict__ out, uint32_t* __restrict__ seg_info /* [2 * SEGS + 1] */) {
+    if (n_dev) {  // speculative launch: the survivor count is still on the device
+        n = *n_dev;
+        if (n > (uint32_t)DEDUP_SEG_TOTAL) {
+            if (threadIdx.x == 0) seg_info[2 * DEDUP_SMALL_SEGS] = 1u;
+            return;
+        }
+    }
     __shared__ HspRec s_a[DEDUP_SEG_MAX];
     __shared__ HspRec s_b[DEDUP_SEG_MAX];
     __shared__ uint32_t s_cnt[DEDUP_SMALL_SEGS];
@@ -258,9 +265,11 @@ uint32_t dedup_seg_info_words() { return 2 * DEDUP_SMALL_SEGS + 1; }
 // seg_info[g] = records of segment g after the chain, seg_info[SEGS + g] = their first slot in out; seg_info[2 * SEGS] != 0:
 // a segment held more than DEDUP_SEG_MAX records (nothing usable was written); must be zero on entry
 // threads: workgroup size (0 = DEDUP_SEG_THREADS)
-void launch_dedup_seg(const HspRec* in, uint32_t n, uint32_t nsegs, void* out_segment_pairs, uint32_t* seg_info, uint32_t threads, hipStream_t s) {
+// n_dev != nullptr: the number of records is read from the device (n ignored); more than dedup_seg_max_total() sets the flag
+void launch_dedup_seg(const HspRec* in, uint32_t n, const uint32_t* n_dev, uint32_t nsegs, void* out_segment_pairs, uint32_t* seg_info,
+                      uint32_t threads, hipStream_t s) {
     threads = threads ? std::min<uint32_t>(DEDUP_SEG_THREADS, std::max<uint32_t>(64, threads & ~63u)) : (uint32_t)DEDUP_SEG_THREADS;
-    hipLaunchKernelGGL(dedup_seg_kernel, dim3(nsegs), dim3(threads), 0, s, in, n, reinterpret_cast<uint4*>(out_segment_pairs), seg_info);
+    hipLaunchKernelGGL(dedup_seg_kernel, dim3(nsegs), dim3(threads), 0, s, in, n, n_dev, reinterpret_cast<uint4*>(out_segment_pairs), seg_info);
 }
 
 uint32_t dedup_small_max_segs() { return DEDUP_SMALL_SEGS; }

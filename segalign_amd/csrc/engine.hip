@@ -196,6 +196,7 @@ static int prof_id(const char* name) {
 // per-device state
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int MAX_SLOTS_PER_DEVICE = 4;
+constexpr uint32_t SPEC_RECS = 4096;  // records of the speculative output copy (64 KB)
 constexpr int SA_MAX_CHUNKS = 4;  // chunks one multi-chunk call carries: 2 reference iterations each = MAX_SEGS segments (8 chunks measured no faster)
 static int SLOTS_PER_DEVICE = 2;  // calls in flight per device (the reference allows one: token == device); SEGALIGN_AMD_SLOTS
 
@@ -323,6 +324,7 @@ static int g_packed_waves = 4096; // SEGALIGN_AMD_PACKED_WAVES: waves of the pac
 static int g_ctx_waves = 0;       // SEGALIGN_AMD_CTX_WAVES: wave budget of the context filter; 0 = one 4096-hit chunk per wave (measured best)
 static int g_ctx_threads = 0;     // SEGALIGN_AMD_CTX_THREADS: workgroup size of the context filter (0 = kernel default)
 static int g_dedup_threads = 0;   // SEGALIGN_AMD_DEDUP_THREADS: workgroup size of the per-segment LDS chain (0 = 1024)
+static int g_spec_dedup = 1;      // SEGALIGN_AMD_SPEC_DEDUP=0: wait for the survivor count before the LDS chain (one more host sync)
 static int g_l2_blocks = 256;     // SEGALIGN_AMD_L2_BLOCKS: workgroups of the second-level packed filter
 static int g_max_waves = 4096;    // SEGALIGN_AMD_MAX_WAVES: waves of the filter kernel (4 per SIMD saturate instruction issue)
 static int g_fast_filter = 0;     // derived in InitializeProcessor: xdrop >= 0 && 7*max(M) <= xdrop
@@ -584,6 +586,26 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
         }
         }
 
+        auto ensure_host_out = [&](size_t n) {
+            if (sl->h_out_cap >= n) return;
+            if (sl->h_out) hipHostFree(sl->h_out);
+            sl->h_out_cap = std::max<size_t>(n, 1u << 16);
+            if (hipHostMalloc((void**)&sl->h_out, sl->h_out_cap * sizeof(sa_segment_pair)) != hipSuccess) {
+                fprintf(stderr, "Error: hipHostMalloc for hsp_output failed\n");
+                exit(12);
+            }
+        };
+        auto ensure_host_seg = [&](size_t n) {
+            if (sl->h_seg_cap >= n) return;
+            if (sl->h_seg) hipHostFree(sl->h_seg);
+            sl->h_seg_cap = std::max<size_t>(n, 1u << 16);
+            if (hipHostMalloc((void**)&sl->h_seg, sl->h_seg_cap * sizeof(uint32_t)) != hipSuccess) {
+                fprintf(stderr, "Error: hipHostMalloc for the segment ids failed\n");
+                exit(12);
+            }
+        };
+        bool spec_tried = false; // ... was launched (a segment too large for LDS is not worth a second attempt)
+        bool spec_done = false;  // the speculative LDS chain of a single-batch call delivered the final records
         if (num_hits > 0 && !segs.empty()) {
             // ---- batches of consecutive iterations: expand (find_hits) + extend (find_hsps) ----
             const uint64_t HIT_BATCH = 1ull << 27;  // 128 Mi hits (1 GiB of 8-byte hits) per batch unless one iteration is larger
@@ -722,9 +744,29 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     else              { ProfScope p(sl, "extend_exact");       launch_extend_exact(ea, st); }
                     { ProfScope p(sl, "extend_entropy"); launch_extend_entropy(ea, st); }
                     check_launch("expand/extend");
+                    // A call that is ONE batch (every table-direct call) does not wait for the survivor count: the per-segment LDS
+                    // chain (:776-782) is launched on the device-side count and its first SPEC_RECS records travel with the
+                    // counters -- one host sync for extension + chain + output instead of two
+                    const bool spec = ca.td && !ca.rm && !ca.raw_hits && it0 == 0 && it == segs.size() &&
+                                      segs.size() <= dedup_small_max_segs() && !g_no_small_dedup && g_spec_dedup;
+                    const uint32_t seg_words = dedup_seg_info_words();
+                    if (spec) {
+                        spec_tried = true;
+                        sl->out16.ensure(dedup_seg_max_total(), "out16");
+                        ensure_host_out(dedup_seg_max_total());
+                        ensure_host_seg(std::max<size_t>(dedup_seg_max_total(), seg_words));
+                        check_memcpy(hipMemsetAsync(sl->d_seg_info, 0, seg_words * sizeof(uint32_t), st), "segment info");
+                        { ProfScope p(sl, "dedup_seg"); launch_dedup_seg(ea.out, 0, &sl->d_cnt->survivors, (uint32_t)segs.size(), sl->out16.p, sl->d_seg_info, (uint32_t)g_dedup_threads, st); }
+                        check_launch("dedup seg");
+                        check_memcpy(hipMemcpyAsync(sl->h_seg_info, sl->d_seg_info, seg_words * sizeof(uint32_t), hipMemcpyDeviceToHost, st), "segment info");
+                        check_memcpy(hipMemcpyAsync(sl->h_out, sl->out16.p, (size_t)SPEC_RECS * sizeof(sa_segment_pair), hipMemcpyDeviceToHost, st),
+                                     "hsp_output");  // :788
+                    }
                     check_memcpy(hipMemcpyAsync(sl->h_cnt, sl->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st), "counters");
                     check_sync(st, "extend");
+                    spec_done = spec && sl->h_seg_info[seg_words - 1] == 0;
                     if (ea.chain_cap && sl->h_cnt->n_long > ea.chain_cap && sl->h_cnt->n_long <= ea.cand_cap_recs) {
+                        spec_done = false;  // (the chain ran on an unfinished survivor list)
                         // more candidates than the chain buffers hold: the chain kernels left the batch alone (device-side
                         // test on the same counter); extend every candidate on its own
                         ExtendArgs eb = ea;
@@ -759,25 +801,23 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
             t_stats.num_entropy = n_ent_total;
 
             // ---- order + de-duplicate (:776-782 ; rm :819-831) ----
-            auto ensure_host_out = [&](size_t n) {
-                if (sl->h_out_cap >= n) return;
-                if (sl->h_out) hipHostFree(sl->h_out);
-                sl->h_out_cap = std::max<size_t>(n, 1u << 16);
-                if (hipHostMalloc((void**)&sl->h_out, sl->h_out_cap * sizeof(sa_segment_pair)) != hipSuccess) {
-                    fprintf(stderr, "Error: hipHostMalloc for hsp_output failed\n");
-                    exit(12);
+            if (survivors > 0 && spec_done && survivors <= dedup_seg_max_total()) {
+                if (survivors > SPEC_RECS) {  // the records beyond the speculative prefix
+                    check_memcpy(hipMemcpyAsync(sl->h_out + SPEC_RECS, sl->out16.p + SPEC_RECS, (size_t)(survivors - SPEC_RECS) * sizeof(sa_segment_pair),
+                                                hipMemcpyDeviceToHost, st), "hsp_output");
+                    check_sync(st, "hsp_output");
                 }
-            };
-            auto ensure_host_seg = [&](size_t n) {
-                if (sl->h_seg_cap >= n) return;
-                if (sl->h_seg) hipHostFree(sl->h_seg);
-                sl->h_seg_cap = std::max<size_t>(n, 1u << 16);
-                if (hipHostMalloc((void**)&sl->h_seg, sl->h_seg_cap * sizeof(uint32_t)) != hipSuccess) {
-                    fprintf(stderr, "Error: hipHostMalloc for the segment ids failed\n");
-                    exit(12);
+                const uint32_t S = dedup_small_max_segs();
+                size_t pos = 0;
+                for (uint32_t g = 0; g < (uint32_t)segs.size(); g++) {  // close the gaps the unique step left
+                    const uint32_t m2 = sl->h_seg_info[g], off = sl->h_seg_info[S + g];
+                    if (m2 && pos != off) memmove(sl->h_out + pos, sl->h_out + off, (size_t)m2 * sizeof(sa_segment_pair));
+                    for (uint32_t i = 0; i < m2; i++) sl->h_seg[pos + i] = g;
+                    pos += m2;
                 }
-            };
-            if (survivors > 0 && ca.raw_hits) {  // the extension stage's own output, unordered
+                n_final = (uint32_t)pos;
+                have_seg = true;
+            } else if (survivors > 0 && ca.raw_hits) {  // the extension stage's own output, unordered
                 sl->out16.ensure(survivors, "out16");
                 ensure_host_out(survivors);
                 launch_strip(sl->recA.p, survivors, sl->out16.p, nullptr, st);
@@ -792,14 +832,14 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                 sl->sort_temp.ensure(tb, "sort temp");
                 HspRec* fin = nullptr;
                 bool done = false;
-                if (!ca.rm && survivors <= dedup_seg_max_total() && segs.size() <= dedup_small_max_segs() && !g_no_small_dedup) {
+                if (!ca.rm && survivors <= dedup_seg_max_total() && segs.size() <= dedup_small_max_segs() && !g_no_small_dedup && !spec_tried) {
                     // the whole chain in LDS, one workgroup per segment; one D2H of the (gapped) records + the segment counts
                     const uint32_t words = dedup_seg_info_words();
                     sl->out16.ensure(survivors, "out16");
                     ensure_host_out(survivors);
                     ensure_host_seg(std::max<size_t>(survivors, words));
                     check_memcpy(hipMemsetAsync(sl->d_seg_info, 0, words * sizeof(uint32_t), st), "segment info");
-                    { ProfScope p(sl, "dedup_seg"); launch_dedup_seg(sl->recA.p, survivors, (uint32_t)segs.size(), sl->out16.p, sl->d_seg_info, (uint32_t)g_dedup_threads, st); }
+                    { ProfScope p(sl, "dedup_seg"); launch_dedup_seg(sl->recA.p, survivors, nullptr, (uint32_t)segs.size(), sl->out16.p, sl->d_seg_info, (uint32_t)g_dedup_threads, st); }
                     check_launch("dedup seg");
                     check_memcpy(hipMemcpyAsync(sl->h_seg_info, sl->d_seg_info, words * sizeof(uint32_t), hipMemcpyDeviceToHost, st), "segment info");
                     check_memcpy(hipMemcpyAsync(sl->h_out, sl->out16.p, (size_t)survivors * sizeof(sa_segment_pair),
@@ -1255,6 +1295,7 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
     if (const char* e = getenv("SEGALIGN_AMD_L2_BLOCKS")) g_l2_blocks = std::max(1, atoi(e));
     if (const char* e = getenv("SEGALIGN_AMD_CTX_WAVES")) g_ctx_waves = std::max(0, atoi(e));
     if (const char* e = getenv("SEGALIGN_AMD_CTX_THREADS")) g_ctx_threads = std::max(0, atoi(e));
+    if (const char* e = getenv("SEGALIGN_AMD_SPEC_DEDUP")) g_spec_dedup = atoi(e) != 0;
     if (const char* e = getenv("SEGALIGN_AMD_DEDUP_THREADS")) g_dedup_threads = std::max(0, atoi(e));
     if (xdrop >= (1 << 25) || xdrop <= -(1 << 25)) {
         fprintf(stderr, "Error: |xdrop| must be below 2^25\n");

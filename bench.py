@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--chunk", type=int, default=250_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU baseline budget")
+    ap.add_argument("--one-interval", action="store_true",
+                    help="profiling aid: set up, run ONE interval with one call in flight, exit (short enough for --pmc passes)")
     ap.add_argument("--host-threads", type=int, default=2,
                     help="host threads issuing SeedAndFilter calls (the reference runs one TBB seeder body per core; "
                          "the engine has 2 slots per device so one call's syncs overlap another call's kernels)")
@@ -236,6 +238,12 @@ def main():
             h += hh
         return b, h
 
+    if args.one_interval:
+        nb, nh = run_item(items[0], None, 1)
+        print(json.dumps({"one_interval": True, "bases": nb, "hsps": nh, "workload": args.workload}))
+        E.ShutdownProcessor()
+        return
+
     def barrier():
         if dist is not None:
             dist.barrier()
@@ -294,8 +302,9 @@ def main():
             "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": wl["data"],
             "config": {"workload": wl["label"] + ", HOXD70, xdrop 910, hspthresh 3000; step = one pass over the whole %d bp query "
-                                                 "block (%d intervals of %d bp), both strands, %d bp chunks (4 chunks of a strand share one "
-                                                 "pass over the kernels), device-side seeding" % (query.size, len(items), args.interval, args.chunk),
+                                                 "block (%d intervals of %d bp), both strands, %d bp chunks (%d chunks of a strand share one "
+                                                 "pass over the kernels), device-side seeding" % (query.size, len(items), args.interval, args.chunk,
+                                                                                                 E.lib().sa_get_chunks_per_call()),
                        "workload_key": args.workload,
                        "parallelism": "query-interval shards x%d (every rank walks the interval list from its own offset), no collective" % world,
                        "hsps_per_step": hsps // max(args.steps * world, 1)},
@@ -303,6 +312,18 @@ def main():
                         "seed_table_build": round(t_table, 3), "query_upload_encode": round(t_query, 3)},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        # table build (setup, once per target block): algorithmic bytes of the reference-layout table, and the bytes
+        # this build writes on top of it -- the neighbourhood table, 4-byte positions or 32-byte context records
+        lm, nent = E.lookup_mode(), E.neighbourhood_entries()
+        tv = float(target.size)
+        alg_tb = tv + 8.0 * 4 ** 12 + 8.0 * tv
+        impl_tb = alg_tb + nent * {0: 0, 1: 4, 2: 32}[lm]
+        line["table_build"] = {
+            "seconds": round(t_table, 4), "lookup_mode": lm, "neighbourhood_entries": nent,
+            "bytes": "1*T + 8*4^12 + 8*T_valid (reference-layout table) [+ 32 B (context) or 4 B per neighbourhood entry]",
+            "algorithmic_bytes": int(alg_tb), "algorithmic_frac": round(alg_tb / max(t_table, 1e-9) / 1e9 / HBM_PEAK_GBS, 5),
+            "written_bytes": int(impl_tb), "written_frac": round(impl_tb / max(t_table, 1e-9) / 1e9 / HBM_PEAK_GBS, 4),
+            "note": "includes hipMalloc of the tables (first block of a process) and every sync of the build"}
         print(json.dumps(line))
         sys.stdout.flush()
     E.ShutdownProcessor()

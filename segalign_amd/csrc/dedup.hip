@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void strip_kernel(const HspRec* __restrict__ i
     }
 }
 
-constexpr int DEDUP_SMALL_SEGS = 16;  // distinct segment ids (reference iterations x chunks of a call) the LDS path handles
+constexpr int DEDUP_SMALL_SEGS = 32;  // distinct segment ids (reference iterations x chunks of a call) the LDS path handles
 
 // ---- the whole chain in LDS, ONE WORKGROUP PER SEGMENT -----------------------------------------------------------------
 // After the chain shortcut a call leaves a few hundred to a few thousand survivors; three library sorts + unique + strip then
@@ -171,23 +171,57 @@ constexpr int DEDUP_SMALL_SEGS = 16;  // distinct segment ids (reference iterati
 // LDS and writes its result into the slot range the segment's INPUT records would occupy (offset = number of survivors in
 // lower segments); the host closes the gaps while it splits the output per chunk anyway.  Eight small workgroups on eight
 // CUs instead of one 1024-thread workgroup walking all records: the stage's latency drops from ~200 us (500 us next to a
-// running filter kernel) to ~20 us, and the limit rises from 1024 survivors per call to 1024 per segment.
+// running filter kernel) to ~20 us, and the limit rises from 1024 survivors per call to 2048 per segment.
 constexpr int DEDUP_SEG_THREADS = 1024;
-constexpr int DEDUP_SEG_MAX = 1024;      // records per segment
-constexpr int DEDUP_SEG_TOTAL = 16384;   // survivors per call (every workgroup scans the whole list once)
+constexpr int DEDUP_SEG_MAX = 2048;      // records per segment (2 x 40 KB of LDS)
+constexpr int DEDUP_SEG_TOTAL = 65536;   // survivors per call (every workgroup scans the whole list once)
 
-template <class Less>
-__device__ __forceinline__ void rank_sort_lds(const HspRec* __restrict__ src, HspRec* __restrict__ dst, uint32_t m) {
-    Less less;
-    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
-        const HspRec me = src[i];
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < m; j++) {
-            const HspRec o = src[j];
-            rank += (less(o, me) || (j < i && !less(me, o))) ? 1u : 0u;  // #smaller + #equivalent before = the stable position
-        }
-        dst[rank] = me;
+// In-place bitonic sort of m <= DEDUP_SEG_MAX records of ONE segment in LDS.  The records' seg field (constant inside a
+// segment) carries the input index while sorting: it is the last key, which makes the keys unique and the result the stable
+// order thrust::stable_sort gives (:776,:782); padding entries up to the next power of two compare above everything.
+// (The quadratic rank sort this replaces took 0.65 ms per 2048 records; the network is m log^2 m / 2 compare-exchanges.)
+constexpr uint32_t SORT_PAD = 0xFFFFFFFFu;
+struct KeyDiag {   // hspComp :54-80 inside one segment, then the input index
+    __device__ bool operator()(const HspRec& x, const HspRec& y) const {
+        const uint32_t dx = x.ref_start - x.query_start, dy = y.ref_start - y.query_start;
+        if (dx != dy) return dx < dy;
+        if (x.ref_start != y.ref_start) return x.ref_start < y.ref_start;
+        if (x.len != y.len) return x.len < y.len;
+        if (x.score != y.score) return x.score > y.score;
+        return x.seg < y.seg;
     }
+};
+struct KeyLastz {  // hspCompLastz :82-108 inside one segment, then the input index
+    __device__ bool operator()(const HspRec& x, const HspRec& y) const {
+        if (x.query_start != y.query_start) return x.query_start < y.query_start;
+        if (x.ref_start != y.ref_start) return x.ref_start < y.ref_start;
+        if (x.len != y.len) return x.len < y.len;
+        if (x.score != y.score) return x.score > y.score;
+        return x.seg < y.seg;
+    }
+};
+template <class Key>
+__device__ __forceinline__ void bitonic_sort_lds(HspRec* __restrict__ a, uint32_t m, uint32_t seg) {
+    Key less;
+    uint32_t P = 1;
+    while (P < m) P <<= 1;
+    for (uint32_t i = threadIdx.x; i < P; i += blockDim.x) a[i].seg = i < m ? i : SORT_PAD;
+    __syncthreads();
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
+                const uint32_t lo = ((t & ~(j - 1u)) << 1) | (t & (j - 1u));  // pair t: a zero bit inserted at bit log2(j)
+                const uint32_t hi = lo | j;
+                const HspRec x = a[lo], y = a[hi];
+                const bool xp = x.seg == SORT_PAD, yp = y.seg == SORT_PAD;
+                const bool y_lt_x = (xp || yp) ? (xp && !yp) : less(y, x);
+                const bool x_lt_y = (xp || yp) ? (yp && !xp) : less(x, y);
+                if (((lo & k) == 0) ? y_lt_x : x_lt_y) { a[lo] = y; a[hi] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) a[i].seg = seg;
     __syncthreads();
 }
 
@@ -226,7 +260,9 @@ __global__ __launch_bounds__(DEDUP_SEG_THREADS) void dedup_seg_kernel(const HspR
         if (threadIdx.x == 0) { seg_info[2 * DEDUP_SMALL_SEGS] = 1u; seg_info[g] = 0; seg_info[DEDUP_SMALL_SEGS + g] = off; }
         return;
     }
-    rank_sort_lds<LessDiag>(s_a, s_b, m);  // :776
+    const uint32_t my_seg = m ? s_a[0].seg : 0u;  // (every record of the workgroup carries the same segment id)
+    __syncthreads();
+    bitonic_sort_lds<KeyDiag>(s_a, m, my_seg);  // :776
     // adjacent-pair unique on the sorted sequence (:778-780, hazard H3), order preserving
     uint32_t carry = 0;
     for (uint32_t base = 0; base < m; base += blockDim.x) {
@@ -235,8 +271,8 @@ __global__ __launch_bounds__(DEDUP_SEG_THREADS) void dedup_seg_kernel(const HspR
         HspRec me;
         me.ref_start = me.query_start = me.len = 0; me.score = 0; me.seg = 0;
         if (i < m) {
-            me = s_b[i];
-            keep = i == 0 || !hsp_contained(s_b[i - 1], me);
+            me = s_a[i];
+            keep = i == 0 || !hsp_contained(s_a[i - 1], me);
         }
         const unsigned long long mask = __ballot(keep);
         if (lane == 0) s_wave[wave] = (uint32_t)__popcll(mask);
@@ -247,12 +283,12 @@ __global__ __launch_bounds__(DEDUP_SEG_THREADS) void dedup_seg_kernel(const HspR
             if (w < wave) pre += c;
             tot += c;
         }
-        if (keep) s_a[carry + pre + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = me;
+        if (keep) s_b[carry + pre + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = me;
         carry += tot;
         __syncthreads();
     }
     const uint32_t m2 = carry;
-    rank_sort_lds<LessLastz>(s_a, s_b, m2);  // :782
+    bitonic_sort_lds<KeyLastz>(s_b, m2, my_seg);  // :782
     for (uint32_t i = threadIdx.x; i < m2; i += blockDim.x) {
         const HspRec r = s_b[i];
         out[off + i] = make_uint4(r.ref_start, r.query_start, r.len, (uint32_t)r.score);

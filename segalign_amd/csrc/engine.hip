@@ -196,8 +196,8 @@ static int prof_id(const char* name) {
 // per-device state
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int MAX_SLOTS_PER_DEVICE = 4;
-constexpr uint32_t SPEC_RECS = 4096;  // records of the speculative output copy (64 KB)
-constexpr int SA_MAX_CHUNKS = 4;  // chunks one multi-chunk call carries: 2 reference iterations each = MAX_SEGS segments (8 chunks measured no faster)
+constexpr uint32_t SPEC_RECS = 16384; // records of the speculative output copy (256 KB = everything the LDS chain can deliver)
+constexpr int SA_MAX_CHUNKS = 16;  // chunks one multi-chunk call may carry: 2 reference iterations each = MAX_SEGS segments
 static int SLOTS_PER_DEVICE = 2;  // calls in flight per device (the reference allows one: token == device); SEGALIGN_AMD_SLOTS
 
 struct Counters {  // device-side scalars of one slot
@@ -322,6 +322,7 @@ static int g_long_cap = 128;      // SEGALIGN_AMD_LONG_CAP: bases per side befor
 static int g_long_blocks = 1792;  // SEGALIGN_AMD_LONG_BLOCKS: grid of the long kernel (4 waves per block)
 static int g_packed_waves = 4096; // SEGALIGN_AMD_PACKED_WAVES: waves of the packed filter (2 workgroups of 8 waves per CU measured best: 3072 +16 %, 6144 +20 %, 8192 +14 %)
 static int g_ctx_waves = 0;       // SEGALIGN_AMD_CTX_WAVES: wave budget of the context filter; 0 = one 4096-hit chunk per wave (measured best)
+static int g_ctx_pipe = 1;        // SEGALIGN_AMD_CTX_PIPE: 1 = no prefetch, 53 VGPRs (measured best by 1-3 %), 2 = ping-pong prefetch, 3 = records only
 static int g_ctx_threads = 0;     // SEGALIGN_AMD_CTX_THREADS: workgroup size of the context filter (0 = kernel default)
 static int g_dedup_threads = 0;   // SEGALIGN_AMD_DEDUP_THREADS: workgroup size of the per-segment LDS chain (0 = 1024)
 static int g_spec_dedup = 1;      // SEGALIGN_AMD_SPEC_DEDUP=0: wait for the survivor count before the LDS chain (one more host sync)
@@ -335,7 +336,7 @@ static int g_no_small_dedup = 0;  // SEGALIGN_AMD_NO_SMALL_DEDUP=1: always use t
 static int g_ctx = 1;             // neighbourhood table with target context when it fits (SEGALIGN_AMD_NO_CTX=1: positions only)
 static int g_td = 1;              // table-direct lookup (neighbourhood table + position probe, probe.hip); SEGALIGN_AMD_NO_TD=1 turns it off
 static int g_chain = 1;           // chain shortcut of the exact stage (SEGALIGN_AMD_NO_CHAIN=1 turns it off)
-static uint32_t CHAIN_CAP = 1u << 20;  // candidates per batch the chain buffers hold (SEGALIGN_AMD_CHAIN_CAP); larger batches fall back
+static uint32_t CHAIN_CAP = 1u << 22;  // candidates per batch the chain buffers hold (SEGALIGN_AMD_CHAIN_CAP); larger batches fall back
 static SeedShape g_shape = {0, 0, 0, {0}};
 static uint32_t g_query_len[SA_BUFFER_DEPTH] = {0, 0};
 
@@ -620,7 +621,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                 int64_t b_seed_lo = seed_lo, b_seed_hi = seed_lo;
                 uint64_t b_hit_lo = hit_lo, b_hit_hi = hit_lo;
                 uint32_t it0 = it;
-                while (it < segs.size() && nseg < MAX_SEGS) {
+                while (it < segs.size() && nseg < (ca.td ? MAX_SEGS : MAX_SEGS_ABS)) {
                     uint64_t upto = segs[it].hit_hi;
                     if (!ca.td && nseg > 0 && upto - b_hit_lo > HIT_BATCH) break;  // (no hit list in a table-direct call)
                     ea.seg_end[nseg++] = upto;
@@ -645,6 +646,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     ea.l2_blocks = (uint32_t)g_l2_blocks;
                     ea.ctx_waves = (uint32_t)g_ctx_waves;
                     ea.ctx_threads = (uint32_t)g_ctx_threads;
+                    ea.ctx_pipe = (uint32_t)g_ctx_pipe;
                 } else if (!ca.raw_hits) {
                     sl->hits.ensure((size_t)bh, "hits");
                     ProfScope p(sl, "expand_hits");
@@ -691,7 +693,10 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                 // sort key, and is off while E is being counted.  The repeat masker takes it too: its window only decides WHICH
                 // hits are extended (all candidates lie inside it), and its chain starts with an exact-duplicate unique
                 // (rm :819-823), so the duplicates the shortcut never produces would be removed there anyway
-                const bool chain = g_chain && g_xdrop >= 0 && ca.query_len < (1u << 29) && !g_count_examined;
+                const bool chain_rel = ca.td && ca.q_hi > ca.q_lo && ca.q_hi - ca.q_lo < (1u << 27);  // positions relative to the call's first
+                const bool chain = g_chain && g_xdrop >= 0 && (chain_rel || (nseg <= MAX_SEGS_ABS && ca.query_len < (1u << 29))) && !g_count_examined;
+                ea.chain_q_bits = chain_rel ? 27u : 29u;
+                ea.chain_q_base = chain_rel ? ca.q_lo : 0u;
                 ea.chain_cap = chain ? CHAIN_CAP : 0u;
                 ea.chain_sort_threads = (uint32_t)g_chain_sort_threads;
                 if (chain) {
@@ -1294,6 +1299,7 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
     if (const char* e = getenv("SEGALIGN_AMD_PACKED_WAVES")) g_packed_waves = std::max(8, atoi(e));
     if (const char* e = getenv("SEGALIGN_AMD_L2_BLOCKS")) g_l2_blocks = std::max(1, atoi(e));
     if (const char* e = getenv("SEGALIGN_AMD_CTX_WAVES")) g_ctx_waves = std::max(0, atoi(e));
+    if (const char* e = getenv("SEGALIGN_AMD_CTX_PIPE")) g_ctx_pipe = atoi(e);
     if (const char* e = getenv("SEGALIGN_AMD_CTX_THREADS")) g_ctx_threads = std::max(0, atoi(e));
     if (const char* e = getenv("SEGALIGN_AMD_SPEC_DEDUP")) g_spec_dedup = atoi(e) != 0;
     if (const char* e = getenv("SEGALIGN_AMD_DEDUP_THREADS")) g_dedup_threads = std::max(0, atoi(e));
@@ -1327,7 +1333,7 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
         g_chain_sort_threads = 256;
         if (const char* e = getenv("SEGALIGN_AMD_CHAIN_SORT_THREADS")) g_chain_sort_threads = std::max(64, std::min(512, atoi(e) & ~63));
         if (const char* e = getenv("SEGALIGN_AMD_CHAIN_CAP")) CHAIN_CAP = (uint32_t)std::max(1, atoi(e));
-        else CHAIN_CAP = 1u << 20;
+        else CHAIN_CAP = 1u << 22;
         g_no_small_dedup = getenv("SEGALIGN_AMD_NO_SMALL_DEDUP") ? 1 : 0;
         g_chunks_per_call = SA_MAX_CHUNKS;
         if (const char* e = getenv("SEGALIGN_AMD_CHUNKS_PER_CALL")) g_chunks_per_call = std::max(1, std::min(SA_MAX_CHUNKS, atoi(e)));
@@ -1617,6 +1623,7 @@ size_t sa_seed_and_filter_range(uint32_t start, uint32_t end, int rev, uint32_t 
 // seeding, lookup, expansion, extension, grouping and ordering launches and the host syncs, while every chunk keeps its own
 // iteration plan, dedup scope and return vector -- bit for bit what one sa_seed_and_filter_range call per chunk returns.
 int sa_max_chunks_per_call(void) { return SA_MAX_CHUNKS; }
+int sa_get_chunks_per_call(void) { return g_chunks_per_call; }  // what sa_seed_interval hands to one call (SEGALIGN_AMD_CHUNKS_PER_CALL)
 size_t sa_seed_and_filter_chunks(uint32_t start, uint32_t end, int rev, uint32_t buffer, sa_segment_pair** outs, size_t* counts) {
     require_proc("SeedAndFilterChunks", buffer);
     const uint32_t chunk = g_wga_chunk;

@@ -440,7 +440,11 @@ constexpr int PK_THREADS = 512;
 constexpr int PK_TAB = 4096;
 
 // ---- pair table: entry (4 target bits | query byte << 4) = {s0, s0 + s1} as two int16 (see above) ---------------------
-template <bool WIDE>  // WIDE: 8-byte entries {s0 + s1, max(s0, s0 + s1)} as two int32 (context filter); else {s0, s0 + s1} as two int16
+// WIDE (context filter): 8-byte entries {s0 + s1, max(s0, s0 + s1)} as two int32 at BYTE ADDRESS (query byte << 8) | (target
+// nibble << 4) | (8 for the reversed walk) -- the 16-bit field the address arithmetic of ctx_step16 produces IS the address,
+// forward and reversed entries of a pair share 16 bytes; query codes are <= 7, so the table ends at 0x7800 (30 KB).
+// else: {s0, s0 + s1} as two int16, entry index (query byte << 4) | target nibble, reversed walk = query byte | 0x88
+template <bool WIDE>
 __device__ __forceinline__ void pk_table_init(uint32_t* __restrict__ s_pk, const int* __restrict__ sub_mat, int nthreads) {
     // the 64 matrix entries go through LDS first (the 4096 pair entries read ~10 of them each): the row-0 maximum over
     // the rows {A, L, N, X, E} is folded in there, scores are raised to -16383
@@ -464,8 +468,12 @@ __device__ __forceinline__ void pk_table_init(uint32_t* __restrict__ s_pk, const
         }
         const int s0 = s_m[r0 * 8 + q0], s1 = s_m[r1 * 8 + q1];
         if (WIDE) {
-            s_pk[2 * i] = (uint32_t)(s0 + s1);
-            s_pk[2 * i + 1] = (uint32_t)max(s0, s0 + s1);
+            const int fl = qb & 0x88;
+            if (fl == 0 || fl == 0x88) {  // (query bytes with one flag bit do not occur)
+                const int w = ((qb & 0x77) << 6) | (rp << 2) | (rev ? 2 : 0);  // dword index of the entry
+                s_pk[w] = (uint32_t)(s0 + s1);
+                s_pk[w + 1] = (uint32_t)max(s0, s0 + s1);
+            }
         } else {
             s_pk[i] = ((uint32_t)s0 & 0xffffu) | ((uint32_t)(s0 + s1) << 16);
         }
@@ -791,15 +799,15 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
 //                                                             exact kernels exactly as before.
 // one 16-base step: td = 16 target bases (2 bit each) in walking order; qa | qb = the 16 query bases (4 bit each) as they lie
 // in memory -- REV = false: walking order (right side); REV = true: the bytes run against the walk (left side; qa holds the
-// first four pairs in bytes 3..0) and every byte must carry the 0x88 "reversed" flags of the pair table.
+// first four pairs in bytes 3..0), scored with the reversed-walk half of every table entry.
 // Instruction choice follows tools/micro/valu_rate.hip: on gfx950 plain 32-bit VOP2 ops (v_add_u32, v_max_i32, v_and_b32,
 // shifts) issue in ~2.8 cycles per wave, everything packed / SDWA / VOP3 (v_pk_add_i16, v_pk_max_i16, v_perm_b32, v_bfe)
 // in ~4.6.  So the context filter scores in int32 -- table entries are 8 bytes {sum = s0 + s1, mx = max(s0, s0 + s1)}, per
-// pair M = max(M, T + mx); T += sum: three full-rate ops, no saturation, no int16 limits -- and only the address
-// arithmetic uses the slow forms: byte address of a pair's entry = (query byte << 7) | (target nibble << 3)
-// = (query byte << 8 | target nibble << 4) >> 1; the 8 target nibbles of the step are spread into the high nibbles of two
-// dwords (even / odd pairs: 3 ops), four byte permutes zip them with the query bytes into 16-bit fields, one SDWA shift per
-// pair turns a field into the address.
+// pair M = max(M, T + mx); T += sum: three full-rate ops, no saturation, no int16 limits -- and the table is laid out so that
+// the address arithmetic needs no slow op beyond the four byte permutes of a step: the 8 target nibbles are spread into the
+// high nibbles of two dwords (even / odd pairs: 3 ops), the permutes zip them with the query bytes into 16-bit fields
+// (query byte << 8) | (target nibble << 4), and that field IS the entry's byte address (pk_table_init<true>): one v_and /
+// v_lshrrev per pair picks it out of its dword.
 template <bool REV>
 __device__ __forceinline__ void ctx_step16(const uint32_t* __restrict__ s_tab, uint32_t td, uint32_t qa, uint32_t qb, int& T, int& M) {
     const uint32_t ev = (td << 4) & 0xF0F0F0F0u;  // pairs 0, 2, 4, 6
@@ -812,10 +820,8 @@ __device__ __forceinline__ void ctx_step16(const uint32_t* __restrict__ s_tab, u
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const uint32_t f = j == 0 || j == 2 ? f02 : j == 1 || j == 3 ? f13 : j == 4 || j == 6 ? f46 : f57;
-        uint32_t addr;
-        if ((j & 2) == 0) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(addr) : "v"(1), "v"(f));
-        else asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(addr) : "v"(1), "v"(f));
-        const uint2 e = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(s_tab) + addr);  // one ds_read_b64
+        const uint32_t addr = (j & 2) == 0 ? (f & 0xFFFFu) : (f >> 16);  // plain VOP2 (full rate), no SDWA
+        const uint2 e = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(s_tab) + addr + (REV ? 8 : 0));  // one ds_read_b64
         M = max(M, T + (int)e.y);
         T += (int)e.x;
     }
@@ -826,7 +832,11 @@ __device__ __forceinline__ void ctx_step16(const uint32_t* __restrict__ s_tab, u
 // whole bench (tools/sweep_threads.sh)
 constexpr int CTX_THREADS = 512;      // default; ExtendArgs::ctx_threads (SEGALIGN_AMD_CTX_THREADS) overrides it per launch
 constexpr int CTX_THREADS_MAX = 1024;
-__global__ __launch_bounds__(CTX_THREADS_MAX) void extend_filter_ctx_kernel(ExtendArgs a) {
+// PIPE: how a wave covers the latency of its stream.  2 = records + query windows of buffer b + 1 requested before buffer b is
+// scored (two full register sets, 77 VGPRs, 6 waves per SIMD); 1 = no prefetch, 53 VGPRs, 8 waves per SIMD; 3 = only the
+// records of b + 1 are prefetched (the query windows are L1 / L2 hits), <= 64 VGPRs, 8 waves per SIMD
+template <int PIPE>
+__global__ __launch_bounds__(CTX_THREADS_MAX, PIPE == 2 ? 4 : 8) void extend_filter_ctx_kernel(ExtendArgs a) {
     __shared__ uint32_t s_pk[2 * PK_TAB];  // 8-byte entries {sum, max prefix} (32 KB)
     extern __shared__ CandRec s_cand_dyn[];  // [waves of the workgroup][STAGE_CAP]
     pk_table_init<true>(s_pk, a.sub_mat, (int)blockDim.x);
@@ -856,7 +866,7 @@ __global__ __launch_bounds__(CTX_THREADS_MAX) void extend_filter_ctx_kernel(Exte
     // latency of the stream is covered by ~2000 cycles of arithmetic instead of by occupancy alone.  The loop is unrolled by
     // two over a pair of register sets (no register-to-register copies between iterations).
     struct Loaded { uint4 c0, c1, qr0, ql0, ql1; uint2 qr1; uint32_t qp; };
-    auto request = [&](uint64_t b, Loaded& L) {
+    auto request_ctx = [&](uint64_t b, Loaded& L) {
         if (b >= b_hi) return;  // (wave-uniform)
         const uint64_t rem = a.num_hits - (b << 6);
         const int cnt = rem >= 64 ? 64 : (int)rem;
@@ -865,6 +875,11 @@ __global__ __launch_bounds__(CTX_THREADS_MAX) void extend_filter_ctx_kernel(Exte
         if (lane >= cnt) return;  // the lane sits out this buffer; its registers keep stale (unused) values
         L.c0 = ctx[2 * entry];      // pos, r0, r1, r2
         L.c1 = ctx[2 * entry + 1];  // l0 .. l3
+    };
+    auto request_query = [&](uint64_t b, Loaded& L) {
+        if (b >= b_hi) return;  // (wave-uniform)
+        const uint64_t rem = a.num_hits - (b << 6);
+        if (lane >= (rem >= 64 ? 64 : (int)rem)) return;
         // query windows: 48 bases from the anchor on, 64 bases before it, from the 4-bit copy in which both are DWORD aligned
         // (encode.hip: byte-aligned 16-byte loads take the slow path of the texture addresser)
         const uint32_t query_loc = L.qp + a.seed_size;  // :204
@@ -907,14 +922,13 @@ __global__ __launch_bounds__(CTX_THREADS_MAX) void extend_filter_ctx_kernel(Exte
         M = 0;
         alive = !skip;
         {
-            const uint32_t D = 0x88888888u;
 #pragma unroll
             for (int st = 0; st < 4; st++) {
                 if (alive) {
                     const uint32_t td = st == 0 ? c1.x : st == 1 ? c1.y : st == 2 ? c1.z : c1.w;
                     const uint32_t a0 = st == 0 ? ql1.w : st == 1 ? ql1.y : st == 2 ? ql0.w : ql0.y;
                     const uint32_t a1 = st == 0 ? ql1.z : st == 1 ? ql1.x : st == 2 ? ql0.z : ql0.x;
-                    ctx_step16<true>(s_pk, td, a0 | D, a1 | D, T, M);
+                    ctx_step16<true>(s_pk, td, a0, a1, T, M);
                     alive = (M - T) <= xdrop;  // :523
                 }
             }
@@ -930,12 +944,33 @@ __global__ __launch_bounds__(CTX_THREADS_MAX) void extend_filter_ctx_kernel(Exte
     A.qr1 = make_uint2(0u, 0u);
     A.qp = 0;
     B = A;
-    request(b_lo, A);
-    for (uint64_t b = b_lo; b < b_hi; b += 2) {
-        request(b + 1, B);
-        score(b, A);
-        request(b + 2, A);
-        if (b + 1 < b_hi) score(b + 1, B);
+    if (PIPE == 2) {
+        request_ctx(b_lo, A);
+        request_query(b_lo, A);
+        for (uint64_t b = b_lo; b < b_hi; b += 2) {
+            request_ctx(b + 1, B);
+            request_query(b + 1, B);
+            score(b, A);
+            request_ctx(b + 2, A);
+            request_query(b + 2, A);
+            if (b + 1 < b_hi) score(b + 1, B);
+        }
+    } else if (PIPE == 3) {
+        request_ctx(b_lo, A);
+        for (uint64_t b = b_lo; b < b_hi; b += 2) {
+            request_query(b, A);
+            request_ctx(b + 1, B);
+            score(b, A);
+            request_query(b + 1, B);
+            request_ctx(b + 2, A);
+            if (b + 1 < b_hi) score(b + 1, B);
+        }
+    } else {
+        for (uint64_t b = b_lo; b < b_hi; b++) {
+            request_ctx(b, A);
+            request_query(b, A);
+            score(b, A);
+        }
     }
     stage_flush(stage, n_stage, a.l2_list, a.l2_count, a.l2_cap, lane);
 }
@@ -1114,7 +1149,7 @@ constexpr uint32_t CHAIN_WALK_EXTRA = 96; // bases walked past the predecessor's
 // (iteration, diagonal, position).  A bucket holds a handful of diagonals with a few hundred candidates each, so the
 // quadratic rank sort is a few microseconds; all buckets together are the candidate list with every diagonal's
 // candidates contiguous and ordered by position -- exactly what the link test needs.  No host involvement.
-constexpr uint32_t CHAIN_BUCKETS = 4096;
+constexpr uint32_t CHAIN_BUCKETS = 16384;  // (a 16-chunk call at human-scale hit density carries ~1.5 M candidates)
 constexpr uint32_t CHAIN_SORT_MAX = 1024;  // entries a bucket may hold and still be sorted (8 KB of LDS); larger: left unsorted,
                                            // which only makes link tests fail, i.e. costs extensions, never correctness
 
@@ -1127,9 +1162,12 @@ __device__ __forceinline__ uint32_t chain_bucket_of(uint32_t seg, const CandRec&
     return (((diag * 2654435761u) ^ ((c.query_loc >> CHAIN_QSHIFT) * 0x85EBCA6Bu) ^ (seg * 0x9E3779B1u)) >> 15) & (CHAIN_BUCKETS - 1u);
 }
 __device__ __forceinline__ unsigned long long chain_key(const ExtendArgs& a, const CandRec& c) {
-    // iteration (3 bits) | diagonal (32) | query position (29)
-    return ((unsigned long long)(seg_of(a, c.hidx) - a.seg_base) << 61) |
-           ((unsigned long long)(uint32_t)(c.ref_loc - c.query_loc) << 29) | (unsigned long long)(c.query_loc & 0x1FFFFFFFu);
+    // iteration | diagonal (32) | query position (q bits): 3 | 32 | 29 with absolute positions (general path, <= 8 iterations per
+    // batch), 5 | 32 | 27 with positions relative to the call's first one (table-direct calls: <= 32 iterations, <= 4 M positions)
+    const uint32_t qb = a.chain_q_bits;
+    return ((unsigned long long)(seg_of(a, c.hidx) - a.seg_base) << (32u + qb)) |
+           ((unsigned long long)(uint32_t)(c.ref_loc - c.query_loc) << qb) |
+           (unsigned long long)((c.query_loc - a.chain_q_base) & ((1u << qb) - 1u));
 }
 
 __global__ __launch_bounds__(256) void chain_count_kernel(ExtendArgs a) {
@@ -1372,7 +1410,10 @@ void launch_extend_filter_ctx(const ExtendArgs& a, hipStream_t s) {
     threads = std::min<uint32_t>(CTX_THREADS_MAX, std::max<uint32_t>(64, threads & ~63u));
     const uint32_t wpb = threads / 64;
     const uint32_t blocks = (uint32_t)((waves + wpb - 1) / wpb);
-    hipLaunchKernelGGL(extend_filter_ctx_kernel, dim3(blocks), dim3(threads), wpb * STAGE_CAP * sizeof(CandRec), s, a);
+    const size_t lds = wpb * STAGE_CAP * sizeof(CandRec);
+    if (a.ctx_pipe == 2) hipLaunchKernelGGL(extend_filter_ctx_kernel<2>, dim3(blocks), dim3(threads), lds, s, a);
+    else if (a.ctx_pipe == 3) hipLaunchKernelGGL(extend_filter_ctx_kernel<3>, dim3(blocks), dim3(threads), lds, s, a);
+    else hipLaunchKernelGGL(extend_filter_ctx_kernel<1>, dim3(blocks), dim3(threads), lds, s, a);
 }
 
 void launch_chain_group(const ExtendArgs& a, hipStream_t s) {  // chain_bucket_cnt must be zero on entry

@@ -13,7 +13,8 @@ namespace sa {
 constexpr int SEQ_PAD = 64;
 
 constexpr int MAX_CARE = 16;  // seed weight limit; reference asserts 3 < kmer_size <= 15 (seed_pos_table.cu:51-52)
-constexpr int MAX_SEGS = 8;   // reference iterations handled by one extension batch
+constexpr int MAX_SEGS = 32;  // reference iterations handled by one extension batch (16 chunks x 2 iterations of a table-direct call)
+constexpr int MAX_SEGS_ABS = 8;  // ... of a batch whose chain sort key carries absolute query positions (general path)
 
 struct SeedShape {            // device copy of the state GenerateShapePos keeps (ntcoding.cpp:6-8)
     int weight;               // # care positions (kmer_size)
@@ -113,6 +114,9 @@ struct ExtendArgs {
     uint32_t l2_cap;
     int src_cand;               // packed filter reads its anchors from l2_list / *l2_count instead of `hits`
     uint32_t ctx_waves;         // wave budget of the context filter (0: one chunk of TD_CHUNK_HITS hits per wave)
+    uint32_t chain_q_bits;      // chain sort key = iteration | diagonal (32) | query position (chain_q_bits) relative to chain_q_base
+    uint32_t chain_q_base;
+    uint32_t ctx_pipe;          // latency-hiding variant of the context filter (see extend_filter_ctx_kernel)
     uint32_t ctx_threads;       // workgroup size of the context filter (0: its default)
     uint32_t l2_blocks;         // grid of the second level (its hit count is known on the device only)
     uint32_t seed_size;

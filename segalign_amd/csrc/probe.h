@@ -7,7 +7,7 @@
 
 namespace sa {
 
-constexpr int TD_MAX_BOUNDS = 8;  // chunk boundaries of one call: SA_MAX_CHUNKS + 1 <= 8
+constexpr int TD_MAX_BOUNDS = 20; // chunk boundaries of one call: SA_MAX_CHUNKS + 1 <= 20
 
 struct TdBounds {                 // query positions of the chunk boundaries of a call, ascending; pos[0] = start, pos[nb-1] = end
     int nb;

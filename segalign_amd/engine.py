@@ -35,7 +35,7 @@ C_ABI_SYMBOLS = [
     "sa_get_num_index", "sa_get_index_table_size", "sa_copy_ref_codes", "sa_copy_index_table", "sa_copy_pos_table",
     "sa_copy_query_codes", "sa_get_query_len", "sa_device_make_seeds", "sa_version",
     "sa_rm_mask_interval", "sa_rm_coverage_intervals", "sa_free_intervals", "sa_get_filter_mode",
-    "sa_seed_interval", "sa_seed_and_filter_chunks", "sa_max_chunks_per_call", "sa_extend_hits",
+    "sa_seed_interval", "sa_seed_and_filter_chunks", "sa_max_chunks_per_call", "sa_get_chunks_per_call", "sa_extend_hits",
     "sa_get_lookup_mode", "sa_get_neighbourhood_entries",
 ]
 IVL_DTYPE = np.dtype([("query_start", "<u4"), ("len", "<u4")])  # struct Segment, repeat_masker_src/graph.h:32-35

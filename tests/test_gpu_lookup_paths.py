@@ -36,7 +36,7 @@ def clean(engine):
 def test_every_lookup_path_equals_the_oracle(oracle, clean, mode, env, transition):
     with_env(env)
     t, q = synth.make_pair(400000, 41, 42, sub_rate=0.09, mask_frac=0.15, records=3, indel_every=450, n_runs=2)
-    c = Case(t, q, chunk=60000, transition=transition).oracle_setup(oracle).engine_setup(clean)
+    c = Case(t, q, chunk=24000, transition=transition).oracle_setup(oracle).engine_setup(clean)  # 17 chunks: a full 16-chunk call + 1
     E = c.E
     assert E.lookup_mode() == mode
     if mode:
@@ -53,10 +53,13 @@ def test_every_lookup_path_equals_the_oracle(oracle, clean, mode, env, transitio
             wants.append(want)
             per[rev].append(want[1:])
         ch = c.chunks()
-        for g in range(0, len(ch), 4):  # multi-chunk calls: own plan / dedup scope / vector per chunk
-            outs = E.SeedAndFilterChunks(ch[g][0], ch[min(g + 3, len(ch) - 1)][1], rev, 0)
-            for j, w in enumerate(wants[g:g + 4]):
-                assert seg_equal(outs[j], w), (mode, rev, g, j)
+        kmax = E.lib().sa_max_chunks_per_call()
+        assert kmax == 16 and len(ch) > kmax
+        for k in (4, kmax):  # multi-chunk calls: own plan / dedup scope / vector per chunk (16 chunks = 32 reference iterations)
+            for g in range(0, len(ch), k):
+                outs = E.SeedAndFilterChunks(ch[g][0], ch[min(g + k - 1, len(ch) - 1)][1], rev, 0)
+                for j, w in enumerate(wants[g:g + k]):
+                    assert seg_equal(outs[j], w), (mode, rev, k, g, j)
     fw, rc, st = E.SeedInterval(0, q_len, q_len, E.STRAND_BOTH, 0, 3)
     assert np.array_equal(fw, np.concatenate(per[False])) and np.array_equal(rc, np.concatenate(per[True]))
     assert fw.size + rc.size > 100

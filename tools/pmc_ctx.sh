@@ -1,13 +1,18 @@
+#!/bin/bash
+# Counter passes for the context filter on ONE interval of the default workload (25 sixteen-chunk calls... one call in flight):
+# each --pmc pass serialises the kernels, so the command is kept short.  Usage (GPU box): bash tools/pmc_ctx.sh [extra env]
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/pmc_ctx
+mkdir -p $OUT
 i=0
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_VMEM_TA_ADDR_FIFO_FULL" \
-           "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum" \
-           "TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum" \
-           "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCP_TCC_READ_REQ_LATENCY_sum" \
-           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE"; do
+for set in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS" \
+           "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU SQ_ACTIVE_INST_SCA" \
+           "TA_TA_BUSY_sum TA_BUSY_AVG TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum"; do
   i=$((i+1))
-  rm -rf /tmp/raw$i
-  rocprofv3 --pmc $set --output-format csv -d /tmp/raw$i -o r -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /tmp/log$i.txt 2>&1
-  python $R/tools/prof_summary.py /tmp/raw$i | grep -A12 "extend_filter_ctx_kernel" | head -14
+  rm -rf /tmp/pmc_raw
+  ( cd $R && timeout 600 rocprofv3 --pmc $set --output-format csv -d /tmp/pmc_raw -o r -- python bench.py --one-interval > $OUT/run$i.log 2>&1 )
+  python $R/tools/prof_summary.py /tmp/pmc_raw --out $OUT/pmc$i.txt
+  grep -A10 "extend_filter_ctx_kernel" $OUT/pmc$i.txt | head -11 > $OUT/ctx$i.txt
 done
+rm -rf /tmp/pmc_raw

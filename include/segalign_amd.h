@@ -106,7 +106,8 @@ void sa_free_segments(sa_segment_pair* p);
  * sa_free_segments); totals (optional) sums the per-call statistics.  Returns the number of HSPs. */
 /* Additive: up to sa_max_chunks_per_call() consecutive wga_chunk-sized chunks [start, start+chunk), ... of one strand in one
  * pass over the kernels.  outs[c] / counts[c] receive exactly what sa_seed_and_filter_range returns for chunk c (own
- * iteration plan, own dedup scope, own header; NULL / 0 for a chunk without seeds).  Returns the sum of the counts. */
+ * iteration plan, own dedup scope, own header; NULL / 0 for a chunk without seeds).  Only the slots of the chunks the range
+ * covers (ceil((end - start) / wga_chunk)) are written.  Returns the sum of the counts. */
 int sa_max_chunks_per_call(void);
 int sa_get_chunks_per_call(void);   /* chunks sa_seed_interval groups into one call (default = the maximum; env SEGALIGN_AMD_CHUNKS_PER_CALL) */
 size_t sa_seed_and_filter_chunks(uint32_t start, uint32_t end, int rev, uint32_t buffer, sa_segment_pair** outs, size_t* counts);

@@ -85,6 +85,14 @@ static inline uint8_t enc(char ch) {
         default: return ORC_X;
     }
 }
+/* team size of a parallel loop: never more threads than 4096-item blocks (a 256-thread fork/join per tiny test chunk costs
+ * more than the chunk) */
+static inline int orc_team(int want, uint64_t items) {
+    uint64_t blocks = (items + 4095) / 4096;
+    if (want < 1) want = 1;
+    if (blocks < 1) blocks = 1;
+    return blocks < (uint64_t)want ? (int)blocks : want;
+}
 static inline uint8_t comp_code(uint8_t c) { return c < 4 ? (uint8_t)(3 - c) : c; } /* :124-151, L/N/E/X keep */
 
 void orc_encode(const char* src, size_t len, uint8_t* dst) {
@@ -581,7 +589,7 @@ static size_t saf_impl(const orc_saf_params* p, const uint64_t* seeds, size_t nu
                 orc_segment* hsp = (orc_segment*)malloc((size_t)iter_num_hits * sizeof(orc_segment));
                 /* find_hits :184-230: k-th bucket entry of seed s -> slot prefix_incl[s]-1-k-start_hit */
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static, 4096) num_threads(p->num_threads > 0 ? p->num_threads : 1)
+#pragma omp parallel for schedule(static, 4096) num_threads(orc_team(p->num_threads, (uint64_t)(lp - start_seed_index + 1)))
 #endif
                 for (int64_t s = start_seed_index; s <= lp; s++) {
                     uint32_t seed = (uint32_t)(seeds[s] >> 32);
@@ -601,7 +609,7 @@ static size_t saf_impl(const orc_saf_params* p, const uint64_t* seeds, size_t nu
                 uint8_t* done = (uint8_t*)malloc((size_t)iter_num_hits);
                 uint64_t ex_local = 0;
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 4096) reduction(+ : ex_local) num_threads(p->num_threads > 0 ? p->num_threads : 1)
+#pragma omp parallel for schedule(dynamic, 4096) reduction(+ : ex_local) num_threads(orc_team(p->num_threads, iter_num_hits))
 #endif
                 for (int64_t h = 0; h < (int64_t)iter_num_hits; h++) {
                     orc_segment o;
@@ -619,7 +627,7 @@ static size_t saf_impl(const orc_saf_params* p, const uint64_t* seeds, size_t nu
                 /* inclusive_scan(done) :769 + compress_output :654-680 = order-preserving compaction */
                 size_t na = 0;
 #ifdef _OPENMP
-#pragma omp parallel for reduction(+ : na) num_threads(p->num_threads > 0 ? p->num_threads : 1)
+#pragma omp parallel for reduction(+ : na) num_threads(orc_team(p->num_threads, iter_num_hits >> 4))
 #endif
                 for (int64_t h = 0; h < (int64_t)iter_num_hits; h++) na += done[h];
                 survivors += na;

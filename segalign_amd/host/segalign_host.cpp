@@ -160,8 +160,9 @@ static void seed_interval(size_t q_block_start, uint32_t q_len /* block_len - se
             std::vector<size_t> n((size_t)kmax, 0);
             for (uint64_t i = a; i < b; i += (uint64_t)cfg.wga_chunk * kmax) {
                 const uint32_t e = (uint32_t)std::min<uint64_t>(i + (uint64_t)cfg.wga_chunk * kmax, b);
+                const int nc = (int)((e - i + cfg.wga_chunk - 1) / cfg.wga_chunk);  // chunks of THIS call: only their slots are written
                 sa_seed_and_filter_chunks((uint32_t)i, e, rev, buffer, res.data(), n.data());
-                for (int c = 0; c < kmax; c++) {
+                for (int c = 0; c < nc; c++) {
                     if (!n[c]) continue;
                     g_num_seed_hits += (uint32_t)res[c][0].score;
                     if (n[c] > 1) {

@@ -22,8 +22,9 @@ def make_records(seed, lens, sub=0.0, invert=False):
     return recs
 
 
-@pytest.mark.parametrize("host_seeding,threads", [(False, 4), (True, 2)])
-def test_host_harness_writes_the_reference_files(oracle, tmp_path, host_seeding, threads):
+@pytest.mark.parametrize("host_seeding,threads,chunk,block", [(False, 4, 20000, 60000), (True, 2, 20000, 60000),
+                                                              (False, 3, 2500, 10**6)])  # 18 chunks per interval: calls of 16 + 2
+def test_host_harness_writes_the_reference_files(oracle, tmp_path, host_seeding, threads, chunk, block):
     t_recs = make_records(100, [40000, 15000, 60000, 9000, 30000])
     q_recs = []
     for i, (name, s) in enumerate(t_recs[::-1]):
@@ -36,7 +37,7 @@ def test_host_harness_writes_the_reference_files(oracle, tmp_path, host_seeding,
     tf, qf = tmp_path / "target.fa", tmp_path / "query.fa"
     write_fasta(tf, t_recs)
     write_fasta(qf, q_recs, width=70)
-    params = dict(chunk=20000, interval=45000, seq_block_size=60000)  # several target blocks, query blocks, intervals
+    params = dict(chunk=chunk, interval=45000, seq_block_size=block)  # several target blocks, query blocks, intervals
     files, cmds = expected_outputs(oracle, [(n, s.tobytes()) for n, s in t_recs], [(n, s.tobytes()) for n, s in q_recs], **params)
     outdir = tmp_path / "out"
     outdir.mkdir()
@@ -52,4 +53,4 @@ def test_host_harness_writes_the_reference_files(oracle, tmp_path, host_seeding,
     for f in files:
         assert got[f] == files[f], f
     assert sorted(res.stdout.decode().strip().split("\n")) == sorted(cmds)
-    assert sum(1 for f in files if f.endswith(".segments")) >= 6 and any(".minus." in f for f in files)
+    assert sum(1 for f in files if f.endswith(".segments")) >= (6 if block < 10**6 else 2) and any(".minus." in f for f in files)

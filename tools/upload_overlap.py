@@ -52,6 +52,8 @@ def main():
     for line in res.stderr.decode().split("\n"):
         if line.startswith("Time elapsed") or line.startswith("#"):
             out.write("  " + line + "\n")
+    if res.returncode != 0:
+        out.write("stderr tail:\n" + "\n".join(res.stderr.decode(errors="replace").split("\n")[-25:]) + "\n")
     kern = []
     for f in glob.glob(os.path.join(raw, "**", "*kernel_trace.csv"), recursive=True):
         for row in csv.DictReader(open(f)):

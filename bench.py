@@ -480,15 +480,18 @@ def committed_profile(args, E):
     shape; (None, None, None) if there is none.  bench.py cannot run the PMC passes on itself (separate rocprofv3 runs,
     tools/profile_bench.sh), so measured HBM traffic comes from the committed collection and is only quoted while the
     collection matches the run: same workload key, and kernel durations that agree (profile_check)."""
+    other = None
     for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*")), reverse=True):
         tj, ks, wk = os.path.join(d, "traffic.json"), os.path.join(d, "kernel_stats.txt"), os.path.join(d, "workload.json")
         if not (os.path.exists(tj) and os.path.exists(ks)):
             continue
         try:
             key = json.load(open(wk)) if os.path.exists(wk) else {"workload": "ce11cb4", "target_mbp": 100.0, "chunk": 250000}
-            mine = {"workload": args.workload, "target_mbp": float(args.target_mbp or 100.0), "chunk": args.chunk}
+            mine = {"workload": args.workload, "chunk": args.chunk,
+                    "target_mbp": float(args.target_mbp or {"human": 500.0, "plumbing": 1.0}.get(args.workload, 100.0))}
             if any(key.get(k) != v for k, v in mine.items()) or args.target_fasta:
-                return None, os.path.relpath(tj, ROOT) + " (other workload: not quoted)", None
+                other = other or os.path.relpath(tj, ROOT) + " (other workload: not quoted)"
+                continue
             stats = {}
             for line in open(ks):
                 m = re.match(r"\s+(?:sa::)?(\w+).*calls=(\d+) total_us=([\d.]+) avg_us=([\d.]+)", line)
@@ -497,7 +500,7 @@ def committed_profile(args, E):
             return json.load(open(tj)), os.path.relpath(tj, ROOT), stats
         except Exception:
             continue
-    return None, None, None
+    return None, other, None
 
 
 def profile_check(prof, solo, kstats, args, scope_kernels=SCOPE_KERNELS):

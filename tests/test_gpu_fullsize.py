@@ -108,6 +108,31 @@ def test_one_full_chunk_bit_exact_vs_oracle(full, rev):
     assert got.shape == want.shape and np.all(got == want)
 
 
+def test_sixteen_chunk_calls_bit_exact_vs_oracle_at_full_size(full):
+    """Half an interval (20 chunks per strand = one 16-chunk call of ~200 M hits + one 4-chunk call) through sa_seed_interval,
+    every chunk against the oracle: the multi-chunk machinery (32 reference iterations in one pass, relative chain keys,
+    per-segment LDS chains, speculative output copy) at the workload's real hit density."""
+    E, O, query = full["E"], full["O"], full["query"]
+    index, pos = E.copy_index_table(), E.copy_pos_table()
+    rcodes = E.copy_ref_codes()
+    qlen = query.size - 19
+    iv = (40_000_000, 45_000_000)
+    fw, rc, st = E.SeedInterval(iv[0], iv[1], qlen, E.STRAND_BOTH, 0, 2)
+    hits = 0
+    for rev, got in ((False, fw), (True, rc)):
+        qcodes = E.copy_query_codes(0, rev)
+        buf = query if not rev else np.frombuffer(O.rev_comp_ascii(query.tobytes(), 0, query.size), dtype=np.uint8)
+        want = []
+        for (a, b) in shard.chunks_of(iv, 250000, qlen, rev):
+            seeds = O.make_seeds(buf.tobytes(), 0, a, b, 19, full["k"], True)
+            w, ost = O.seed_and_filter(rcodes, qcodes, index, pos, seeds, full["sub_mat"])
+            want.append(w[1:])
+            hits += ost["num_hits"]
+        want = np.concatenate(want)
+        assert got.shape == want.shape and np.all(got == want), rev
+    assert st["num_hits"] == hits and hits > 400_000_000 and fw.size + rc.size > 500
+
+
 # ---- BASELINE configs[3]: repeat-masker path on the same 100 Mbp target (self-alignment, neighbor_proportion 0.2, M 1) ----
 @pytest.fixture(scope="module")
 def full_rm(full):

@@ -322,7 +322,7 @@ static int g_long_cap = 128;      // SEGALIGN_AMD_LONG_CAP: bases per side befor
 static int g_long_blocks = 1792;  // SEGALIGN_AMD_LONG_BLOCKS: grid of the long kernel (4 waves per block)
 static int g_packed_waves = 4096; // SEGALIGN_AMD_PACKED_WAVES: waves of the packed filter (2 workgroups of 8 waves per CU measured best: 3072 +16 %, 6144 +20 %, 8192 +14 %)
 static int g_ctx_waves = 0;       // SEGALIGN_AMD_CTX_WAVES: wave budget of the context filter; 0 = one 4096-hit chunk per wave (measured best)
-static int g_ctx_pipe = 1;        // SEGALIGN_AMD_CTX_PIPE: 1 = no prefetch, 53 VGPRs (measured best by 1-3 %), 2 = ping-pong prefetch, 3 = records only
+static int g_ctx_pipe = 1;        // SEGALIGN_AMD_CTX_PIPE: 1 = no prefetch, 53 VGPRs (measured best by 1-3 %), 2 = ping-pong prefetch
 static int g_ctx_threads = 0;     // SEGALIGN_AMD_CTX_THREADS: workgroup size of the context filter (0 = kernel default)
 static int g_dedup_threads = 0;   // SEGALIGN_AMD_DEDUP_THREADS: workgroup size of the per-segment LDS chain (0 = 1024)
 static int g_spec_dedup = 1;      // SEGALIGN_AMD_SPEC_DEDUP=0: wait for the survivor count before the LDS chain (one more host sync)

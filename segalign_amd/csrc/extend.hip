@@ -832,9 +832,10 @@ __device__ __forceinline__ void ctx_step16(const uint32_t* __restrict__ s_tab, u
 // whole bench (tools/sweep_threads.sh)
 constexpr int CTX_THREADS = 512;      // default; ExtendArgs::ctx_threads (SEGALIGN_AMD_CTX_THREADS) overrides it per launch
 constexpr int CTX_THREADS_MAX = 1024;
-// PIPE: how a wave covers the latency of its stream.  2 = records + query windows of buffer b + 1 requested before buffer b is
-// scored (two full register sets, 77 VGPRs, 6 waves per SIMD); 1 = no prefetch, 53 VGPRs, 8 waves per SIMD; 3 = only the
-// records of b + 1 are prefetched (the query windows are L1 / L2 hits), <= 64 VGPRs, 8 waves per SIMD
+// PIPE: how a wave covers the latency of its stream.  1 (default) = no prefetch, 53 VGPRs, up to 8 waves per SIMD; 2 = records +
+// query windows of buffer b + 1 requested before buffer b is scored (two full register sets, 77 VGPRs, 6 waves per SIMD).
+// Measured within 2 % of each other (tools/sweep_pipe.sh; a third variant that prefetched only the records spilled and lost
+// 25 %): the kernel is not waiting for its stream, see DESIGN.md 4.5a
 template <int PIPE>
 __global__ __launch_bounds__(CTX_THREADS_MAX, PIPE == 2 ? 4 : 8) void extend_filter_ctx_kernel(ExtendArgs a) {
     __shared__ uint32_t s_pk[2 * PK_TAB];  // 8-byte entries {sum, max prefix} (32 KB)
@@ -953,16 +954,6 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, PIPE == 2 ? 4 : 8) void extend_fil
             score(b, A);
             request_ctx(b + 2, A);
             request_query(b + 2, A);
-            if (b + 1 < b_hi) score(b + 1, B);
-        }
-    } else if (PIPE == 3) {
-        request_ctx(b_lo, A);
-        for (uint64_t b = b_lo; b < b_hi; b += 2) {
-            request_query(b, A);
-            request_ctx(b + 1, B);
-            score(b, A);
-            request_query(b + 1, B);
-            request_ctx(b + 2, A);
             if (b + 1 < b_hi) score(b + 1, B);
         }
     } else {
@@ -1412,7 +1403,6 @@ void launch_extend_filter_ctx(const ExtendArgs& a, hipStream_t s) {
     const uint32_t blocks = (uint32_t)((waves + wpb - 1) / wpb);
     const size_t lds = wpb * STAGE_CAP * sizeof(CandRec);
     if (a.ctx_pipe == 2) hipLaunchKernelGGL(extend_filter_ctx_kernel<2>, dim3(blocks), dim3(threads), lds, s, a);
-    else if (a.ctx_pipe == 3) hipLaunchKernelGGL(extend_filter_ctx_kernel<3>, dim3(blocks), dim3(threads), lds, s, a);
     else hipLaunchKernelGGL(extend_filter_ctx_kernel<1>, dim3(blocks), dim3(threads), lds, s, a);
 }
 

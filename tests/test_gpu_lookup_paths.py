@@ -81,6 +81,39 @@ def test_lookup_paths_under_a_max_hits_split(oracle, clean, mode, env):
     c.E.set_max_hits(0)
 
 
+def test_multi_chunk_call_with_empty_chunks_and_a_max_hits_split(oracle, clean):
+    """One 16-chunk call whose chunks are not alike: chunks without a single seed (runs of N: NULL / 0 in their slots, no header),
+    a soft-masked chunk, and -- second pass -- a MAX_HITS low enough that one chunk needs more than two reference iterations,
+    which sends the WHOLE call down the general path (per-seed-word prefixes, batches of <= 8 iterations).  Every slot must equal
+    the single-chunk call and the oracle."""
+    with_env({})
+    t, q = synth.make_pair(300000, 61, 62, sub_rate=0.08, mask_frac=0.1, records=2, indel_every=600)
+    q = q.copy()
+    chunk = 20000
+    q[3 * chunk:5 * chunk] = ord("N")                      # chunks 3, 4: no seeds at all
+    q[9 * chunk:10 * chunk] = np.frombuffer(bytes(q[9 * chunk:10 * chunk]).lower(), dtype=np.uint8)  # chunk 9: soft-masked
+    c = Case(t, q, chunk=chunk).oracle_setup(oracle).engine_setup(clean)
+    E = c.E
+    ch = c.chunks()
+    assert len(ch) >= 15
+    for mh in (1 << 30, 6000):
+        E.set_max_hits(mh)
+        for rev in (False, True):
+            wants = [c.oracle_saf(c.host_seeds(s, e, rev), rev, max_hits=mh)[0] if c.host_seeds(s, e, rev).size else None for (s, e) in ch]
+            k = min(len(ch), 16)
+            outs = E.SeedAndFilterChunks(ch[0][0], ch[k - 1][1], rev, 0)
+            n_empty = 0
+            for j in range(k):
+                if wants[j] is None:
+                    assert outs[j].size == 0, (mh, rev, j)
+                    n_empty += 1
+                else:
+                    assert seg_equal(outs[j], wants[j]), (mh, rev, j)
+                    assert seg_equal(E.SeedAndFilterRange(ch[j][0], ch[j][1], rev, 0), wants[j]), (mh, rev, j)
+            assert n_empty >= 2 or rev  # (the N run lies elsewhere on the minus strand's chunk grid)
+    E.set_max_hits(0)
+
+
 @pytest.mark.parametrize("mode,env", MODES)
 def test_lookup_paths_repeat_masker(oracle, clean, mode, env):
     with_env(env)

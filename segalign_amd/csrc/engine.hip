@@ -919,7 +919,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
     t_stats.num_hits = num_hits;
     t_stats.num_survivors = survivors;
     t_stats.num_anchors = n_final;
-    if (K > 1) {
+    if (K > 1 && ca.outs) {
         // ---- one return vector per chunk: records are ordered by segment, chunk c owns segments
         //      [chunk_first_seg[c], chunk_first_seg[c+1]) ; a chunk without seeds returns nothing (seeder.cpp:76) ----
         size_t pos = 0;
@@ -1938,34 +1938,61 @@ size_t sa_rm_mask_interval(uint32_t start_pos, uint32_t end_pos, uint32_t ref_st
     const uint32_t lim = block_len >= g_seed_size ? block_len - g_seed_size + 1 : 0;
     const uint32_t end_pos_rc = block_len - 1 - start_pos;  // seeder.cpp:46-47
     uint64_t tot_seeds = 0, tot_hits = 0, tot_hsps = 0;
-    for (uint64_t i = start_pos; i < end_pos; i += g_wga_chunk) {  // :73
-        const uint32_t start = (uint32_t)i;
-        const uint32_t end = (uint32_t)std::min<uint64_t>(i + g_wga_chunk, end_pos);  // :76-77
-        for (int rev = 0; rev < 2; rev++) {
-            if (!(strands & (rev ? SA_STRAND_MINUS : SA_STRAND_PLUS))) continue;
+    // The reference walks the plus-strand chunks and derives a minus-strand chunk from each (:73-150).  Coverage counting is
+    // order independent and every chunk keeps its own iteration plan and dedup scope, so the chunks of a strand are grouped:
+    // consecutive chunks that tile a range go through ONE table-direct pass (up to g_chunks_per_call of them), the rest --
+    // the minus-strand chunk of a short last plus chunk overlaps its neighbour (:118-119) -- go on their own.
+    struct Range { uint32_t s0, s1; };
+    for (int rev = 0; rev < 2; rev++) {
+        if (!(strands & (rev ? SA_STRAND_MINUS : SA_STRAND_PLUS))) continue;
+        std::vector<Range> rs;
+        for (uint64_t i = start_pos; i < end_pos; i += g_wga_chunk) {  // :73
+            const uint32_t start = (uint32_t)i;
+            const uint32_t end = (uint32_t)std::min<uint64_t>(i + g_wga_chunk, end_pos);  // :76-77
             uint32_t s0 = start, s1 = end;
             if (rev) {  // :118-119: the minus-strand chunk is derived from the plus-strand chunk END
                 s0 = block_len - 1 - end;
                 s1 = (uint32_t)std::min<uint64_t>((uint64_t)s0 + g_wga_chunk, end_pos_rc);
             }
             if (s1 > lim) s1 = lim;
-            const uint8_t* q = rev ? dc->ref_rc.codes : dc->ref.codes;
-            const PackedBuf* q4 = rev ? &dc->ref4_rc : &dc->ref4;
+            if (s1 > s0) rs.push_back({s0, s1});
+        }
+        if (rev) std::reverse(rs.begin(), rs.end());  // ascending positions
+        const uint8_t* q = rev ? dc->ref_rc.codes : dc->ref.codes;
+        const PackedBuf* q4 = rev ? &dc->ref4_rc : &dc->ref4;
+        const bool td_ok = td_eligible(dc, q4);
+        size_t a = 0;
+        while (a < rs.size()) {
+            size_t b = a + 1;
+            while (td_ok && b < rs.size() && (int)(b - a) < g_chunks_per_call && rs[b].s0 == rs[b - 1].s1) b++;
+            int Kc = (int)(b - a);
+            uint32_t bp[SA_MAX_CHUNKS + 1];
+            for (int c = 0; c < Kc; c++) bp[c] = rs[a + c].s0;
+            bp[Kc] = rs[b - 1].s1;
             uint32_t ns = 0xFFFFFFFFu, words = 0;
-            if (td_eligible(dc, q4)) {
-                const uint32_t bp[2] = {s0, std::max(s0, s1)};
+            if (td_ok) ns = td_front(dc, sl, q, Kc, bp, 1, &words);
+            if (ns == 0xFFFFFFFFu && Kc > 1) {  // one of the chunks needs the general path (MAX_HITS): one chunk per call
+                b = a + 1;
+                Kc = 1;
+                bp[1] = rs[a].s1;
                 ns = td_front(dc, sl, q, 1, bp, 1, &words);
             }
             const bool td = ns != 0xFFFFFFFFu;
-            if (!td) ns = device_seeds(sl, q, s0, s1);
-            if (ns == 0) continue;  // :103,140
-            CoreArgs ca = {q, block_len, 1, rev, ref_start, ref_end, s0, s1, sl->cov_diff.p, block_len + 1, q4};
-            ca.td = td ? 1 : 0;
-            ca.td_words = words;
-            saf_core(dc, sl, ns, ca, nullptr);
-            tot_seeds += ns;
-            tot_hits += t_stats.num_hits;
-            tot_hsps += t_stats.num_anchors;
+            if (!td) ns = device_seeds(sl, q, rs[a].s0, rs[a].s1);
+            if (ns != 0) {  // :103,140
+                CoreArgs ca = {q, block_len, 1, rev, ref_start, ref_end, bp[0], bp[Kc], sl->cov_diff.p, block_len + 1, q4};
+                ca.td = td ? 1 : 0;
+                ca.td_words = words;
+                if (Kc > 1) {
+                    ca.nchunks = Kc;
+                    for (int c = 0; c <= Kc; c++) ca.seed_bound[c] = 0u;  // (a table-direct call derives them from its chunk plans)
+                }
+                saf_core(dc, sl, ns, ca, nullptr);
+                tot_seeds += ns;
+                tot_hits += t_stats.num_hits;
+                tot_hsps += t_stats.num_anchors;
+            }
+            a = b;
         }
     }
     const size_t n = coverage_finish(sl, block_len, M, tot_hsps, out);

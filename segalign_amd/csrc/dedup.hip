@@ -226,7 +226,8 @@ __device__ __forceinline__ void bitonic_sort_lds(HspRec* __restrict__ a, uint32_
 }
 
 __global__ __launch_bounds__(DEDUP_SEG_THREADS) void dedup_seg_kernel(const HspRec* __restrict__ in, uint32_t n, const uint32_t* __restrict__ n_dev,
-                                                                      uint4* __restrict__ out, uint32_t* __restrict__ seg_info /* [2 * SEGS + 1] */) {
+                                                                      uint4* __restrict__ out, uint32_t* __restrict__ seg_info /* [2 * SEGS + 1] */,
+                                                                      uint32_t seg_max /* <= DEDUP_SEG_MAX */) {
     if (n_dev) {  // speculative launch: the survivor count is still on the device
         n = *n_dev;
         if (n > (uint32_t)DEDUP_SEG_TOTAL) {
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(DEDUP_SEG_THREADS) void dedup_seg_kernel(const HspR
     uint32_t off = 0;
     for (uint32_t t = 0; t < g; t++) off += s_cnt[t];
     const uint32_t m = s_m;
-    if (m > DEDUP_SEG_MAX) {  // the host falls back to the library sorts
+    if (m > seg_max) {  // the host falls back to the library sorts
         if (threadIdx.x == 0) { seg_info[2 * DEDUP_SMALL_SEGS] = 1u; seg_info[g] = 0; seg_info[DEDUP_SMALL_SEGS + g] = off; }
         return;
     }
@@ -302,10 +303,12 @@ uint32_t dedup_seg_info_words() { return 2 * DEDUP_SMALL_SEGS + 1; }
 // a segment held more than DEDUP_SEG_MAX records (nothing usable was written); must be zero on entry
 // threads: workgroup size (0 = DEDUP_SEG_THREADS)
 // n_dev != nullptr: the number of records is read from the device (n ignored); more than dedup_seg_max_total() sets the flag
+// seg_max: records per segment the LDS path accepts (0 = DEDUP_SEG_MAX; tests lower it to reach the fallback)
 void launch_dedup_seg(const HspRec* in, uint32_t n, const uint32_t* n_dev, uint32_t nsegs, void* out_segment_pairs, uint32_t* seg_info,
-                      uint32_t threads, hipStream_t s) {
+                      uint32_t threads, uint32_t seg_max, hipStream_t s) {
+    seg_max = seg_max ? std::min<uint32_t>(seg_max, DEDUP_SEG_MAX) : (uint32_t)DEDUP_SEG_MAX;
     threads = threads ? std::min<uint32_t>(DEDUP_SEG_THREADS, std::max<uint32_t>(64, threads & ~63u)) : (uint32_t)DEDUP_SEG_THREADS;
-    hipLaunchKernelGGL(dedup_seg_kernel, dim3(nsegs), dim3(threads), 0, s, in, n, n_dev, reinterpret_cast<uint4*>(out_segment_pairs), seg_info);
+    hipLaunchKernelGGL(dedup_seg_kernel, dim3(nsegs), dim3(threads), 0, s, in, n, n_dev, reinterpret_cast<uint4*>(out_segment_pairs), seg_info, seg_max);
 }
 
 uint32_t dedup_small_max_segs() { return DEDUP_SMALL_SEGS; }

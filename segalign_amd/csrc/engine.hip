@@ -196,7 +196,8 @@ static int prof_id(const char* name) {
 // per-device state
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int MAX_SLOTS_PER_DEVICE = 4;
-constexpr uint32_t SPEC_RECS = 16384; // records of the speculative output copy (256 KB = everything the LDS chain can deliver)
+static uint32_t SPEC_RECS = 16384;    // records of the speculative output copy (256 KB); SEGALIGN_AMD_SPEC_RECS (tests)
+static uint32_t g_dedup_seg_max = 0;   // SEGALIGN_AMD_DEDUP_SEG_MAX: records per segment the LDS chain accepts (0 = its LDS capacity; tests)
 constexpr int SA_MAX_CHUNKS = 16;  // chunks one multi-chunk call may carry: 2 reference iterations each = MAX_SEGS segments
 static int SLOTS_PER_DEVICE = 2;  // calls in flight per device (the reference allows one: token == device); SEGALIGN_AMD_SLOTS
 
@@ -761,7 +762,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                         ensure_host_out(dedup_seg_max_total());
                         ensure_host_seg(std::max<size_t>(dedup_seg_max_total(), seg_words));
                         check_memcpy(hipMemsetAsync(sl->d_seg_info, 0, seg_words * sizeof(uint32_t), st), "segment info");
-                        { ProfScope p(sl, "dedup_seg"); launch_dedup_seg(ea.out, 0, &sl->d_cnt->survivors, (uint32_t)segs.size(), sl->out16.p, sl->d_seg_info, (uint32_t)g_dedup_threads, st); }
+                        { ProfScope p(sl, "dedup_seg"); launch_dedup_seg(ea.out, 0, &sl->d_cnt->survivors, (uint32_t)segs.size(), sl->out16.p, sl->d_seg_info, (uint32_t)g_dedup_threads, g_dedup_seg_max, st); }
                         check_launch("dedup seg");
                         check_memcpy(hipMemcpyAsync(sl->h_seg_info, sl->d_seg_info, seg_words * sizeof(uint32_t), hipMemcpyDeviceToHost, st), "segment info");
                         check_memcpy(hipMemcpyAsync(sl->h_out, sl->out16.p, (size_t)SPEC_RECS * sizeof(sa_segment_pair), hipMemcpyDeviceToHost, st),
@@ -844,7 +845,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     ensure_host_out(survivors);
                     ensure_host_seg(std::max<size_t>(survivors, words));
                     check_memcpy(hipMemsetAsync(sl->d_seg_info, 0, words * sizeof(uint32_t), st), "segment info");
-                    { ProfScope p(sl, "dedup_seg"); launch_dedup_seg(sl->recA.p, survivors, nullptr, (uint32_t)segs.size(), sl->out16.p, sl->d_seg_info, (uint32_t)g_dedup_threads, st); }
+                    { ProfScope p(sl, "dedup_seg"); launch_dedup_seg(sl->recA.p, survivors, nullptr, (uint32_t)segs.size(), sl->out16.p, sl->d_seg_info, (uint32_t)g_dedup_threads, g_dedup_seg_max, st); }
                     check_launch("dedup seg");
                     check_memcpy(hipMemcpyAsync(sl->h_seg_info, sl->d_seg_info, words * sizeof(uint32_t), hipMemcpyDeviceToHost, st), "segment info");
                     check_memcpy(hipMemcpyAsync(sl->h_out, sl->out16.p, (size_t)survivors * sizeof(sa_segment_pair),
@@ -1299,9 +1300,15 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
     if (const char* e = getenv("SEGALIGN_AMD_PACKED_WAVES")) g_packed_waves = std::max(8, atoi(e));
     if (const char* e = getenv("SEGALIGN_AMD_L2_BLOCKS")) g_l2_blocks = std::max(1, atoi(e));
     if (const char* e = getenv("SEGALIGN_AMD_CTX_WAVES")) g_ctx_waves = std::max(0, atoi(e));
+    g_ctx_pipe = 1;
     if (const char* e = getenv("SEGALIGN_AMD_CTX_PIPE")) g_ctx_pipe = atoi(e);
     if (const char* e = getenv("SEGALIGN_AMD_CTX_THREADS")) g_ctx_threads = std::max(0, atoi(e));
+    g_spec_dedup = 1;
     if (const char* e = getenv("SEGALIGN_AMD_SPEC_DEDUP")) g_spec_dedup = atoi(e) != 0;
+    SPEC_RECS = 16384;
+    if (const char* e = getenv("SEGALIGN_AMD_SPEC_RECS")) SPEC_RECS = (uint32_t)std::max(1, std::min(16384, atoi(e)));
+    g_dedup_seg_max = 0;
+    if (const char* e = getenv("SEGALIGN_AMD_DEDUP_SEG_MAX")) g_dedup_seg_max = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("SEGALIGN_AMD_DEDUP_THREADS")) g_dedup_threads = std::max(0, atoi(e));
     if (xdrop >= (1 << 25) || xdrop <= -(1 << 25)) {
         fprintf(stderr, "Error: |xdrop| must be below 2^25\n");

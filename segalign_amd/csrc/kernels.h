@@ -210,7 +210,7 @@ uint32_t dedup_small_max_segs();
 uint32_t dedup_seg_max_total();
 uint32_t dedup_seg_info_words();
 void launch_dedup_seg(const HspRec* in, uint32_t n, const uint32_t* n_dev, uint32_t nsegs, void* out_segment_pairs, uint32_t* seg_info,
-                      uint32_t threads, hipStream_t s);
+                      uint32_t threads, uint32_t seg_max, hipStream_t s);
 
 // ---- coverage.hip (repeat-masker post-processing, repeat_masker_src/seeder.cpp:153-188) ------------------------
 struct SegPair16 { uint32_t ref_start, query_start, len; int32_t score; };  // layout of sa_segment_pair / segmentPair

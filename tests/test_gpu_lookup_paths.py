@@ -18,7 +18,8 @@ MODES = [(2, {}), (1, {"SEGALIGN_AMD_NO_CTX": "1"}), (0, {"SEGALIGN_AMD_NO_TD": 
 
 
 def with_env(env):
-    for k in ("SEGALIGN_AMD_NO_CTX", "SEGALIGN_AMD_NO_TD"):
+    for k in ("SEGALIGN_AMD_NO_CTX", "SEGALIGN_AMD_NO_TD", "SEGALIGN_AMD_SPEC_RECS", "SEGALIGN_AMD_DEDUP_SEG_MAX",
+              "SEGALIGN_AMD_SPEC_DEDUP", "SEGALIGN_AMD_NO_SMALL_DEDUP", "SEGALIGN_AMD_CTX_PIPE"):
         os.environ.pop(k, None)
     os.environ.update(env)
 
@@ -79,6 +80,30 @@ def test_lookup_paths_under_a_max_hits_split(oracle, clean, mode, env):
                 want, st = c.oracle_saf(c.host_seeds(s, e, rev), rev, max_hits=mh)
                 assert seg_equal(c.E.SeedAndFilterRange(s, e, rev, 0), want), (mode, mh, rev, s, e)
     c.E.set_max_hits(0)
+
+
+@pytest.mark.parametrize("env", [{"SEGALIGN_AMD_SPEC_RECS": "8"},        # most records travel in the second copy
+                                 {"SEGALIGN_AMD_DEDUP_SEG_MAX": "4"},     # a segment too large for the LDS chain: library sorts
+                                 {"SEGALIGN_AMD_SPEC_DEDUP": "0"},        # chain launched after the survivor count is known
+                                 {"SEGALIGN_AMD_NO_SMALL_DEDUP": "1"},    # library sorts only
+                                 {"SEGALIGN_AMD_CTX_PIPE": "2"}])         # the prefetching variant of the context filter
+def test_every_output_path_of_a_multi_chunk_call(oracle, clean, env):
+    """The ways the survivors of a call can reach the host -- speculative LDS chain with one or two copies, the same chain after
+    a sync, the library-sort fallback -- must all give the oracle's vectors."""
+    with_env(env)
+    t, q = synth.make_pair(200000, 71, 72, sub_rate=0.08, mask_frac=0.1, records=2, indel_every=500)
+    c = Case(t, q, chunk=12000).oracle_setup(oracle).engine_setup(clean)
+    ch = c.chunks()
+    assert len(ch) == 17
+    total = 0
+    for rev in (False, True):
+        wants = [c.oracle_saf(c.host_seeds(s, e, rev), rev)[0] for (s, e) in ch]
+        outs = c.E.SeedAndFilterChunks(ch[0][0], ch[15][1], rev, 0)
+        for j in range(16):
+            assert seg_equal(outs[j], wants[j]), (env, rev, j)
+            total += outs[j].size - 1
+        assert seg_equal(c.E.SeedAndFilterRange(ch[16][0], ch[16][1], rev, 0), wants[16]), (env, rev)
+    assert total > 64
 
 
 def test_multi_chunk_call_with_empty_chunks_and_a_max_hits_split(oracle, clean):

@@ -140,6 +140,40 @@ def test_multi_chunk_call_with_empty_chunks_and_a_max_hits_split(oracle, clean):
 
 
 @pytest.mark.parametrize("mode,env", MODES)
+def test_low_complexity_mega_buckets(oracle, clean, mode, env):
+    """Unmasked low-complexity sequence: a 3 kb poly-A run and a 1.5 kb (CT)n microsatellite in the target put thousands of
+    positions into single buckets; the query's own runs then produce ~10^6 hits from a few hundred positions, thousands of
+    diagonals whose candidates all extend to overlapping HSPs (chain shortcut, > 2048 survivors in one dedup segment ->
+    library-sort fallback), a record of the probe that spans many 64-hit buffers, and scores far above 3*hspthresh."""
+    with_env(env)
+    rng = np.random.default_rng(91)
+    t, q = synth.make_pair(120000, 91, 92, sub_rate=0.08, mask_frac=0.05, records=2, indel_every=700)
+    t, q = t.copy(), q.copy()
+    t[20000:23000] = ord("A")
+    t[70000:71500] = np.tile(np.frombuffer(b"CT", dtype=np.uint8), 750)
+    q[50000:50400] = ord("A")
+    q[50150] = ord("G")                                   # one transition inside the run
+    q[90000:90300] = np.tile(np.frombuffer(b"CT", dtype=np.uint8), 150)
+    c = Case(t, q, chunk=30000).oracle_setup(oracle).engine_setup(clean)
+    E = c.E
+    assert E.lookup_mode() == mode
+    hits = 0
+    for rev in (False, True):
+        wants = []
+        for (s, e) in c.chunks():
+            want, st = c.oracle_saf(c.host_seeds(s, e, rev), rev)
+            assert seg_equal(E.SeedAndFilterRange(s, e, rev, 0), want), (mode, rev, s, e)
+            assert E.last_call_stats()["num_hits"] == st["num_hits"]
+            hits = max(hits, st["num_hits"])
+            wants.append(want)
+        ch = c.chunks()
+        outs = E.SeedAndFilterChunks(ch[0][0], ch[-1][1], rev, 0)
+        for j, w in enumerate(wants):
+            assert seg_equal(outs[j], w), (mode, rev, j)
+    assert hits > 1_000_000
+
+
+@pytest.mark.parametrize("mode,env", MODES)
 def test_lookup_paths_repeat_masker(oracle, clean, mode, env):
     with_env(env)
     unit = synth.random_dna(600, 77)

@@ -23,10 +23,10 @@ def human_block(oracle, engine):
     per = TLEN // 4
     target = synth.join_records([t[i * per:(i + 1) * per] for i in range(4)])
     del t
-    # query block: 1 Mbp of 1.2 %-diverged pieces of distant target regions, every third one inverted (block shuffles)
+    # query block: 4 Mbp of 1.2 %-diverged pieces of distant target regions, every third one inverted (block shuffles)
     rng = np.random.default_rng(7)
     pieces = []
-    for i in range(4):
+    for i in range(16):
         p = int(rng.integers(0, target.size - 300000))
         seg = synth.mutate(target[p:p + 250000].copy(), 100 + i, 0.012, indel_every=900)
         pieces.append(synth.reverse_complement(seg) if i % 3 == 0 else seg)
@@ -95,3 +95,23 @@ def test_configs2_block_chunks_bit_exact_vs_oracle(human_block, rev):
     outs = E.SeedAndFilterChunks(0, 500000, rev, 0)
     assert np.array_equal(outs[0], E.SeedAndFilterRange(0, 250000, rev, 0))
     assert np.array_equal(outs[1], E.SeedAndFilterRange(250000, 500000, rev, 0))
+
+
+def test_configs2_block_sixteen_chunk_call_bit_exact_vs_oracle(human_block):
+    """ONE call over sixteen chunks of the plus strand at human-scale hit density (~0.5 G hits, > 1 M chain candidates, tens
+    of thousands of survivors in 32 dedup segments): every chunk's vector against the oracle."""
+    E, O, query = human_block["E"], human_block["O"], human_block["query"]
+    qcodes = E.copy_query_codes(0, False)
+    end_pos = query.size - 19
+    assert end_pos > 15 * 250000
+    outs = E.SeedAndFilterChunks(0, min(16 * 250000, end_pos), False, 0)
+    st_call = E.last_call_stats()
+    hits = 0
+    for c in range(16):
+        a, b = c * 250000, min((c + 1) * 250000, end_pos)
+        seeds = O.make_seeds(query.tobytes(), 0, a, b, 19, human_block["k"], True)
+        want, st = O.seed_and_filter(human_block["rcodes"], qcodes, human_block["index"], human_block["pos"], seeds,
+                                     human_block["sub_mat"])
+        assert outs[c].shape == want.shape and np.all(outs[c] == want), (c, outs[c][:3], want[:3])
+        hits += st["num_hits"]
+    assert st_call["num_hits"] == hits and hits > 400_000_000

@@ -212,6 +212,8 @@ struct Counters {  // device-side scalars of one slot
     uint32_t n_ent;   // entropy candidates (this batch)
     uint32_t n_heads; // run heads of the chain shortcut (this batch)
     uint32_t n_l2;    // hits the context filter handed to the second level (this batch)
+    uint32_t n_l2_max;  // largest sub-list of them (compared with the sub-list capacity)
+    uint32_t pad2[3];
 };
 
 struct Slot {
@@ -223,7 +225,9 @@ struct Slot {
     DevBuf<uint8_t> scan_temp, sort_temp;
     DevBuf<Hit> hits;
     DevBuf<HspRec> recA, recB;
-    DevBuf<CandRec> cand_list, l2_list;
+    DevBuf<CandRec> cand_list;
+    DevBuf<L2Rec> l2_list;
+    DevBuf<uint32_t> l2_counts, l2_prefix;  // sub-list counters (one 128-byte line each) and their prefix
     DevBuf<CandRec> chain_tmp, chain_sorted;  // chain shortcut of the exact stage
     DevBuf<uint32_t> chain_is_head, chain_heads, chain_bucket_cnt, chain_bucket_start;
     DevBuf<EntRec> ent_list;
@@ -327,7 +331,7 @@ static int g_ctx_pipe = 1;        // SEGALIGN_AMD_CTX_PIPE: 1 = no prefetch, 53 
 static int g_ctx_threads = 0;     // SEGALIGN_AMD_CTX_THREADS: workgroup size of the context filter (0 = kernel default)
 static int g_dedup_threads = 0;   // SEGALIGN_AMD_DEDUP_THREADS: workgroup size of the per-segment LDS chain (0 = 1024)
 static int g_spec_dedup = 1;      // SEGALIGN_AMD_SPEC_DEDUP=0: wait for the survivor count before the LDS chain (one more host sync)
-static int g_l2_blocks = 256;     // SEGALIGN_AMD_L2_BLOCKS: workgroups of the second-level packed filter
+static int g_l2_blocks = 512;     // SEGALIGN_AMD_L2_BLOCKS: workgroups of the second-level packed filter
 static int g_max_waves = 4096;    // SEGALIGN_AMD_MAX_WAVES: waves of the filter kernel (4 per SIMD saturate instruction issue)
 static int g_fast_filter = 0;     // derived in InitializeProcessor: xdrop >= 0 && 7*max(M) <= xdrop
 static int g_packed_filter = 0;   // derived in InitializeProcessor: the packed upper-bound filter may be used
@@ -435,6 +439,8 @@ static void slot_destroy(Slot& s) {
     s.out16.release("out16");
     s.cand_list.release("candidate list");
     s.l2_list.release("second-level list");
+    s.l2_counts.release("second-level counters");
+    s.l2_prefix.release("second-level prefix");
     s.chain_tmp.release("chain"); s.chain_sorted.release("chain"); s.chain_is_head.release("chain");
     s.chain_heads.release("chain"); s.chain_bucket_cnt.release("chain"); s.chain_bucket_start.release("chain"); s.ent_list.release("entropy list");
     s.cov_diff.release("coverage"); s.cov_pre.release("coverage"); s.cov_is_start.release("coverage");
@@ -642,8 +648,15 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     ea.td_pos = dc->nbr_pos;
                     ea.td_ctx = dc->nbr_ctx;
                     ea.seed_size = g_seed_size;
-                    if (ea.td_ctx) sl->l2_list.ensure((size_t)std::max<uint64_t>(1u << 16, bh / 8), "second-level list");
-                    ea.l2_count = &sl->d_cnt->n_l2;
+                    if (ea.td_ctx) {
+                        sl->l2_list.ensure((size_t)std::max<uint64_t>((uint64_t)L2_NSUB * TD_CHUNK_HITS, bh / 8), "second-level list");  // (a sub-list can take a whole chunk)
+                        sl->l2_counts.ensure((size_t)L2_NSUB * L2_CNT_STRIDE, "second-level counters");
+                        sl->l2_prefix.ensure((size_t)L2_NSUB + 1, "second-level prefix");
+                    }
+                    ea.l2_count = sl->l2_counts.p;
+                    ea.l2_prefix = sl->l2_prefix.p;
+                    ea.l2_total = &sl->d_cnt->n_l2;
+                    ea.l2_max = &sl->d_cnt->n_l2_max;
                     ea.l2_blocks = (uint32_t)g_l2_blocks;
                     ea.ctx_waves = (uint32_t)g_ctx_waves;
                     ea.ctx_threads = (uint32_t)g_ctx_threads;
@@ -720,7 +733,9 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                 before.n_long = 0;
                 before.n_ent = 0;
                 before.n_heads = 0;
-                check_memcpy(hipMemsetAsync(&sl->d_cnt->n_long, 0, 4 * sizeof(uint32_t), st), "counters");
+                before.n_l2 = 0;
+                before.n_l2_max = 0;
+                check_memcpy(hipMemsetAsync(&sl->d_cnt->n_long, 0, 5 * sizeof(uint32_t), st), "counters");
                 for (;;) {  // rerun the batch with larger lists if one overflowed (device writes are guarded)
                     ea.out = sl->recA.p;
                     ea.out_cap = (uint32_t)std::min<size_t>(sl->recA.cap, 0xFFFFFFFFu);
@@ -731,7 +746,8 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     if (ea.td && ea.td_ctx) {
                         // context filter over the table's own 32-byte records, then the packed filter on what it could not decide
                         ea.l2_list = sl->l2_list.p;
-                        ea.l2_cap = (uint32_t)std::min<size_t>(sl->l2_list.cap, 0xFFFFFFFFu);
+                        ea.l2_cap = (uint32_t)std::min<size_t>(sl->l2_list.cap / L2_NSUB, 0xFFFFFFu);  // per sub-list
+                        check_memcpy(hipMemsetAsync(sl->l2_counts.p, 0, (size_t)L2_NSUB * L2_CNT_STRIDE * sizeof(uint32_t), st), "second-level counters");
                         { ProfScope p(sl, "extend_filter"); launch_extend_filter_ctx(ea, st); }
                         ExtendArgs e2 = ea;
                         e2.td = 0;
@@ -784,9 +800,10 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                         check_sync(st, "extend (no chain)");
                     }
                     const Counters& c = *sl->h_cnt;
-                    const bool l2_ok = !(ea.td && ea.td_ctx) || c.n_l2 <= ea.l2_cap;
+                    const bool l2_ok = !(ea.td && ea.td_ctx) || c.n_l2_max <= ea.l2_cap;
                     if (c.survivors <= ea.out_cap && c.n_long <= ea.cand_cap_recs && c.n_ent <= ea.ent_cap_recs && l2_ok) break;
-                    if (!l2_ok) sl->l2_list.ensure((size_t)c.n_l2, "second-level list(grow)");  // (the later stages saw a truncated list)
+                    if (!l2_ok)  // (the later stages saw a truncated list)
+                        sl->l2_list.ensure((size_t)c.n_l2_max * L2_NSUB + ((size_t)c.n_l2_max * L2_NSUB) / 4, "second-level list(grow)");
                     // an overflowing long list also truncates what the later kernels saw: size everything from the
                     // counts of this attempt (upper bounds for the rerun: survivors <= hits, entropy candidates <= hits)
                     if (c.n_long > ea.cand_cap_recs) sl->cand_list.ensure((size_t)c.n_long, "candidate list(grow)");

@@ -169,8 +169,9 @@ __device__ __forceinline__ void stage_flush(const T* __restrict__ stage, int cnt
     if (lane < cnt && base + (uint32_t)lane < cap) list[base + (uint32_t)lane] = stage[lane];
 }
 
-// append one record per flagged lane to the wave's stage; flush the first 64 when they are complete.  n is wave-uniform.
-template <typename T>
+// append one record per flagged lane to the wave's stage; flush up to 64 of them once FLUSH are pending (stage capacity:
+// FLUSH - 1 pending + 64 new).  n is wave-uniform.
+template <int FLUSH = 64, typename T>
 __device__ __forceinline__ void stage_append(T* __restrict__ stage, int& n, bool flag, const T& rec, T* __restrict__ list,
                                              uint32_t* __restrict__ counter, uint32_t cap, int lane, unsigned long long lane_lt) {
     const unsigned long long m = __ballot(flag);
@@ -178,11 +179,12 @@ __device__ __forceinline__ void stage_append(T* __restrict__ stage, int& n, bool
     if (flag) stage[n + __popcll(m & lane_lt)] = rec;
     n += __popcll(m);
     __builtin_amdgcn_wave_barrier();
-    if (n >= 64) {
-        stage_flush(stage, 64, list, counter, cap, lane);
-        const int rest = n - 64;
+    if (n >= FLUSH) {
+        const int k = n < 64 ? n : 64;
+        stage_flush(stage, k, list, counter, cap, lane);
+        const int rest = n - k;
         T tmp = rec;
-        if (lane < rest) tmp = stage[64 + lane];
+        if (lane < rest) tmp = stage[k + lane];
         __builtin_amdgcn_wave_barrier();
         if (lane < rest) stage[lane] = tmp;
         __builtin_amdgcn_wave_barrier();
@@ -542,7 +544,10 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
     constexpr bool TD = SRC == SRC_TD;
     __shared__ uint32_t s_pk[PK_TAB];
     __shared__ CandRec s_cand[PK_THREADS / 64][STAGE_CAP];
+    __shared__ uint32_t s_l2pre[SRC == SRC_CAND ? L2_NSUB + 1 : 1];  // SRC_CAND: prefix of the sub-lists of the second-level list
     pk_table_init<false>(s_pk, a.sub_mat, PK_THREADS);
+    if (SRC == SRC_CAND)
+        for (int i = threadIdx.x; i <= L2_NSUB; i += PK_THREADS) s_l2pre[i] = a.l2_prefix[i];
     __syncthreads();
     CandRec* stage = s_cand[threadIdx.x >> 6];
     int n_stage = 0;
@@ -555,7 +560,7 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
 
     // ---- the wave's queue of 64-hit buffers: round-robin over all waves of the grid (hit list), or one contiguous range
     //      per wave (TD) ----
-    const uint64_t total_hits = SRC == SRC_CAND ? (uint64_t)min(*a.l2_count, a.l2_cap) : a.num_hits;
+    const uint64_t total_hits = SRC == SRC_CAND ? (uint64_t)s_l2pre[SRC == SRC_CAND ? L2_NSUB : 0] : a.num_hits;
     const uint64_t num_buf = (total_hits + 63) >> 6;
     const uint64_t W = (uint64_t)gridDim.x * (PK_THREADS / 64);
     const uint64_t wid = (uint64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (PK_THREADS / 64) + (threadIdx.x >> 6)));
@@ -570,7 +575,8 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
     };
     TdCursor cursor = {0u, {0u, 0u, 0ull}, 0u};
     if (TD && cur_buf < buf_end) cursor.seek(a, lane, (uint32_t)(cur_buf << 6));
-    uint32_t f_idx = 0;  // SRC_CAND: the fetched record's own hit index
+    uint32_t f_idx = 0;  // SRC_CAND: the fetched record's own hit index ...
+    uint32_t f_known = 0, f_tm = 0, f_flags = 3;  // ... and what level 1 knows about it (L2Rec)
     auto fetch = [&](uint64_t b, int cnt) -> Hit {
         Hit h = {0u, 0u};
         f_idx = (uint32_t)(b << 6) + (uint32_t)lane;
@@ -578,10 +584,18 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
             if (lane < cnt) h = a.hits[(b << 6) + lane];
         } else if (SRC == SRC_CAND) {
             if (lane < cnt) {
-                const CandRec c = a.l2_list[(b << 6) + lane];
+                const uint32_t g = (uint32_t)(b << 6) + (uint32_t)lane;  // record g of the concatenated sub-lists
+                uint32_t sl = 0;
+#pragma unroll
+                for (uint32_t step = L2_NSUB / 2; step >= 1; step >>= 1)
+                    if (s_l2pre[(sl + step) & (SRC == SRC_CAND ? 0xFFFFu : 0u)] <= g) sl += step;  // largest sl with prefix[sl] <= g
+                const L2Rec c = a.l2_list[(size_t)sl * a.l2_cap + (g - s_l2pre[sl & (SRC == SRC_CAND ? 0xFFFFu : 0u)])];
                 h.ref_loc = c.ref_loc;
                 h.query_loc = c.query_loc;
                 f_idx = c.hidx;
+                f_known = (uint32_t)c.known;
+                f_tm = c.tm;
+                f_flags = c.flags;
             }
         } else if (cnt > 0) {  // (wave-uniform)
             uint64_t entry;
@@ -596,9 +610,9 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
     };
     int buf_cnt = buf_count(cur_buf), nxt_cnt = buf_count(nxt_buf), consumed = 0;
     Hit buf = fetch(cur_buf, buf_cnt);
-    uint32_t buf_idx = f_idx;
+    uint32_t buf_idx = f_idx, buf_known = f_known, buf_tm = f_tm, buf_flags = f_flags;
     Hit nxt = fetch(nxt_buf, nxt_cnt);
-    uint32_t nxt_idx = f_idx;
+    uint32_t nxt_idx = f_idx, nxt_known = f_known, nxt_tm = f_tm, nxt_flags = f_flags;
 
     // ---- per-lane state ----
     int phase = PH_FIN;
@@ -608,6 +622,8 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
     uint4 h_tw = {0u, 0u, 0u, 0u}, h_qlo = {0u, 0u, 0u, 0u}, h_qhi = {0u, 0u, 0u, 0u};  // first LEFT window, fetched with the hit
     s16x2 T = {0, 0}, M = {0, 0};
     int bestR = 0, best = 0;
+    bool left_known = false;  // SRC_CAND: level 1 settled the left side, `left_best` is its best score
+    int left_best = 0;
 
     for (;;) {
         // ================= 1. advance every live lane by one 64-base window of its current side =================
@@ -690,10 +706,15 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
             if (!alive) {
                 if (!left) {  // -> left side (:457-476): anchor-1, anchor-2, ...
                     bestR = m;
-                    phase = PH_LEFT;
-                    walked = 0;
-                    T = (s16x2){0, 0};
-                    M = (s16x2){0, 0};
+                    if (SRC == SRC_CAND && left_known) {
+                        best = left_best;
+                        phase = PH_FIN;
+                    } else {
+                        phase = PH_LEFT;
+                        walked = 0;
+                        T = (s16x2){0, 0};
+                        M = (s16x2){0, 0};
+                    }
                 } else {
                     best = m;
                     phase = PH_FIN;
@@ -718,13 +739,14 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
             unsigned long long need = fin;
             bool got = false;
             Hit mine = {0u, 0u};
-            uint32_t mine_idx = 0;
+            uint32_t mine_idx = 0, mine_known = 0, mine_tm = 0, mine_flags = 3;
             while (need != 0ull) {
                 const int avail = buf_cnt - consumed;
                 if (avail <= 0) {
                     if (nxt_cnt == 0) break;  // queue exhausted
                     buf = nxt;
                     buf_idx = nxt_idx;
+                    buf_known = nxt_known; buf_tm = nxt_tm; buf_flags = nxt_flags;
                     buf_cnt = nxt_cnt;
                     cur_buf = nxt_buf;
                     consumed = 0;
@@ -732,6 +754,7 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
                     nxt_cnt = buf_count(nxt_buf);
                     nxt = fetch(nxt_buf, nxt_cnt);
                     nxt_idx = f_idx;
+                    nxt_known = f_known; nxt_tm = f_tm; nxt_flags = f_flags;
                     continue;
                 }
                 const int rank = __popcll(need & lane_lt);
@@ -740,10 +763,17 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
                 const uint32_t hr = (uint32_t)__shfl((int)buf.ref_loc, src, 64);
                 const uint32_t hq = (uint32_t)__shfl((int)buf.query_loc, src, 64);
                 const uint32_t hi = SRC == SRC_CAND ? (uint32_t)__shfl((int)buf_idx, src, 64) : (uint32_t)(cur_buf << 6) + (uint32_t)src;
+                uint32_t hk = 0, ht = 0, hf = 3;
+                if (SRC == SRC_CAND) {
+                    hk = (uint32_t)__shfl((int)buf_known, src, 64);
+                    ht = (uint32_t)__shfl((int)buf_tm, src, 64);
+                    hf = (uint32_t)__shfl((int)buf_flags, src, 64);
+                }
                 if (take) {
                     mine.ref_loc = hr;
                     mine.query_loc = hq;
                     mine_idx = hi;
+                    mine_known = hk; mine_tm = ht; mine_flags = hf;
                     got = true;
                 }
                 consumed += min(__popcll(need), avail);
@@ -761,13 +791,29 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
                     bool skip = false;
                     if (a.rm) skip = !(ref_loc >= a.rm_win_start && ref_loc <= a.rm_win_end);  // rm :239-244,:305-333
                     // anchors beyond the block (hand-made seed words only) are never extended, see extend_filter_kernel
+                    left_known = false;
                     if (skip || ref_loc > a.ref_len || query_loc > a.query_len) {
                         phase = PH_FIN;
+                    } else if (SRC == SRC_CAND && mine_flags == 0u) {  // both sides settled by level 1: only the verdict is left
+                        bestR = (int)mine_known;
+                        best = (int)mine_tm;
+                        phase = PH_FIN;
+                    } else if (SRC == SRC_CAND && mine_flags == 2u) {  // right side settled; the left walk continues after 64 bases
+                        bestR = (int)mine_known;
+                        phase = PH_LEFT;
+                        walked = 64;
+                        const short t16 = (short)(mine_tm & 0xFFFFu), m16 = (short)(mine_tm >> 16);
+                        T = (s16x2){t16, t16};
+                        M = (s16x2){m16, m16};
                     } else {
                         phase = PH_RIGHT;  // :299-324
                         walked = 0;
                         T = (s16x2){0, 0};
                         M = (s16x2){0, 0};
+                        if (SRC == SRC_CAND && mine_flags == 1u) {  // left side settled by level 1
+                            left_known = true;
+                            left_best = (int)mine_known;
+                        }
                     }
                 } else {
                     has_hit = false;
@@ -827,11 +873,13 @@ __device__ __forceinline__ void ctx_step16(const uint32_t* __restrict__ s_tab, u
     }
 }
 
-// Workgroup size: 512 threads (three workgroups per CU = the 6 waves per SIMD the 77 VGPRs allow).  384 / 640 / 768 / 1024
-// threads -- which leave more LDS and wave slots to the tail kernels of the other streams -- measured 2-3 % slower on the
-// whole bench (tools/sweep_threads.sh)
-constexpr int CTX_THREADS = 512;      // default; ExtendArgs::ctx_threads (SEGALIGN_AMD_CTX_THREADS) overrides it per launch
+// Workgroup size: 1024 threads (two workgroups per CU = 8 waves per SIMD at 53 VGPRs; the pair table is built once per 16 waves).
+// Since the second-level list is appended to through 256 counters instead of one, the kernel is no longer serialised on an
+// atomic and the extra occupancy is worth ~3 % over 512 threads (tools/sweep_pipe.sh)
+constexpr int CTX_THREADS = 1024;      // default; ExtendArgs::ctx_threads (SEGALIGN_AMD_CTX_THREADS) overrides it per launch
 constexpr int CTX_THREADS_MAX = 1024;
+constexpr int CTX_STAGE_FLUSH = 32;                    // forwards are rare (~4 % of the hits): flush early, keep the stage small
+constexpr int CTX_STAGE_CAP = CTX_STAGE_FLUSH - 1 + 64 + 1;  // 96 records of 24 bytes per wave: three workgroups per CU still fit
 // PIPE: how a wave covers the latency of its stream.  1 (default) = no prefetch, 53 VGPRs, up to 8 waves per SIMD; 2 = records +
 // query windows of buffer b + 1 requested before buffer b is scored (two full register sets, 77 VGPRs, 6 waves per SIMD).
 // Measured within 2 % of each other (tools/sweep_pipe.sh; a third variant that prefetched only the records spilled and lost
@@ -839,10 +887,10 @@ constexpr int CTX_THREADS_MAX = 1024;
 template <int PIPE>
 __global__ __launch_bounds__(CTX_THREADS_MAX, PIPE == 2 ? 4 : 8) void extend_filter_ctx_kernel(ExtendArgs a) {
     __shared__ uint32_t s_pk[2 * PK_TAB];  // 8-byte entries {sum, max prefix} (32 KB)
-    extern __shared__ CandRec s_cand_dyn[];  // [waves of the workgroup][STAGE_CAP]
+    extern __shared__ L2Rec s_l2_dyn[];  // [waves of the workgroup][CTX_STAGE_CAP]
     pk_table_init<true>(s_pk, a.sub_mat, (int)blockDim.x);
     __syncthreads();
-    CandRec* stage = s_cand_dyn + (threadIdx.x >> 6) * STAGE_CAP;
+    L2Rec* stage = s_l2_dyn + (threadIdx.x >> 6) * CTX_STAGE_CAP;
     int n_stage = 0;
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
@@ -859,6 +907,9 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, PIPE == 2 ? 4 : 8) void extend_fil
     const uint64_t b_lo = c_lo * (TD_CHUNK_HITS / 64);
     const uint64_t b_hi = min(c_hi * (TD_CHUNK_HITS / 64), num_buf);
     if (b_lo >= b_hi) return;
+    const uint32_t my_sub = (uint32_t)wid & (uint32_t)(L2_NSUB - 1);  // this wave's sub-list of the second-level list
+    L2Rec* __restrict__ my_list = a.l2_list + (size_t)my_sub * a.l2_cap;
+    uint32_t* __restrict__ my_count = a.l2_count + my_sub * L2_CNT_STRIDE;
     TdCursor cursor = {0u, {0u, 0u, 0ull}, 0u};
     cursor.m0 = a.td_chunk[c_lo];
     cursor.load_window(a, lane);
@@ -916,7 +967,7 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, PIPE == 2 ? 4 : 8) void extend_fil
                 alive = (M - T) <= xdrop;  // :374, looked at once per 16 bases
             }
         }
-        bool undecided = alive;  // still walking at the end of the context
+        const bool r_alive = alive;  // still walking at the end of the context
         const int bestR = M;
         // ---- left side (:478-604): 4 steps on the pre-reversed context; the query bytes run against the walk ----
         T = 0;
@@ -934,11 +985,14 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, PIPE == 2 ? 4 : 8) void extend_fil
                 }
             }
         }
-        undecided = undecided || alive;
-        const bool fwd = !skip && (undecided || classify(a, bestR + M) != 0);
-        CandRec cr;
+        const bool l_alive = alive;
+        const bool fwd = !skip && (r_alive || l_alive || classify(a, bestR + M) != 0);
+        L2Rec cr;  // what is known travels with the anchor (kernels.h): level 2 walks only what is still open
         cr.ref_loc = ref_loc; cr.query_loc = query_loc; cr.hidx = (uint32_t)(b << 6) + (uint32_t)lane;
-        stage_append(stage, n_stage, fwd, cr, a.l2_list, a.l2_count, a.l2_cap, lane, lane_lt);
+        cr.flags = (r_alive ? 1u : 0u) | (l_alive ? 2u : 0u);
+        cr.known = r_alive ? M : bestR;  // flags 1: bestL; flags 0 / 2: bestR
+        cr.tm = (l_alive && !r_alive) ? (((uint32_t)T & 0xFFFFu) | ((uint32_t)M << 16)) : (uint32_t)M;  // flags 2: left walk state; flags 0: bestL
+        stage_append<CTX_STAGE_FLUSH>(stage, n_stage, fwd, cr, my_list, my_count, a.l2_cap, lane, lane_lt);
     };
     Loaded A, B;
     A.c0 = A.c1 = A.qr0 = A.ql0 = A.ql1 = make_uint4(0u, 0u, 0u, 0u);
@@ -963,7 +1017,29 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, PIPE == 2 ? 4 : 8) void extend_fil
             score(b, A);
         }
     }
-    stage_flush(stage, n_stage, a.l2_list, a.l2_count, a.l2_cap, lane);
+    stage_flush(stage, n_stage, my_list, my_count, a.l2_cap, lane);
+}
+
+// one workgroup of L2_NSUB threads: prefix of the sub-list counts (clamped to their capacity), total and maximum
+__global__ __launch_bounds__(L2_NSUB) void l2_prefix_kernel(ExtendArgs a) {
+    __shared__ uint32_t s_v[L2_NSUB];
+    const uint32_t c = a.l2_count[threadIdx.x * L2_CNT_STRIDE];
+    s_v[threadIdx.x] = min(c, a.l2_cap);
+    __syncthreads();
+    uint32_t pre = 0, mx = 0;
+    for (int t = 0; t < L2_NSUB; t++) {  // 256 broadcast reads per thread: a microsecond
+        const uint32_t v = s_v[t];
+        if (t < (int)threadIdx.x) pre += v;
+    }
+    a.l2_prefix[threadIdx.x] = pre;
+    // maximum of the raw counts (wave reduce, then one atomic per wave)
+    mx = c;
+    for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(a.l2_max, mx);
+    if (threadIdx.x == L2_NSUB - 1) {
+        a.l2_prefix[L2_NSUB] = pre + s_v[L2_NSUB - 1];
+        *a.l2_total = pre + s_v[L2_NSUB - 1];
+    }
 }
 
 // =====================================================================================================================
@@ -1401,9 +1477,10 @@ void launch_extend_filter_ctx(const ExtendArgs& a, hipStream_t s) {
     threads = std::min<uint32_t>(CTX_THREADS_MAX, std::max<uint32_t>(64, threads & ~63u));
     const uint32_t wpb = threads / 64;
     const uint32_t blocks = (uint32_t)((waves + wpb - 1) / wpb);
-    const size_t lds = wpb * STAGE_CAP * sizeof(CandRec);
+    const size_t lds = wpb * CTX_STAGE_CAP * sizeof(L2Rec);
     if (a.ctx_pipe == 2) hipLaunchKernelGGL(extend_filter_ctx_kernel<2>, dim3(blocks), dim3(threads), lds, s, a);
     else hipLaunchKernelGGL(extend_filter_ctx_kernel<1>, dim3(blocks), dim3(threads), lds, s, a);
+    hipLaunchKernelGGL(l2_prefix_kernel, dim3(1), dim3(L2_NSUB), 0, s, a);
 }
 
 void launch_chain_group(const ExtendArgs& a, hipStream_t s) {  // chain_bucket_cnt must be zero on entry

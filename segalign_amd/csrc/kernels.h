@@ -42,6 +42,25 @@ struct CandRec {              // a hit the X-drop filter could not reject: exten
     uint32_t hidx;            // index of the hit inside the launch (for the segment id)
 };
 
+// What the context filter hands to the second level: the anchor plus what level 1 already knows, so that level 2 walks only
+// the side(s) that were still alive at the end of the 48 + 64 context bases.
+//   flags bit 0: right side undecided, bit 1: left side undecided
+//   flags 0 (both sides dropped inside the context, the bound passes): known = bestR, tm = bestL -- nothing left to walk
+//   flags 1: known = bestL (the left side is settled), the right side is walked from the anchor
+//   flags 2: known = bestR, tm = running score (low 16 bits) | best score (high 16 bits) of the left walk after 64 bases,
+//            which level 2 continues from there
+//   flags 3: both sides from the anchor
+struct L2Rec {
+    uint32_t ref_loc, query_loc;
+    uint32_t hidx;
+    int32_t known;
+    uint32_t tm;
+    uint32_t flags;
+};
+
+constexpr int L2_NSUB = 256;        // sub-lists of the second-level list
+constexpr int L2_CNT_STRIDE = 32;   // dwords between their counters (one 128-byte line each)
+
 struct EntRec {               // finished hit with hspthresh <= total <= 3*hspthresh: needs the entropy factor (:608)
     uint32_t ref_loc, query_loc;
     int32_t bposR, boffL;     // best offsets right / left of the anchor
@@ -109,9 +128,16 @@ struct ExtendArgs {
     uint32_t td_m;
     const uint32_t* td_pos;     // neighbourhood table runs: seed START positions in the target (+ seed_size = anchor, :220)
     const CtxRec* td_ctx;       // != null: the runs carry their target context (then td_pos is unused): context filter + second level
-    CandRec* l2_list;           // hits the context filter could not decide (walk alive at the end of the context, or bound passes)
+    // hits the context filter could not decide (walk alive at the end of the context, or bound passes): L2_NSUB sub-lists of
+    // l2_cap records each, sub-list s appended to through counter l2_count[s * L2_CNT_STRIDE] (a wave uses sub-list
+    // wave id % L2_NSUB).  ONE list with ONE counter serialised the whole filter on a single L2 atomic address: 125 k
+    // appends of 64 records per call at ~11 ns each cost 0.67 ms of a 2.3 ms kernel.
+    L2Rec* l2_list;
     uint32_t* l2_count;
     uint32_t l2_cap;
+    uint32_t* l2_prefix;        // [L2_NSUB + 1]: exclusive prefix of min(count, l2_cap) over the sub-lists (l2_prefix_kernel)
+    uint32_t* l2_total;         // -> number of records in all sub-lists
+    uint32_t* l2_max;           // -> largest sub-list count (> l2_cap: records were dropped, the host regrows and reruns)
     int src_cand;               // packed filter reads its anchors from l2_list / *l2_count instead of `hits`
     uint32_t ctx_waves;         // wave budget of the context filter (0: one chunk of TD_CHUNK_HITS hits per wave)
     uint32_t chain_q_bits;      // chain sort key = iteration | diagonal (32) | query position (chain_q_bits) relative to chain_q_base

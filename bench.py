@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--chunk", type=int, default=250_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="bounded CPU baseline budget")
+    ap.add_argument("--intervals-in-flight", type=int, default=2,
+                    help="query intervals processed concurrently (each with --host-threads calls in flight), like the reference's seeder threads")
     ap.add_argument("--one-interval", action="store_true",
                     help="profiling aid: set up, run ONE interval with one call in flight, exit (short enough for --pmc passes)")
     ap.add_argument("--host-threads", type=int, default=2,
@@ -186,6 +188,8 @@ def main():
     E.select_devices([local_rank])
     E.InitializeInterface(1)
     kmer = E.GenerateShapePos(SHAPE)
+    # one engine slot per call in flight (the engine's default is 2)
+    os.environ.setdefault("SEGALIGN_AMD_SLOTS", str(max(2, max(1, args.host_threads) * max(1, args.intervals_in_flight))))
     E.InitializeProcessor(wl["transition"], args.chunk, seed_size, sub_mat, xdrop, hspthresh, False)
     t0 = time.time()
     keep = E.SendRefWriteRequest(target, 0, target.size)
@@ -229,6 +233,13 @@ def main():
             # (repeat_masker_src/main.cpp hands them to parallel seeder bodies): keep `nt` of them in flight
             from concurrent.futures import ThreadPoolExecutor
             with ThreadPoolExecutor(nt) as pool:
+                res = list(pool.map(lambda it: run_item(it, collect, threads), todo))
+            return sum(r[0] for r in res), sum(r[1] for r in res)
+        if args.intervals_in_flight > 1 and threads is None and len(todo) > 1:
+            # the reference host keeps several seeder bodies (intervals) in flight (src/main.cpp:601-737, one per TBB thread):
+            # the calls of one interval finish together, a second interval fills the gap
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(args.intervals_in_flight) as pool:
                 res = list(pool.map(lambda it: run_item(it, collect, threads), todo))
             return sum(r[0] for r in res), sum(r[1] for r in res)
         b = h = 0
@@ -454,7 +465,7 @@ def roofline(args, E, wl, prof, call_stats, run_step, run_item, items):
         "random_line_roofline": ({"lines_per_launch": int(traffic // 128), "peak_lines_per_s": RANDOM_LINES_PER_S,
                                   "frac_single_stream": round(traffic / 128 / (s_avg_us * 1e-6) / RANDOM_LINES_PER_S, 4)}
                                  if (traffic and s_avg_us) else None),
-        "calls_in_flight": max(1, args.host_threads), "single_stream": single,
+        "calls_in_flight": max(1, args.host_threads) * max(1, args.intervals_in_flight), "single_stream": single,
         "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
         "algorithmic_bytes_per_launch": round(alg_t[key] / max(launches, 1)) if key else None,
         "dominant_share_of_gpu_time": round(ms / gpu_ms, 4) if gpu_ms else None,

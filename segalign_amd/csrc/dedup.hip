@@ -173,7 +173,7 @@ constexpr int DEDUP_SMALL_SEGS = 32;  // distinct segment ids (reference iterati
 // CUs instead of one 1024-thread workgroup walking all records: the stage's latency drops from ~200 us (500 us next to a
 // running filter kernel) to ~20 us, and the limit rises from 1024 survivors per call to 2048 per segment.
 constexpr int DEDUP_SEG_THREADS = 1024;
-constexpr int DEDUP_SEG_MAX = 2048;      // records per segment (2 x 40 KB of LDS)
+constexpr int DEDUP_SEG_MAX = 2048;      // records per segment (40 KB of LDS)
 constexpr int DEDUP_SEG_TOTAL = 65536;   // survivors per call (every workgroup scans the whole list once)
 
 // In-place bitonic sort of m <= DEDUP_SEG_MAX records of ONE segment in LDS.  The records' seg field (constant inside a
@@ -235,8 +235,8 @@ __global__ __launch_bounds__(DEDUP_SEG_THREADS) void dedup_seg_kernel(const HspR
             return;
         }
     }
-    __shared__ HspRec s_a[DEDUP_SEG_MAX];
-    __shared__ HspRec s_b[DEDUP_SEG_MAX];
+    __shared__ HspRec s_a[DEDUP_SEG_MAX];  // ONE buffer (40 KB): the unique step compacts in place, so the workgroup fits into the
+                                           // LDS a single retiring filter workgroup frees
     __shared__ uint32_t s_cnt[DEDUP_SMALL_SEGS];
     __shared__ uint32_t s_m, s_wave[DEDUP_SEG_THREADS / 64];
     const uint32_t g = blockIdx.x;
@@ -273,25 +273,27 @@ __global__ __launch_bounds__(DEDUP_SEG_THREADS) void dedup_seg_kernel(const HspR
         me.ref_start = me.query_start = me.len = 0; me.score = 0; me.seg = 0;
         if (i < m) {
             me = s_a[i];
-            keep = i == 0 || !hsp_contained(s_a[i - 1], me);
+            keep = i == 0 || !hsp_contained(s_a[i - 1], me);  // the INPUT neighbour (H3): slot i - 1 still holds it, see below
         }
         const unsigned long long mask = __ballot(keep);
         if (lane == 0) s_wave[wave] = (uint32_t)__popcll(mask);
-        __syncthreads();
+        __syncthreads();  // every read of this tile is done before anything is written
         uint32_t pre = 0, tot = 0;
         for (int w = 0; w < (int)(blockDim.x >> 6); w++) {
             const uint32_t c = s_wave[w];
             if (w < wave) pre += c;
             tot += c;
         }
-        if (keep) s_b[carry + pre + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = me;
+        // in place: kept records move left, so a slot is only ever overwritten by a record from its own or a later position;
+        // the last slot of the tile (the next tile's input neighbour) is rewritten only with itself
+        if (keep) s_a[carry + pre + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = me;
         carry += tot;
         __syncthreads();
     }
     const uint32_t m2 = carry;
-    bitonic_sort_lds<KeyLastz>(s_b, m2, my_seg);  // :782
+    bitonic_sort_lds<KeyLastz>(s_a, m2, my_seg);  // :782
     for (uint32_t i = threadIdx.x; i < m2; i += blockDim.x) {
-        const HspRec r = s_b[i];
+        const HspRec r = s_a[i];
         out[off + i] = make_uint4(r.ref_start, r.query_start, r.len, (uint32_t)r.score);
     }
     if (threadIdx.x == 0) { seg_info[g] = m2; seg_info[DEDUP_SMALL_SEGS + g] = off; }

@@ -1738,11 +1738,15 @@ size_t sa_seed_interval(uint32_t start, uint32_t end, uint32_t q_len, int strand
     for (int rev = 0; rev < 2; rev++) {
         if (!(strands & (rev ? SA_STRAND_MINUS : SA_STRAND_PLUS))) continue;
         const uint32_t a = rev ? q_len - end : start, b = rev ? q_len - start : end;
-        for (uint64_t i = a; i < b; i += (uint64_t)g_wga_chunk * per_job) {
+        // equal groups: 40 chunks go as 14 + 14 + 12, not 16 + 16 + 8 (the calls of an interval finish together)
+        const uint64_t nchunks = b > a ? ((uint64_t)b - a + g_wga_chunk - 1) / g_wga_chunk : 0;
+        const uint64_t ncalls = (nchunks + per_job - 1) / per_job;
+        const uint64_t group = ncalls ? (nchunks + ncalls - 1) / ncalls : 1;
+        for (uint64_t i = a; i < b; i += (uint64_t)g_wga_chunk * group) {
             Job jb;
             memset(&jb, 0, sizeof(jb));
             jb.a = (uint32_t)i;
-            jb.b = (uint32_t)std::min<uint64_t>(i + (uint64_t)g_wga_chunk * per_job, b);
+            jb.b = (uint32_t)std::min<uint64_t>(i + (uint64_t)g_wga_chunk * group, b);
             jb.rev = rev;
             jb.k = (int)(((uint64_t)jb.b - jb.a + g_wga_chunk - 1) / g_wga_chunk);
             jobs.push_back(jb);

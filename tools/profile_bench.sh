@@ -15,7 +15,9 @@ RAW=/tmp/prof_raw_$TAG
 rm -rf $RAW; mkdir -p $OUT $RAW
 cd $R
 echo "stats pass: python bench.py $*" > $OUT/commands.txt
-python -c "import json,sys; json.dump({'workload': sys.argv[1], 'target_mbp': float(sys.argv[2]), 'chunk': int(sys.argv[3])}, open(sys.argv[4], 'w'))" $WORKLOAD $TARGET_MBP $CHUNK $OUT/workload.json   # bench.py quotes traffic.json only for this shape
+# bench.py quotes traffic.json only for this shape; single_stream: the stats pass ran with ONE call in flight (SINGLE_STREAM=1 and
+# "--host-threads 1 --intervals-in-flight 1" among the bench args), so its kernel averages are overlap-free
+python -c "import json,sys; json.dump({'workload': sys.argv[1], 'target_mbp': float(sys.argv[2]), 'chunk': int(sys.argv[3]), 'single_stream': sys.argv[5] == '1'}, open(sys.argv[4], 'w'))" $WORKLOAD $TARGET_MBP $CHUNK $OUT/workload.json ${SINGLE_STREAM:-0}
 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/stats -o r -- python bench.py "$@" > $OUT/bench_under_stats.log 2>&1
 python tools/prof_summary.py $RAW/stats --out $OUT/kernel_stats.txt
 grep "^{\"metric\"" $OUT/bench_under_stats.log | tail -1 > $OUT/bench_line_under_stats.json

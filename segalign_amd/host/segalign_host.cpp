@@ -313,6 +313,11 @@ int main(int argc, char** argv) {
     fprintf(stderr, "Using %d threads\n", cfg.num_threads);
     cfg.num_gpu = sa_initialize_interface(cfg.num_gpu);                                                        // main.cpp:297
     sa_generate_shape_pos(cfg.shape.c_str());                                                                 // main.cpp:180
+    {   // one engine slot per seeder thread, up to four calls in flight per device (more only queue behind the filter kernels)
+        char slots[16];
+        snprintf(slots, sizeof(slots), "%d", std::max(2, std::min(4, cfg.num_threads)));
+        setenv("SEGALIGN_AMD_SLOTS", slots, 0);
+    }
     sa_initialize_processor(cfg.transition, cfg.wga_chunk, cfg.seed_size, sub_mat, cfg.xdrop, cfg.hspthresh, cfg.noentropy);  // :298
 
     auto t0 = std::chrono::steady_clock::now();

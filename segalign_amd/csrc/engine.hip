@@ -327,6 +327,7 @@ static int g_long_cap = 128;      // SEGALIGN_AMD_LONG_CAP: bases per side befor
 static int g_long_blocks = 1792;  // SEGALIGN_AMD_LONG_BLOCKS: grid of the long kernel (4 waves per block)
 static int g_packed_waves = 4096; // SEGALIGN_AMD_PACKED_WAVES: waves of the packed filter (2 workgroups of 8 waves per CU measured best: 3072 +16 %, 6144 +20 %, 8192 +14 %)
 static int g_ctx_waves = 0;       // SEGALIGN_AMD_CTX_WAVES: wave budget of the context filter; 0 = one 4096-hit chunk per wave (measured best)
+static uint32_t g_l2_cap_test = 0; // SEGALIGN_AMD_L2_CAP
 static int g_ctx_pipe = 1;        // SEGALIGN_AMD_CTX_PIPE: 1 = no prefetch, 53 VGPRs (measured best by 1-3 %), 2 = ping-pong prefetch
 static int g_ctx_threads = 0;     // SEGALIGN_AMD_CTX_THREADS: workgroup size of the context filter (0 = kernel default)
 static int g_dedup_threads = 0;   // SEGALIGN_AMD_DEDUP_THREADS: workgroup size of the per-segment LDS chain (0 = 1024)
@@ -649,7 +650,9 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     ea.td_ctx = dc->nbr_ctx;
                     ea.seed_size = g_seed_size;
                     if (ea.td_ctx) {
-                        sl->l2_list.ensure((size_t)std::max<uint64_t>((uint64_t)L2_NSUB * TD_CHUNK_HITS, bh / 8), "second-level list");  // (a sub-list can take a whole chunk)
+                        // (a sub-list can take a whole chunk; SEGALIGN_AMD_L2_CAP: tests start small to reach the regrow-and-rerun path)
+                        sl->l2_list.ensure(g_l2_cap_test ? (size_t)g_l2_cap_test
+                                                         : (size_t)std::max<uint64_t>((uint64_t)L2_NSUB * TD_CHUNK_HITS, bh / 8), "second-level list");
                         sl->l2_counts.ensure((size_t)L2_NSUB * L2_CNT_STRIDE, "second-level counters");
                         sl->l2_prefix.ensure((size_t)L2_NSUB + 1, "second-level prefix");
                     }
@@ -1319,6 +1322,8 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
     if (const char* e = getenv("SEGALIGN_AMD_CTX_WAVES")) g_ctx_waves = std::max(0, atoi(e));
     g_ctx_pipe = 1;
     if (const char* e = getenv("SEGALIGN_AMD_CTX_PIPE")) g_ctx_pipe = atoi(e);
+    g_l2_cap_test = 0;
+    if (const char* e = getenv("SEGALIGN_AMD_L2_CAP")) g_l2_cap_test = (uint32_t)std::max(L2_NSUB, atoi(e));
     if (const char* e = getenv("SEGALIGN_AMD_CTX_THREADS")) g_ctx_threads = std::max(0, atoi(e));
     g_spec_dedup = 1;
     if (const char* e = getenv("SEGALIGN_AMD_SPEC_DEDUP")) g_spec_dedup = atoi(e) != 0;

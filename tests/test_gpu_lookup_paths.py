@@ -19,7 +19,7 @@ MODES = [(2, {}), (1, {"SEGALIGN_AMD_NO_CTX": "1"}), (0, {"SEGALIGN_AMD_NO_TD": 
 
 def with_env(env):
     for k in ("SEGALIGN_AMD_NO_CTX", "SEGALIGN_AMD_NO_TD", "SEGALIGN_AMD_SPEC_RECS", "SEGALIGN_AMD_DEDUP_SEG_MAX",
-              "SEGALIGN_AMD_SPEC_DEDUP", "SEGALIGN_AMD_NO_SMALL_DEDUP", "SEGALIGN_AMD_CTX_PIPE"):
+              "SEGALIGN_AMD_SPEC_DEDUP", "SEGALIGN_AMD_NO_SMALL_DEDUP", "SEGALIGN_AMD_CTX_PIPE", "SEGALIGN_AMD_L2_CAP"):
         os.environ.pop(k, None)
     os.environ.update(env)
 
@@ -86,7 +86,8 @@ def test_lookup_paths_under_a_max_hits_split(oracle, clean, mode, env):
                                  {"SEGALIGN_AMD_DEDUP_SEG_MAX": "4"},     # a segment too large for the LDS chain: library sorts
                                  {"SEGALIGN_AMD_SPEC_DEDUP": "0"},        # chain launched after the survivor count is known
                                  {"SEGALIGN_AMD_NO_SMALL_DEDUP": "1"},    # library sorts only
-                                 {"SEGALIGN_AMD_CTX_PIPE": "2"}])         # the prefetching variant of the context filter
+                                 {"SEGALIGN_AMD_CTX_PIPE": "2"},          # the prefetching variant of the context filter
+                                 {"SEGALIGN_AMD_L2_CAP": "1024"}])        # 4 records per sub-list: overflow, regrow, rerun
 def test_every_output_path_of_a_multi_chunk_call(oracle, clean, env):
     """The ways the survivors of a call can reach the host -- speculative LDS chain with one or two copies, the same chain after
     a sync, the library-sort fallback -- must all give the oracle's vectors."""

@@ -25,7 +25,7 @@ def main():
     for f in sorted(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)):
         out.write("== %s\n" % os.path.relpath(f, d))
         for i, row in enumerate(csv.DictReader(open(f))):
-            if i >= 20:
+            if i >= 40:
                 break
             out.write("  %-70s calls=%s total_ns=%s avg_ns=%s pct=%s\n" % (
                 short(row.get("Name", "")), row.get("Calls"), row.get("TotalDurationNs"), row.get("AverageNs"),
@@ -37,7 +37,7 @@ def main():
             agg[k][0] += 1
             agg[k][1] += int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
         out.write("== %s (from trace)\n" % os.path.relpath(f, d))
-        for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:20]:
+        for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
             out.write("  %-70s calls=%d total_us=%.1f avg_us=%.2f\n" % (k, n, t / 1e3, t / 1e3 / n))
     for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         agg = defaultdict(lambda: defaultdict(float))

@@ -199,3 +199,34 @@ def test_configs3_repeat_masker_chunks_bit_exact_vs_oracle(full_rm, strands):
     want_iv = O.rm_coverage_intervals(allh, L, 1)
     got_iv, tot = E.RmMaskInterval(start_pos, end_pos, ws, we, strands, 1)
     assert np.array_equal(got_iv, want_iv) and tot["num_hsps"] == allh.size
+
+
+def test_configs3_repeat_masker_grouped_interval_vs_oracle(full_rm):
+    """Half an interval of the plan, both strands, through sa_rm_mask_interval -- sixteen-chunk table-direct passes, a short last
+    plus chunk whose minus chunk overlaps its neighbour (seeder.cpp:118-119) -- against the oracle chunk by chunk."""
+    E, O, target = full_rm["E"], full_rm["O"], full_rm["target"]
+    L, chunk = target.size, 250000
+    start_pos, end_pos, ws, we = 42_000_000, 47_100_000, 40_000_000, 52_000_000
+    end_pos_rc = L - 1 - start_pos
+    hsps, seeds_n, hits_n = [], 0, 0
+    for i in range(start_pos, end_pos, chunk):
+        for rev in (False, True):
+            s0, s1 = i, min(i + chunk, end_pos)
+            if rev:
+                s0 = L - 1 - s1
+                s1 = min(s0 + chunk, end_pos_rc)
+            buf = full_rm["rc_ascii"] if rev else target
+            seeds = O.make_seeds(buf.tobytes(), 0, s0, s1, 19, full_rm["k"], True)
+            if seeds.size == 0:
+                continue
+            want, st = O.seed_and_filter(full_rm["rcodes"], full_rm["rc_codes"] if rev else full_rm["rcodes"], full_rm["index"],
+                                         full_rm["pos"], seeds, full_rm["sub_mat"], rm=(rev, ws, we))
+            seeds_n += int(seeds.size)
+            hits_n += int(st["num_hits"])
+            hsps.append(want[1:])
+    allh = np.concatenate(hsps)
+    want_iv = O.rm_coverage_intervals(allh, L, 1)
+    got_iv, tot = E.RmMaskInterval(start_pos, end_pos, ws, we, E.STRAND_BOTH, 1)
+    assert np.array_equal(got_iv, want_iv)
+    assert tot == dict(num_seeds=seeds_n, num_hits=hits_n, num_hsps=int(allh.size))
+    assert hits_n > 400_000_000 and got_iv.size > 100

@@ -61,10 +61,12 @@ def test_configs4_whole_interval_chunks_bit_exact_vs_oracle(notrans, rev):
         hits += st["num_hits"]
         hsps += want.size - 1
     assert hits > 4_000_000 and hsps > 50
-    for g in range(0, len(chunks), 4):  # four chunks of a strand in one pass over the kernels
-        outs = E.SeedAndFilterChunks(chunks[g][0], chunks[min(g + 3, len(chunks) - 1)][1], rev, 0)
-        for j, w in enumerate(wants[g:g + 4]):
-            assert outs[j].shape == w.shape and np.all(outs[j] == w)
+    assert len(chunks) == 8
+    for k in (4, 8):  # four / all eight chunks of the strand in one pass over the kernels
+        for g in range(0, len(chunks), k):
+            outs = E.SeedAndFilterChunks(chunks[g][0], chunks[min(g + k - 1, len(chunks) - 1)][1], rev, 0)
+            for j, w in enumerate(wants[g:g + k]):
+                assert outs[j].shape == w.shape and np.all(outs[j] == w), (k, g, j)
 
 
 def test_configs4_interval_properties(notrans):

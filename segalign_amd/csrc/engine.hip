@@ -328,6 +328,7 @@ static int g_long_blocks = 1792;  // SEGALIGN_AMD_LONG_BLOCKS: grid of the long 
 static int g_packed_waves = 4096; // SEGALIGN_AMD_PACKED_WAVES: waves of the packed filter (2 workgroups of 8 waves per CU measured best: 3072 +16 %, 6144 +20 %, 8192 +14 %)
 static int g_ctx_waves = 0;       // SEGALIGN_AMD_CTX_WAVES: wave budget of the context filter; 0 = one 4096-hit chunk per wave (measured best)
 static uint32_t g_l2_cap_test = 0; // SEGALIGN_AMD_L2_CAP
+static int g_nbr_two_stage = 1;   // SEGALIGN_AMD_NBR_ONE_STAGE=1: every table entry cuts its own context out of the target
 static int g_ctx_pipe = 1;        // SEGALIGN_AMD_CTX_PIPE: 1 = no prefetch, 53 VGPRs (measured best by 1-3 %), 2 = ping-pong prefetch
 static int g_ctx_threads = 0;     // SEGALIGN_AMD_CTX_THREADS: workgroup size of the context filter (0 = kernel default)
 static int g_dedup_threads = 0;   // SEGALIGN_AMD_DEDUP_THREADS: workgroup size of the per-segment LDS chain (0 = 1024)
@@ -1108,7 +1109,8 @@ static bool ensure_nbr(DevCtx* dc) {
     size_t free_b = 0, total_b = 0;
     hipMemGetInfo(&free_b, &total_b);
     const size_t reserve = (size_t)8 << 30;  // keep 8 GiB for the slots' work buffers
-    const size_t need_ctx = (size_t)std::max<uint64_t>(total, 1) * sizeof(CtxRec);
+    // (+ num_index records behind the table: scratch of the two-stage fill, part of the same allocation)
+    const size_t need_ctx = (size_t)(std::max<uint64_t>(total, 1) + dc->num_index) * sizeof(CtxRec);
     const size_t need_pos = (size_t)std::max<uint64_t>(total, 1) * sizeof(uint32_t);
     if (g_ctx && dc->ref2.base && need_ctx + reserve <= free_b + dc->nbr_ctx_cap) {
         // runs with their target context: 32 bytes per entry (33 GB for a 100 Mbp block with transitions)
@@ -1123,7 +1125,8 @@ static bool ensure_nbr(DevCtx* dc) {
         if (dbg) fprintf(stderr, "neighbourhood table: %.1f M entries, hipMalloc of %.1f GB took %.1f ms\n", total / 1e6, need_ctx / 1e9, now() - t_a);
         const double t_b = now();
         launch_nbr_fill_ctx(dc->bucket_start, dc->pos_table, nkeys, tmask, g_shape.weight, dc->nbr_start, dc->ref2.base, dc->ref2.stride,
-                            g_seed_size, dc->nbr_ctx, st);
+                            g_seed_size, dc->nbr_ctx, (g_nbr_two_stage && tmask != 0) ? dc->nbr_ctx + std::max<uint64_t>(total, 1) : nullptr,
+                            (uint32_t)dc->num_index, st);
         check_launch("nbr fill ctx");
         check_sync(st, "nbr fill ctx");
         if (dbg) fprintf(stderr, "neighbourhood table: context fill took %.1f ms\n", now() - t_b);
@@ -1359,6 +1362,7 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
         g_chain = getenv("SEGALIGN_AMD_NO_CHAIN") ? 0 : 1;
         g_td = getenv("SEGALIGN_AMD_NO_TD") ? 0 : 1;
         g_ctx = getenv("SEGALIGN_AMD_NO_CTX") ? 0 : 1;
+        g_nbr_two_stage = getenv("SEGALIGN_AMD_NBR_ONE_STAGE") ? 0 : 1;
         g_chain_sort_threads = 256;
         if (const char* e = getenv("SEGALIGN_AMD_CHAIN_SORT_THREADS")) g_chain_sort_threads = std::max(64, std::min(512, atoi(e) & ~63));
         if (const char* e = getenv("SEGALIGN_AMD_CHAIN_CAP")) CHAIN_CAP = (uint32_t)std::max(1, atoi(e));

@@ -100,8 +100,52 @@ __global__ __launch_bounds__(256) void nbr_fill_ctx_kernel(const uint32_t* __res
     }
 }
 
+// Two-stage form of the same fill (used when `scratch` holds num_index records): stage 1 cuts the context of every seed position
+// ONCE, in pos_table order (one random target line per POSITION instead of one per table entry: 13 x fewer); stage 2 copies
+// the records of the 13 source buckets of a key into its run -- every source is a contiguous piece of the scratch array.
+__global__ __launch_bounds__(256) void ctx_by_index_kernel(const uint32_t* __restrict__ pos_table, uint32_t num_index,
+                                                           const uint8_t* __restrict__ ref2, size_t ref2_stride, uint32_t seed_size,
+                                                           uint4* __restrict__ out /* 2 x uint4 per position */) {
+    for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < num_index; id += gridDim.x * blockDim.x) {
+        const uint32_t p = pos_table[id];
+        const uint32_t a = p + seed_size;                       // anchor (:220)
+        const uint32_t jj0 = (a >> 2) + (uint32_t)PACK2_BIAS;   // logical byte of the anchor's 4-base group in copy a & 3
+        const uint32_t line = (jj0 - 16u) / (uint32_t)PACK2_PAYLOAD;
+        const uint8_t* tp = ref2 + (size_t)(a & 3u) * ref2_stride + (jj0 + 32u * line);
+        const uint4 rw = load16u(tp), lw = load16u(tp - 16);
+        out[2 * (size_t)id] = make_uint4(p, rw.x, rw.y, rw.z);
+        out[2 * (size_t)id + 1] = make_uint4(__builtin_bitreverse32(lw.w), __builtin_bitreverse32(lw.z),
+                                             __builtin_bitreverse32(lw.y), __builtin_bitreverse32(lw.x));
+    }
+}
+__global__ __launch_bounds__(256) void nbr_copy_ctx_kernel(const uint32_t* __restrict__ bucket_start, uint32_t nkeys, uint32_t tmask, int weight,
+                                                           const uint64_t* __restrict__ nbr_start, const uint4* __restrict__ by_index,
+                                                           uint4* __restrict__ ctx) {
+    const uint32_t gl = threadIdx.x & (NBR_GROUP - 1);
+    const uint32_t groups = gridDim.x * (blockDim.x / NBR_GROUP);
+    for (uint32_t k = blockIdx.x * (blockDim.x / NBR_GROUP) + threadIdx.x / NBR_GROUP; k < nkeys; k += groups) {
+        uint64_t o = nbr_start[k];
+        for (int j = -1; j < weight; j++) {
+            if (j >= 0 && !((tmask >> j) & 1u)) continue;
+            const uint32_t kk = j < 0 ? k : (k ^ (2u << (2 * j)));
+            const uint32_t b = bucket_start[kk], n = bucket_start[kk + 1] - b;
+            // 2 * n uint4 words, consecutive lanes take consecutive words (32 bytes per record, 16 per lane)
+            for (uint32_t i = gl; i < 2 * n; i += NBR_GROUP) ctx[2 * o + i] = by_index[2 * (size_t)b + i];
+            o += n;
+        }
+    }
+}
+
 void launch_nbr_fill_ctx(const uint32_t* bucket_start, const uint32_t* pos_table, uint32_t nkeys, uint32_t tmask, int weight,
-                         const uint64_t* nbr_start, const uint8_t* ref2, size_t ref2_stride, uint32_t seed_size, CtxRec* ctx, hipStream_t s) {
+                         const uint64_t* nbr_start, const uint8_t* ref2, size_t ref2_stride, uint32_t seed_size, CtxRec* ctx,
+                         CtxRec* scratch, uint32_t num_index, hipStream_t s) {
+    if (scratch) {
+        hipLaunchKernelGGL(ctx_by_index_kernel, dim3(8192), dim3(256), 0, s, pos_table, num_index, ref2, ref2_stride, seed_size,
+                           reinterpret_cast<uint4*>(scratch));
+        hipLaunchKernelGGL(nbr_copy_ctx_kernel, dim3(8192), dim3(256), 0, s, bucket_start, nkeys, tmask, weight, nbr_start,
+                           reinterpret_cast<const uint4*>(scratch), reinterpret_cast<uint4*>(ctx));
+        return;
+    }
     hipLaunchKernelGGL(nbr_fill_ctx_kernel, dim3(8192), dim3(256), 0, s, bucket_start, pos_table, nkeys, tmask, weight, nbr_start, ref2,
                        ref2_stride, seed_size, reinterpret_cast<uint4*>(ctx));
 }

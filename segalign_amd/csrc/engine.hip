@@ -1108,7 +1108,8 @@ static bool ensure_nbr(DevCtx* dc) {
     const double t_a = now();
     size_t free_b = 0, total_b = 0;
     hipMemGetInfo(&free_b, &total_b);
-    const size_t reserve = (size_t)8 << 30;  // keep 8 GiB for the slots' work buffers
+    // keep room for the slots' work buffers: at human-scale hit density a sixteen-chunk call holds ~6 GB of lists per slot
+    const size_t reserve = ((size_t)8 << 30) + ((size_t)4 << 30) * (size_t)SLOTS_PER_DEVICE;
     // (+ num_index records behind the table: scratch of the two-stage fill, part of the same allocation)
     const size_t need_ctx = (size_t)(std::max<uint64_t>(total, 1) + dc->num_index) * sizeof(CtxRec);
     const size_t need_pos = (size_t)std::max<uint64_t>(total, 1) * sizeof(uint32_t);

@@ -109,7 +109,7 @@ void sa_free_segments(sa_segment_pair* p);
  * iteration plan, own dedup scope, own header; NULL / 0 for a chunk without seeds).  Only the slots of the chunks the range
  * covers (ceil((end - start) / wga_chunk)) are written.  Returns the sum of the counts. */
 int sa_max_chunks_per_call(void);
-int sa_get_chunks_per_call(void);   /* chunks sa_seed_interval groups into one call (default = the maximum; env SEGALIGN_AMD_CHUNKS_PER_CALL) */
+int sa_get_chunks_per_call(void);   /* chunks sa_seed_interval groups into one call (option chunks_per_call) */
 size_t sa_seed_and_filter_chunks(uint32_t start, uint32_t end, int rev, uint32_t buffer, sa_segment_pair** outs, size_t* counts);
 
 struct sa_call_stats; /* defined below */
@@ -164,7 +164,39 @@ void sa_set_max_hits(int64_t max_hits);
 int64_t sa_get_max_hits(void);
 int sa_max_hits_for_mem(uint64_t total_global_mem);
 
+/* ---- options: the engine's one switchboard -------------------------------------------------------------------
+ * Every tunable and every switch of the engine lives in one table.  A value is resolved at each sa_initialize_processor:
+ * sa_set_option(name, v)  >  environment variable SEGALIGN_AMD_<NAME IN UPPER CASE>  >  default; values are clamped to the
+ * option's range.  sa_set_option returns -1 for an unknown name.  Results are bit-identical under every setting; the options
+ * choose between implementations of the same reference semantics (src/seed_filter.cu:682-828) or size their launches.
+ *
+ * Deployment options
+ *   slots             calls in flight per device (default 2, max 4; the reference allows 1: its token IS the device)
+ *   chunks_per_call   wga_chunk-sized chunks sa_seed_interval / sa_rm_mask_interval hand to one pass (default 16 = maximum)
+ *   no_ctx            1: neighbourhood table without target context (lookup mode 1)
+ *   no_td             1: no neighbourhood table (lookup mode 0: seed words -> buckets -> hit list, the reference's shape)
+ *   ctx32             1: 32-byte context records + pair-scoring context filter instead of 28-byte records + class filter
+ *   no_chain          1: every candidate is extended on its own (no chain shortcut, DESIGN.md 4.5')
+ *   no_packed_filter / no_fast_filter   1: fall back to the byte-coded / the exact per-base X-drop filter kernels
+ *   debug             1: table-build timings on stderr
+ * Launch geometry (defaults are the measured optima, tools/sweep_*.sh)
+ *   fin_batch, bufs_per_wave, long_cap, long_blocks, max_waves, packed_waves, l2_blocks, ctx_waves, ctx_threads, ctx_pipe,
+ *   chain_sort_threads, dedup_threads, nbr_one_stage
+ * Test-only options (small capacities that force the overflow / fallback branches of the orchestration)
+ *   l2_cap, spec_dedup, spec_recs, dedup_seg_max, no_small_dedup, chain_cap, audit_cap
+ */
+int sa_set_option(const char* name, int64_t value);
+int sa_reset_option(const char* name);     /* NULL: every option back to environment / default */
+int64_t sa_get_option(const char* name);   /* value resolved at the last sa_initialize_processor (INT64_MIN: unknown name) */
+int sa_option_count(void);
+const char* sa_option_name(int i, int* test_only /* nullable */);
+
 /* ---- introspection (tests, bench, profiling; not part of the reference surface) --------------------------- */
+
+/* With option audit_cap = N > 0: every hit the X-drop FILTER levels reject in a table-direct call is recorded (up to N per call).
+ * Returns how many the calling thread's last call recorded and copies min(that, cap_pairs) {ref_loc, query_loc} pairs.  The
+ * parity tests extend each of them with the oracle and require that none passes: the filters' bounds are upper bounds. */
+size_t sa_get_audit(uint32_t* dst_pairs, size_t cap_pairs);
 
 typedef struct sa_call_stats {
     uint64_t num_seeds;
@@ -189,8 +221,8 @@ int sa_get_filter_mode(void);
 /* Seed lookup path of the device-seeded entry points (sa_seed_and_filter_range / _chunks, sa_seed_interval,
  * sa_rm_mask_interval) on device 0: 0 = general path (seed words -> find_num_hits / find_hits shape, also used by the drop-in
  * sa_seed_and_filter), 1 = table-direct (neighbourhood table + position probe, no seed words, no hit list), 2 = table-direct
- * with target context in the table (the X-drop filter streams 32-byte records).  Chosen by available HBM;
- * SEGALIGN_AMD_NO_CTX=1 / SEGALIGN_AMD_NO_TD=1 force 1 / 0.  Results are identical on every path. */
+ * with target context in the table (the X-drop filter streams 28-byte records).  Chosen by available HBM;
+ * options no_ctx / no_td force 1 / 0.  Results are identical on every path. */
 int sa_get_lookup_mode(void);
 uint64_t sa_get_neighbourhood_entries(void); /* run entries of the neighbourhood table (0 when not built) */
 

@@ -181,6 +181,24 @@ def extend_hit(ref_codes, query_codes, sub_mat, ref_loc, query_loc, xdrop=910, h
     return bool(ok), tuple(int(x) for x in out[0]), ex.value
 
 
+def extend_hits_pass(ref_codes, query_codes, sub_mat, pairs, xdrop=910, hspthresh=3000, noentropy=False, log4_is_float=True):
+    """orc_extend_hit over many anchors (pairs[:, 0] = ref_loc, pairs[:, 1] = query_loc): bool array 'the hit passes' and the
+    records.  One parameter block for the whole batch (the per-call wrapper above rebuilds it every time)."""
+    ref_codes = np.ascontiguousarray(ref_codes, np.uint8)
+    query_codes = np.ascontiguousarray(query_codes, np.uint8)
+    sub_mat = np.ascontiguousarray(sub_mat, np.int32)
+    p = _ext_params(ref_codes, query_codes, sub_mat, xdrop, hspthresh, noentropy, log4_is_float)
+    pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+    ok = np.zeros(pairs.shape[0], dtype=bool)
+    out = np.zeros(pairs.shape[0], dtype=SEG_DTYPE)
+    ex = C.c_uint64(0)
+    f = lib().orc_extend_hit
+    base, step = out.ctypes.data, SEG_DTYPE.itemsize
+    for i in range(pairs.shape[0]):
+        ok[i] = bool(f(C.byref(p), int(pairs[i, 0]), int(pairs[i, 1]), base + i * step, C.addressof(ex)))
+    return ok, out
+
+
 def seed_and_filter(ref_codes, query_codes, index_table, pos_table, seeds, sub_mat, seed_size=19, xdrop=910,
                     hspthresh=3000, noentropy=False, max_hits=1 << 30, num_threads=0, log4_is_float=True,
                     rm=None):

@@ -113,14 +113,66 @@ __global__ __launch_bounds__(256) void pack2_phase_kernel(const uint8_t* __restr
 // dword-aligned ones do not: 0.55 -> 0.39 ms per 52 M hits for its load stream alone).
 __global__ __launch_bounds__(256) void pack4_phase_kernel(const uint8_t* __restrict__ codes, uint32_t len,
                                                           uint8_t* __restrict__ out, size_t copy_stride, uint32_t nbytes) {
-    const uint64_t total = (uint64_t)nbytes * PACK4_COPIES;
+    // Bytes BELOW 0 of a shifted copy hold real bases too (byte j of copy (k, s) starts at base 2 (j + s) + k, so bytes
+    // -s-1 .. -1 carry bases 0 .. 2 s + k - 1, and byte -s-1 of a k = 1 copy carries base 0 in its high nibble): the left
+    // windows of anchors near the block start read them, and a pad code there would cut a walk the reference continues.
+    const uint32_t span = nbytes + PACK4_FRONT;  // bytes [-PACK4_FRONT, nbytes) of every copy
+    const uint64_t total = (uint64_t)span * PACK4_COPIES;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t c = (uint32_t)(i / nbytes), j = (uint32_t)(i % nbytes);
+        const uint32_t c = (uint32_t)(i / span);
+        const int64_t j = (int64_t)(i % span) - PACK4_FRONT;
         const uint32_t k = c & 1u, sh = c >> 1;
-        const uint64_t p0 = ((uint64_t)j + sh) * 2 + k, p1 = p0 + 1;
-        const uint32_t c0 = p0 < len ? (codes[p0] & 7u) : 7u, c1 = p1 < len ? (codes[p1] & 7u) : 7u;
-        out[c * copy_stride + j] = (uint8_t)(c0 | (c1 << 4));
+        const int64_t p0 = (j + (int64_t)sh) * 2 + k, p1 = p0 + 1;
+        const uint32_t c0 = (p0 >= 0 && p0 < (int64_t)len) ? (codes[p0] & 7u) : 7u;
+        const uint32_t c1 = (p1 >= 0 && p1 < (int64_t)len) ? (codes[p1] & 7u) : 7u;
+        out[(int64_t)c * (int64_t)copy_stride + j] = (uint8_t)(c0 | (c1 << 4));
     }
+}
+
+// ---- 2-bit copies of a QUERY strand for the class filter (extend.hip 1d) --------------------------------------------------
+// Copy c = p + 4 s (p = base phase 0..3, s = byte shift 0..3): byte j holds bases [4 (j + s) + p, 4 (j + s) + p + 4), first base
+// in the low bits, codes >= 4 stored as 0, zero beyond the block.  A 64-base window that starts at ANY base position `pos` is
+// four DWORD-ALIGNED dwords of copy (pos & 3, (pos >> 2) & 3) at byte (pos >> 2) - ((pos >> 2) & 3): no byte-granular load
+// and no funnel shifts in the filter.  Each thread produces one dword of one copy from the 19 codes it spans.
+__global__ __launch_bounds__(256) void pack2_shifted_kernel(const uint8_t* __restrict__ codes, uint32_t len,
+                                                            uint8_t* __restrict__ out, size_t copy_stride) {
+    const uint32_t ndw = (uint32_t)(copy_stride / 4);
+    const uint64_t total = (uint64_t)ndw * Q2_COPIES;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t c = (uint32_t)(i / ndw), w = (uint32_t)(i % ndw);
+        const uint32_t p = c & 3u, sh = c >> 2;
+        const uint64_t b0 = ((uint64_t)w * 4 + sh) * 4 + p;  // first base of this dword
+        uint32_t v = 0;
+        if (b0 < len) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint64_t pos = b0 + k;
+                const uint32_t cd = pos < len ? codes[pos] : 0u;
+                v |= (cd < 4u ? cd : 0u) << (2 * k);
+            }
+        }
+        *reinterpret_cast<uint32_t*>(out + (size_t)c * copy_stride + (size_t)w * 4) = v;
+    }
+}
+
+// which of the 8 codes occur in a block: the class filter's score bounds only have to cover the codes that are there
+__global__ __launch_bounds__(256) void code_presence_kernel(const uint8_t* __restrict__ codes, uint32_t len, uint32_t* __restrict__ mask) {
+    uint32_t m = 0;
+    const uint32_t nvec = len / 16;
+    const uint4* in4 = reinterpret_cast<const uint4*>(codes);  // (the padded sequence buffers are 16-byte aligned)
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += gridDim.x * blockDim.x) {
+        const uint4 v = in4[i];
+        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) m |= 1u << ((d[j] >> (8 * b)) & 7u);
+    }
+    if (blockIdx.x == 0)
+        for (uint32_t i = nvec * 16 + threadIdx.x; i < len; i += blockDim.x) m |= 1u << (codes[i] & 7u);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m |= (uint32_t)__shfl_xor((int)m, off, 64);
+    if ((threadIdx.x & 63) == 0 && m) atomicOr(mask, m);
 }
 
 static inline int grid_for(uint64_t work_items, int block, int max_blocks = 256 * 8) {
@@ -150,7 +202,15 @@ void launch_pack2_phases(const uint8_t* codes, uint32_t len, uint8_t* out, size_
     hipLaunchKernelGGL(pack2_phase_kernel, dim3(grid_for((uint64_t)nphys * 4, 256)), dim3(256), 0, s, codes, len, out, copy_stride, nphys);
 }
 void launch_pack4_phases(const uint8_t* codes, uint32_t len, uint8_t* out, size_t copy_stride, uint32_t nbytes, hipStream_t s) {
-    hipLaunchKernelGGL(pack4_phase_kernel, dim3(grid_for((uint64_t)nbytes * PACK4_COPIES, 256)), dim3(256), 0, s, codes, len, out, copy_stride, nbytes);
+    hipLaunchKernelGGL(pack4_phase_kernel, dim3(grid_for((uint64_t)(nbytes + PACK4_FRONT) * PACK4_COPIES, 256)), dim3(256), 0, s, codes, len, out, copy_stride, nbytes);
+}
+size_t q2_copy_stride(uint32_t len) { return (((size_t)len / 4 + 1 + Q2_TAIL) + 127) & ~(size_t)127; }
+void launch_pack2_shifted(const uint8_t* codes, uint32_t len, uint8_t* out, size_t copy_stride, hipStream_t s) {
+    hipLaunchKernelGGL(pack2_shifted_kernel, dim3(grid_for((uint64_t)(copy_stride / 4) * Q2_COPIES, 256)), dim3(256), 0, s, codes, len, out, copy_stride);
+}
+void launch_code_presence(const uint8_t* codes, uint32_t len, uint32_t* mask, hipStream_t s) {
+    if (len == 0) return;
+    hipLaunchKernelGGL(code_presence_kernel, dim3(grid_for(len / 16 + 1, 256)), dim3(256), 0, s, codes, len, mask);
 }
 void launch_encode_rev_comp(const uint8_t* ascii, uint8_t* codes, uint8_t* codes_rc, uint32_t len, hipStream_t s) {
     // two streaming passes: the second reads the freshly written codes (L2 / Infinity Cache resident)

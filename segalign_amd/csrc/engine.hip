@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cctype>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -152,6 +153,13 @@ struct PackedBuf {  // phase copies of a packed sequence (packed X-drop filter):
         base = alloc + PACK_PAD;
         launch_pack4_phases(codes, len, base, stride, nbytes, s);
     }
+    // the sixteen shifted 2-bit copies of a query strand (class filter, encode.hip): every byte is written, no pads
+    void create_q2(const uint8_t* codes, uint32_t len, const char* tag, hipStream_t s) {
+        stride = q2_copy_stride(len);
+        reserve(stride * Q2_COPIES, tag);
+        base = alloc;
+        launch_pack2_shifted(codes, len, base, stride, s);
+    }
     void clear() {
         base = nullptr;
         stride = 0;
@@ -213,7 +221,8 @@ struct Counters {  // device-side scalars of one slot
     uint32_t n_heads; // run heads of the chain shortcut (this batch)
     uint32_t n_l2;    // hits the context filter handed to the second level (this batch)
     uint32_t n_l2_max;  // largest sub-list of them (compared with the sub-list capacity)
-    uint32_t pad2[3];
+    uint32_t n_audit;   // (tests) hits the filters rejected, see the audit option
+    uint32_t pad2[2];
 };
 
 struct Slot {
@@ -227,6 +236,7 @@ struct Slot {
     DevBuf<HspRec> recA, recB;
     DevBuf<CandRec> cand_list;
     DevBuf<L2Rec> l2_list;
+    DevBuf<uint2> audit;                    // (tests) rejected hits of the filter levels
     DevBuf<uint32_t> l2_counts, l2_prefix;  // sub-list counters (one 128-byte line each) and their prefix
     DevBuf<CandRec> chain_tmp, chain_sorted;  // chain shortcut of the exact stage
     DevBuf<uint32_t> chain_is_head, chain_heads, chain_bucket_cnt, chain_bucket_start;
@@ -241,6 +251,7 @@ struct Slot {
     DevBuf<uint32_t> td_tcnt;
     DevBuf<TdRec> td_rec;
     DevBuf<uint32_t> td_chunk;
+    DevBuf<uint32_t> td_bits;         // head-bit map of the call's hits (class filter)
     DevBuf<uint8_t> td_partial;
     void* d_td_bounds = nullptr;
     TdPlan* d_td_plan = nullptr;
@@ -276,7 +287,12 @@ struct DevCtx {
     const char* ref_host_ptr = nullptr;  // identity of the block last sent (to skip a second upload for the table)
     PackedBuf ref2;                      // 2-bit phase copies of the target (packed filter)
     PackedBuf query4[SA_BUFFER_DEPTH], query4_rc[SA_BUFFER_DEPTH];  // 4-bit phase copies of the query strands
+    PackedBuf query2[SA_BUFFER_DEPTH], query2_rc[SA_BUFFER_DEPTH];  // 2-bit shifted copies of the query strands (class filter)
     PackedBuf ref4, ref4_rc;             // repeat masker: the query IS the target
+    PackedBuf refq2, refq2_rc;           // ... and its 2-bit shifted copies
+    uint32_t* d_present = nullptr;       // code-presence masks on the device: [0] target, [1 + b] query buffer b
+    uint32_t ref_present = 0xFFu;        // which of the 8 codes occur in the resident target / query blocks (class_scores)
+    uint32_t query_present[SA_BUFFER_DEPTH] = {0xFFu, 0xFFu};
     SeqBuf ref_rc;                       // repeat masker
     uint32_t* bucket_start = nullptr;    // 4^k + 1
     uint32_t* pos_table = nullptr;
@@ -294,6 +310,8 @@ struct DevCtx {
     uint64_t* nbr_start = nullptr;       // nkeys + 1
     uint32_t* nbr_pos = nullptr;         // == pos_table when no transition word exists (nbr_alias); null when nbr_ctx is built
     CtxRec* nbr_ctx = nullptr;           // the runs WITH their target context (32 B per entry): context filter, extend.hip 1c
+    Ctx28* nbr_ctx28 = nullptr;          // ... or as 28-byte records + nbr_pos as the side array: class filter, extend.hip 1d (default)
+    bool nbr_pos_in_arena = false;       // nbr_pos lies inside the context allocation (not freed on its own)
     CtxRec* nbr_ctx_alloc = nullptr;     // its allocation outlives a target block (hipMalloc of 150 GB takes ~4 s): grow-only
     size_t nbr_ctx_cap = 0;              // bytes
     bool nbr_alias = false;
@@ -341,13 +359,40 @@ static int g_chain_sort_threads = 256;  // SEGALIGN_AMD_CHAIN_SORT_THREADS
 static int g_chunks_per_call = SA_MAX_CHUNKS;  // SEGALIGN_AMD_CHUNKS_PER_CALL: chunks sa_seed_interval hands to one multi-chunk call
 static int g_no_small_dedup = 0;  // SEGALIGN_AMD_NO_SMALL_DEDUP=1: always use the library sorts
 static int g_ctx = 1;             // neighbourhood table with target context when it fits (SEGALIGN_AMD_NO_CTX=1: positions only)
+static int g_ctx32 = 0;           // SEGALIGN_AMD_CTX32=1: 32-byte records + pair-scoring context filter (extend.hip 1c) instead of the class filter
+static uint32_t g_audit_cap = 0;  // SEGALIGN_AMD_AUDIT_CAP (tests): record up to this many hits the filter levels reject per call
 static int g_td = 1;              // table-direct lookup (neighbourhood table + position probe, probe.hip); SEGALIGN_AMD_NO_TD=1 turns it off
 static int g_chain = 1;           // chain shortcut of the exact stage (SEGALIGN_AMD_NO_CHAIN=1 turns it off)
 static uint32_t CHAIN_CAP = 1u << 22;  // candidates per batch the chain buffers hold (SEGALIGN_AMD_CHAIN_CAP); larger batches fall back
 static SeedShape g_shape = {0, 0, 0, {0}};
 static uint32_t g_query_len[SA_BUFFER_DEPTH] = {0, 0};
 
+static int64_t opt_value(const char* name);  // the option table (below)
+
 static thread_local sa_call_stats t_stats;
+static thread_local std::vector<uint2> t_audit;  // rejected hits of the calling thread's last hot call (audit option)
+
+// Class scores of the class filter (extend.hip 1d): cls[x] bounds every matrix entry a base pair with (target code ^ query
+// code) == x can have.  Codes >= 4 are stored as code 0 in the 2-bit copies, so a pair with such a code can show up in ANY
+// class: its score joins every cls[x] -- but only for the codes that actually occur in the two resident blocks.
+static void class_scores(uint32_t present_t, uint32_t present_q, int cls[4]) {
+    for (int x = 0; x < 4; x++) {
+        int m = INT32_MIN;
+        for (int r = 0; r < 4; r++) m = std::max(m, g_sub_mat[r * 8 + (r ^ x)]);
+        cls[x] = m;
+    }
+    bool any = false;
+    int na = INT32_MIN;
+    for (int r = 0; r < 8; r++)
+        for (int q = 0; q < 8; q++) {
+            if (r < 4 && q < 4) continue;
+            if (r >= 4 && !((present_t >> r) & 1u)) continue;
+            if (q >= 4 && !((present_q >> q) & 1u)) continue;
+            na = std::max(na, g_sub_mat[r * 8 + q]);
+            any = true;
+        }
+    if (any) for (int x = 0; x < 4; x++) cls[x] = std::max(cls[x], na);
+}
 
 static int max_hits_for_mem(uint64_t total_global_mem) {  // src/seed_filter.cu:832-841, literally
     float global_mem_gb = static_cast<float>(total_global_mem / 1073741824.0f);
@@ -441,13 +486,14 @@ static void slot_destroy(Slot& s) {
     s.out16.release("out16");
     s.cand_list.release("candidate list");
     s.l2_list.release("second-level list");
+    s.audit.release("audit list");
     s.l2_counts.release("second-level counters");
     s.l2_prefix.release("second-level prefix");
     s.chain_tmp.release("chain"); s.chain_sorted.release("chain"); s.chain_is_head.release("chain");
     s.chain_heads.release("chain"); s.chain_bucket_cnt.release("chain"); s.chain_bucket_start.release("chain"); s.ent_list.release("entropy list");
     s.cov_diff.release("coverage"); s.cov_pre.release("coverage"); s.cov_is_start.release("coverage");
     s.cov_is_end.release("coverage"); s.cov_sidx.release("coverage"); s.cov_eidx.release("coverage"); s.cov_pairs.release("coverage");
-    s.td_toff.release("probe"); s.td_tcnt.release("probe"); s.td_rec.release("probe"); s.td_chunk.release("probe"); s.td_partial.release("probe");
+    s.td_toff.release("probe"); s.td_tcnt.release("probe"); s.td_rec.release("probe"); s.td_chunk.release("probe"); s.td_bits.release("probe"); s.td_partial.release("probe");
     dev_free(s.d_td_bounds, "probe bounds"); dev_free(s.d_td_plan, "probe plan"); dev_free(s.d_seg_info, "segment info");
     s.d_td_bounds = nullptr; s.d_td_plan = nullptr; s.d_seg_info = nullptr;
     if (s.h_seg_info) hipHostFree(s.h_seg_info);
@@ -502,6 +548,10 @@ struct CoreArgs {
     // sa_extend_hits (introspection): sl->hits already holds raw_hits anchors; one iteration, no lookup, no dedup -- the
     // survivors of the extension stage (find_hsps + done-flag compaction) are returned as they are
     uint64_t raw_hits;
+    // class filter: 2-bit shifted copies of this call's strand and of the other strand, code presence of the query block
+    const PackedBuf* q2_own;
+    const PackedBuf* q2_other;
+    uint32_t q_present;
 };
 
 static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa_segment_pair** out) {
@@ -650,7 +700,15 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     ea.td_pos = dc->nbr_pos;
                     ea.td_ctx = dc->nbr_ctx;
                     ea.seed_size = g_seed_size;
-                    if (ea.td_ctx) {
+                    if (dc->nbr_ctx28 && ca.q2_own && ca.q2_own->base && ca.q2_other && ca.q2_other->base) {
+                        ea.td_ctx28 = dc->nbr_ctx28;
+                        ea.td_bits = reinterpret_cast<const uint64_t*>(sl->td_bits.p);
+                        ea.q2_own = ca.q2_own->base;
+                        ea.q2_other = ca.q2_other->base;
+                        ea.q2_stride = ca.q2_own->stride;
+                        class_scores(dc->ref_present, ca.q_present, ea.cls);
+                    }
+                    if (ea.td_ctx || ea.td_ctx28) {
                         // (a sub-list can take a whole chunk; SEGALIGN_AMD_L2_CAP: tests start small to reach the regrow-and-rerun path)
                         sl->l2_list.ensure(g_l2_cap_test ? (size_t)g_l2_cap_test
                                                          : (size_t)std::max<uint64_t>((uint64_t)L2_NSUB * TD_CHUNK_HITS, bh / 8), "second-level list");
@@ -739,7 +797,14 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                 before.n_heads = 0;
                 before.n_l2 = 0;
                 before.n_l2_max = 0;
-                check_memcpy(hipMemsetAsync(&sl->d_cnt->n_long, 0, 5 * sizeof(uint32_t), st), "counters");
+                check_memcpy(hipMemsetAsync(&sl->d_cnt->n_long, 0, 6 * sizeof(uint32_t), st), "counters");
+                if (g_audit_cap && ca.td) {
+                    sl->audit.ensure(g_audit_cap, "audit list");
+                    ea.audit_list = sl->audit.p;
+                    ea.audit_count = &sl->d_cnt->n_audit;
+                    ea.audit_cap = g_audit_cap;
+                }
+                before.n_audit = 0;
                 for (;;) {  // rerun the batch with larger lists if one overflowed (device writes are guarded)
                     ea.out = sl->recA.p;
                     ea.out_cap = (uint32_t)std::min<size_t>(sl->recA.cap, 0xFFFFFFFFu);
@@ -747,12 +812,12 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     ea.cand_cap_recs = (uint32_t)std::min<size_t>(sl->cand_list.cap, 0xFFFFFFFFu);
                     ea.ent_list = sl->ent_list.p;
                     ea.ent_cap_recs = (uint32_t)std::min<size_t>(sl->ent_list.cap, 0xFFFFFFFFu);
-                    if (ea.td && ea.td_ctx) {
-                        // context filter over the table's own 32-byte records, then the packed filter on what it could not decide
+                    if (ea.td && (ea.td_ctx || ea.td_ctx28)) {
+                        // context / class filter over the table's own records, then the packed filter on what it could not decide
                         ea.l2_list = sl->l2_list.p;
                         ea.l2_cap = (uint32_t)std::min<size_t>(sl->l2_list.cap / L2_NSUB, 0xFFFFFFu);  // per sub-list
                         check_memcpy(hipMemsetAsync(sl->l2_counts.p, 0, (size_t)L2_NSUB * L2_CNT_STRIDE * sizeof(uint32_t), st), "second-level counters");
-                        { ProfScope p(sl, "extend_filter"); launch_extend_filter_ctx(ea, st); }
+                        { ProfScope p(sl, "extend_filter"); if (ea.td_ctx28) launch_extend_filter_cls(ea, st); else launch_extend_filter_ctx(ea, st); }
                         ExtendArgs e2 = ea;
                         e2.td = 0;
                         e2.src_cand = 1;
@@ -804,7 +869,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                         check_sync(st, "extend (no chain)");
                     }
                     const Counters& c = *sl->h_cnt;
-                    const bool l2_ok = !(ea.td && ea.td_ctx) || c.n_l2_max <= ea.l2_cap;
+                    const bool l2_ok = !(ea.td && (ea.td_ctx || ea.td_ctx28)) || c.n_l2_max <= ea.l2_cap;
                     if (c.survivors <= ea.out_cap && c.n_long <= ea.cand_cap_recs && c.n_ent <= ea.ent_cap_recs && l2_ok) break;
                     if (!l2_ok)  // (the later stages saw a truncated list)
                         sl->l2_list.ensure((size_t)c.n_l2_max * L2_NSUB + ((size_t)c.n_l2_max * L2_NSUB) / 4, "second-level list(grow)");
@@ -821,6 +886,14 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                 survivors = sl->h_cnt->survivors;
                 n_cand_total += sl->h_cnt->n_long;
                 n_ent_total += sl->h_cnt->n_ent;
+            }
+            if (g_audit_cap && ca.td) {  // (tests) the rejected hits of the last batch
+                const uint32_t na = std::min(sl->h_cnt->n_audit, g_audit_cap);
+                t_audit.resize(na);
+                if (na) {
+                    check_memcpy(hipMemcpyAsync(t_audit.data(), sl->audit.p, (size_t)na * sizeof(uint2), hipMemcpyDeviceToHost, st), "audit");
+                    check_sync(st, "audit");
+                }
             }
             t_stats.num_examined = sl->h_cnt->examined;
             t_stats.num_examined_filter = sl->h_cnt->examined_filter;
@@ -1056,10 +1129,12 @@ __global__ void widen_u32_kernel(const uint32_t* __restrict__ in, uint64_t* __re
 
 static void nbr_release(DevCtx* dc) {
     dev_free(dc->nbr_start, "nbr_start");
-    if (!dc->nbr_alias) dev_free(dc->nbr_pos, "nbr_pos");
+    if (!dc->nbr_alias && !dc->nbr_pos_in_arena) dev_free(dc->nbr_pos, "nbr_pos");
     dc->nbr_start = nullptr;
     dc->nbr_pos = nullptr;
+    dc->nbr_pos_in_arena = false;
     dc->nbr_ctx = nullptr;  // (the allocation stays: nbr_ctx_alloc)
+    dc->nbr_ctx28 = nullptr;
     dc->nbr_alias = false;
     dc->nbr_total = 0;
     dc->nbr_state = 0;
@@ -1103,17 +1178,44 @@ static bool ensure_nbr(DevCtx* dc) {
             return false;
         }
     }
-    const bool dbg = getenv("SEGALIGN_AMD_DEBUG") != nullptr;
+    const bool dbg = opt_value("debug") != 0;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_a = now();
     size_t free_b = 0, total_b = 0;
-    hipMemGetInfo(&free_b, &total_b);
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = total_b = 0;  // (then only the plain lookup modes are tried)
     // keep room for the slots' work buffers: at human-scale hit density a sixteen-chunk call holds ~6 GB of lists per slot
     const size_t reserve = ((size_t)8 << 30) + ((size_t)4 << 30) * (size_t)SLOTS_PER_DEVICE;
+    const size_t need_pos = (size_t)std::max<uint64_t>(total, 1) * sizeof(uint32_t);
+    // 28-byte records + the side array of positions (class filter): 32 bytes per entry; the two-stage fill wants num_index
+    // records of scratch behind them, which is given up (one-stage fill) when only the table itself fits
+    const size_t rec28 = (((size_t)std::max<uint64_t>(total, 1) * sizeof(Ctx28)) + 255) & ~(size_t)255;
+    const size_t pos28 = (need_pos + 255) & ~(size_t)255;
+    const size_t scratch28 = (size_t)dc->num_index * sizeof(Ctx28);
     // (+ num_index records behind the table: scratch of the two-stage fill, part of the same allocation)
     const size_t need_ctx = (size_t)(std::max<uint64_t>(total, 1) + dc->num_index) * sizeof(CtxRec);
-    const size_t need_pos = (size_t)std::max<uint64_t>(total, 1) * sizeof(uint32_t);
-    if (g_ctx && dc->ref2.base && need_ctx + reserve <= free_b + dc->nbr_ctx_cap) {
+    if (g_ctx && !g_ctx32 && dc->ref2.base && rec28 + pos28 + reserve <= free_b + dc->nbr_ctx_cap) {
+        const bool two_stage = g_nbr_two_stage && tmask != 0 && rec28 + pos28 + scratch28 + reserve <= free_b + dc->nbr_ctx_cap;
+        const size_t need = rec28 + pos28 + (two_stage ? scratch28 : 0);
+        if (dc->nbr_ctx_cap < need) {
+            dev_free(dc->nbr_ctx_alloc, "nbr_ctx");
+            dc->nbr_ctx_alloc = nullptr;
+            dc->nbr_ctx_cap = 0;
+            dc->nbr_ctx_alloc = (CtxRec*)dev_malloc(need, "nbr_ctx");
+            dc->nbr_ctx_cap = need;
+        }
+        uint8_t* arena = reinterpret_cast<uint8_t*>(dc->nbr_ctx_alloc);
+        dc->nbr_ctx28 = reinterpret_cast<Ctx28*>(arena);
+        dc->nbr_pos = reinterpret_cast<uint32_t*>(arena + rec28);
+        dc->nbr_pos_in_arena = true;
+        if (dbg) fprintf(stderr, "neighbourhood table: %.1f M entries, hipMalloc of %.1f GB took %.1f ms\n", total / 1e6, need / 1e9, now() - t_a);
+        const double t_b = now();
+        launch_nbr_fill_ctx28(dc->bucket_start, dc->pos_table, nkeys, tmask, g_shape.weight, dc->nbr_start, dc->ref2.base, dc->ref2.stride,
+                              g_seed_size, dc->nbr_ctx28, dc->nbr_pos, two_stage ? reinterpret_cast<Ctx28*>(arena + rec28 + pos28) : nullptr,
+                              (uint32_t)dc->num_index, st);
+        check_launch("nbr fill ctx28");
+        check_sync(st, "nbr fill ctx28");
+        if (dbg) fprintf(stderr, "neighbourhood table: context fill (%s) took %.1f ms\n", two_stage ? "two-stage" : "one-stage", now() - t_b);
+    } else if (g_ctx && g_ctx32 && dc->ref2.base && need_ctx + reserve <= free_b + dc->nbr_ctx_cap) {
         // runs with their target context: 32 bytes per entry (33 GB for a 100 Mbp block with transitions)
         if (dc->nbr_ctx_cap < need_ctx) {
             dev_free(dc->nbr_ctx_alloc, "nbr_ctx");
@@ -1188,18 +1290,28 @@ static uint32_t td_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, int K, con
         ProfScope p(sl, "seed_probe");
         launch_probe_lookup(qcodes, start, n, sh, dc->nbr_start, dc->nkeys, sl->td_toff.p, sl->td_tcnt.p, sl->td_partial.p, st);
     }
-    {
-        ProfScope p(sl, "probe_compact");
-        launch_probe_compact(start, n, sl->td_toff.p, sl->td_tcnt.p, sl->td_partial.p, sl->d_td_bounds, sl->td_rec.p, sl->td_chunk.p, TD_CHUNK_CAP, tb, st);
+    // head-bit map for the class filter: sized for 64 hits per position; a denser call regrows it and repeats the compaction
+    const bool want_bits = dc->nbr_ctx28 != nullptr;
+    if (want_bits) sl->td_bits.ensure(std::max<size_t>((size_t)n * 2 + 64, 1u << 16), "probe head bits");
+    for (;;) {
+        {
+            ProfScope p(sl, "probe_compact");
+            launch_probe_compact(start, n, sl->td_toff.p, sl->td_tcnt.p, sl->td_partial.p, sl->d_td_bounds, sl->td_rec.p, sl->td_chunk.p, TD_CHUNK_CAP,
+                                 want_bits ? sl->td_bits.p : nullptr, (uint32_t)std::min<size_t>(sl->td_bits.cap, 0xFFFFFFFFu), tb, st);
+        }
+        {
+            ProfScope p(sl, "iteration_plan");
+            launch_probe_plan(qcodes, sh, tmask, dc->bucket_start, sl->d_td_bounds, K, sl->td_rec.p, sl->d_td_plan, st);
+        }
+        check_launch("probe");
+        check_memcpy(hipMemcpyAsync(sl->h_td_plan, sl->d_td_plan, sizeof(TdPlan) * K, hipMemcpyDeviceToHost, st), "probe plan");
+        check_memcpy(hipMemsetAsync(sl->d_cnt, 0, sizeof(Counters), st), "counters");
+        check_sync(st, "probe plan");
+        const uint64_t call_hits = sl->h_td_plan[K - 1].hit_base + sl->h_td_plan[K - 1].num_hits;
+        const uint64_t need_words = ((call_hits + 63) >> 6) * 2 + 16;  // (the filter reads up to six 64-bit words past the last buffer)
+        if (!want_bits || need_words <= sl->td_bits.cap || call_hits > 0xFFFFFFFFull) break;
+        sl->td_bits.ensure((size_t)need_words + need_words / 4, "probe head bits(grow)");
     }
-    {
-        ProfScope p(sl, "iteration_plan");
-        launch_probe_plan(qcodes, sh, tmask, dc->bucket_start, sl->d_td_bounds, K, sl->td_rec.p, sl->d_td_plan, st);
-    }
-    check_launch("probe");
-    check_memcpy(hipMemcpyAsync(sl->h_td_plan, sl->d_td_plan, sizeof(TdPlan) * K, hipMemcpyDeviceToHost, st), "probe plan");
-    check_memcpy(hipMemsetAsync(sl->d_cnt, 0, sizeof(Counters), st), "counters");
-    check_sync(st, "probe plan");
     uint64_t nvalid = 0;
     for (int c = 0; c < K; c++) {
         const TdPlan& tp = sl->h_td_plan[c];
@@ -1234,6 +1346,109 @@ static const uint8_t* upload_ascii(DevCtx* dc, const char* src, size_t len, cons
         hipEventRecord(dc->up_ev[k], st);
     }
     return dc->up_tmp.p;
+}
+
+// code presence of a freshly encoded block -> *host_mask (one small D2H; the callers synchronise the admin stream anyway)
+static void presence_of(DevCtx* dc, const uint8_t* codes, uint32_t len, int slot, uint32_t* host_mask) {
+    if (!dc->d_present) dc->d_present = (uint32_t*)dev_malloc((1 + SA_BUFFER_DEPTH) * sizeof(uint32_t), "code presence");
+    check_memcpy(hipMemsetAsync(dc->d_present + slot, 0, sizeof(uint32_t), dc->admin), "code presence");
+    launch_code_presence(codes, len, dc->d_present + slot, dc->admin);
+    check_memcpy(hipMemcpyAsync(host_mask, dc->d_present + slot, sizeof(uint32_t), hipMemcpyDeviceToHost, dc->admin), "code presence");
+}
+static void set_query2(CoreArgs& ca, DevCtx* dc, uint32_t buffer, int rev) {  // plain calls: strand copies of query buffer `buffer`
+    ca.q2_own = rev ? &dc->query2_rc[buffer] : &dc->query2[buffer];
+    ca.q2_other = rev ? &dc->query2[buffer] : &dc->query2_rc[buffer];
+    ca.q_present = dc->query_present[buffer];
+}
+static void set_query2_rm(CoreArgs& ca, DevCtx* dc, int rev) {  // repeat masker: the query is the target
+    ca.q2_own = rev ? &dc->refq2_rc : &dc->refq2;
+    ca.q2_other = rev ? &dc->refq2 : &dc->refq2_rc;
+    ca.q_present = dc->ref_present;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// options: ONE table for every tunable / switch of the engine (documented in include/segalign_amd.h, sa_set_option).
+// Resolution at every InitializeProcessor: value set through sa_set_option > environment SEGALIGN_AMD_<NAME> > default.
+// ------------------------------------------------------------------------------------------------------------------
+struct Option {
+    const char* name;
+    int64_t def, lo, hi;
+    int test_only;      // 1: exists to reach a code path from the test matrix; 0: deployment tuning
+    int64_t value;      // resolved value
+    int64_t api_value;
+    bool api_set;
+};
+static Option g_opts[] = {
+    // deployment
+    {"slots", 2, 1, MAX_SLOTS_PER_DEVICE, 0},          // calls in flight per device (the reference allows one: token == device)
+    {"chunks_per_call", SA_MAX_CHUNKS, 1, SA_MAX_CHUNKS, 0},  // chunks sa_seed_interval / sa_rm_mask_interval hand to one pass
+    {"no_ctx", 0, 0, 1, 0},                            // 1: neighbourhood table without target context (lookup mode 1)
+    {"no_td", 0, 0, 1, 0},                             // 1: no neighbourhood table at all (lookup mode 0, the reference-shaped path)
+    {"no_chain", 0, 0, 1, 0},                          // 1: every candidate is extended on its own (no chain shortcut)
+    {"no_packed_filter", 0, 0, 1, 0},                  // 1: byte-coded filter kernels only (also disables table-direct lookup)
+    {"no_fast_filter", 0, 0, 1, 0},                    // 1: exact per-base filter only
+    {"ctx32", 0, 0, 1, 0},                             // 1: 32-byte context records + pair-scoring context filter (round-2 form)
+    {"debug", 0, 0, 1, 0},                             // 1: table-build timings on stderr
+    // launch geometry (swept by tools/sweep_*.sh; the defaults are the measured optima)
+    {"fin_batch", 48, 1, 64, 0}, {"bufs_per_wave", 8, 1, 1 << 20, 0}, {"long_cap", 128, 0, 2 * PACK_PAD, 0},
+    {"long_blocks", 1792, 1, 1 << 20, 0}, {"max_waves", 4096, 4, 1 << 20, 0}, {"packed_waves", 4096, 8, 1 << 20, 0},
+    {"l2_blocks", 512, 1, 1 << 20, 0}, {"ctx_waves", 0, 0, 1 << 20, 0}, {"ctx_threads", 0, 0, 1024, 0},
+    {"ctx_pipe", 1, 1, 2, 0}, {"chain_sort_threads", 256, 64, 512, 0}, {"dedup_threads", 0, 0, 1024, 0},
+    {"nbr_one_stage", 0, 0, 1, 0},
+    // test-only: small capacities that force the overflow / fallback branches
+    {"l2_cap", 0, 0, 1 << 30, 1}, {"spec_dedup", 1, 0, 1, 1}, {"spec_recs", 16384, 1, 16384, 1}, {"dedup_seg_max", 0, 0, 1 << 30, 1},
+    {"no_small_dedup", 0, 0, 1, 1}, {"chain_cap", 1 << 22, 1, 1 << 30, 1}, {"audit_cap", 0, 0, 1 << 28, 1},
+};
+static Option* find_option(const char* name) {
+    for (auto& o : g_opts)
+        if (strcmp(o.name, name) == 0) return &o;
+    return nullptr;
+}
+static int64_t opt_value(const char* name) {
+    Option* o = find_option(name);
+    return o ? o->value : 0;
+}
+static void resolve_options() {
+    for (auto& o : g_opts) {
+        int64_t v = o.def;
+        char env[96] = "SEGALIGN_AMD_";
+        size_t n = strlen(env);
+        for (const char* c = o.name; *c && n + 1 < sizeof(env); c++) env[n++] = (char)toupper((unsigned char)*c);
+        env[n] = '\0';
+        if (o.api_set) v = o.api_value;
+        else if (const char* e = getenv(env)) {
+            char* endp = nullptr;
+            v = strtoll(e, &endp, 10);
+            if (endp == e) v = 1;  // a switch set to a non-number ("yes") counts as on
+        }
+        o.value = std::max(o.lo, std::min(o.hi, v));
+    }
+    SLOTS_PER_DEVICE = (int)opt_value("slots");
+    g_chunks_per_call = (int)opt_value("chunks_per_call");
+    g_ctx = opt_value("no_ctx") ? 0 : 1;
+    g_td = opt_value("no_td") ? 0 : 1;
+    g_chain = opt_value("no_chain") ? 0 : 1;
+    g_ctx32 = (int)opt_value("ctx32");
+    g_fin_batch = (int)opt_value("fin_batch");
+    g_bufs_per_wave = (int)opt_value("bufs_per_wave");
+    g_long_cap = (int)opt_value("long_cap") & ~7;
+    g_long_blocks = (int)opt_value("long_blocks");
+    g_max_waves = (int)opt_value("max_waves");
+    g_packed_waves = (int)opt_value("packed_waves");
+    g_l2_blocks = (int)opt_value("l2_blocks");
+    g_ctx_waves = (int)opt_value("ctx_waves");
+    g_ctx_threads = (int)opt_value("ctx_threads");
+    g_ctx_pipe = (int)opt_value("ctx_pipe");
+    g_chain_sort_threads = (int)opt_value("chain_sort_threads") & ~63;
+    g_dedup_threads = (int)opt_value("dedup_threads");
+    g_nbr_two_stage = opt_value("nbr_one_stage") ? 0 : 1;
+    g_l2_cap_test = opt_value("l2_cap") ? (uint32_t)std::max<int64_t>(L2_NSUB, opt_value("l2_cap")) : 0u;
+    g_spec_dedup = (int)opt_value("spec_dedup");
+    SPEC_RECS = (uint32_t)opt_value("spec_recs");
+    g_dedup_seg_max = (uint32_t)opt_value("dedup_seg_max");
+    g_no_small_dedup = (int)opt_value("no_small_dedup");
+    CHAIN_CAP = (uint32_t)opt_value("chain_cap");
+    g_audit_cap = (uint32_t)opt_value("audit_cap");
 }
 
 static void require_init(const char* who) {
@@ -1315,27 +1530,7 @@ int sa_initialize_interface(int num_gpu) {  // seed_filter_interface.cu:49-80
 void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_size, const int* sub_mat, int xdrop,
                              int hspthresh, int noentropy) {  // src/seed_filter.cu:830-897
     require_init("InitializeProcessor");
-    if (const char* e = getenv("SEGALIGN_AMD_SLOTS")) SLOTS_PER_DEVICE = std::max(1, std::min(MAX_SLOTS_PER_DEVICE, atoi(e)));
-    if (const char* e = getenv("SEGALIGN_AMD_FIN_BATCH")) g_fin_batch = std::max(1, std::min(64, atoi(e)));
-    if (const char* e = getenv("SEGALIGN_AMD_BUFS_PER_WAVE")) g_bufs_per_wave = std::max(1, atoi(e));
-    if (const char* e = getenv("SEGALIGN_AMD_LONG_CAP")) g_long_cap = std::max(0, atoi(e)) & ~7;
-    if (const char* e = getenv("SEGALIGN_AMD_LONG_BLOCKS")) g_long_blocks = std::max(1, atoi(e));
-    if (const char* e = getenv("SEGALIGN_AMD_MAX_WAVES")) g_max_waves = std::max(4, atoi(e));
-    if (const char* e = getenv("SEGALIGN_AMD_PACKED_WAVES")) g_packed_waves = std::max(8, atoi(e));
-    if (const char* e = getenv("SEGALIGN_AMD_L2_BLOCKS")) g_l2_blocks = std::max(1, atoi(e));
-    if (const char* e = getenv("SEGALIGN_AMD_CTX_WAVES")) g_ctx_waves = std::max(0, atoi(e));
-    g_ctx_pipe = 1;
-    if (const char* e = getenv("SEGALIGN_AMD_CTX_PIPE")) g_ctx_pipe = atoi(e);
-    g_l2_cap_test = 0;
-    if (const char* e = getenv("SEGALIGN_AMD_L2_CAP")) g_l2_cap_test = (uint32_t)std::max(L2_NSUB, atoi(e));
-    if (const char* e = getenv("SEGALIGN_AMD_CTX_THREADS")) g_ctx_threads = std::max(0, atoi(e));
-    g_spec_dedup = 1;
-    if (const char* e = getenv("SEGALIGN_AMD_SPEC_DEDUP")) g_spec_dedup = atoi(e) != 0;
-    SPEC_RECS = 16384;
-    if (const char* e = getenv("SEGALIGN_AMD_SPEC_RECS")) SPEC_RECS = (uint32_t)std::max(1, std::min(16384, atoi(e)));
-    g_dedup_seg_max = 0;
-    if (const char* e = getenv("SEGALIGN_AMD_DEDUP_SEG_MAX")) g_dedup_seg_max = (uint32_t)std::max(1, atoi(e));
-    if (const char* e = getenv("SEGALIGN_AMD_DEDUP_THREADS")) g_dedup_threads = std::max(0, atoi(e));
+    resolve_options();
     if (xdrop >= (1 << 25) || xdrop <= -(1 << 25)) {
         fprintf(stderr, "Error: |xdrop| must be below 2^25\n");
         exit(1);
@@ -1358,19 +1553,8 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
         // the 4-bit query copies carry PACK_PAD bytes = 2 * PACK_PAD bases of padding: a capped walk must end inside it
         if (g_long_cap > 2 * PACK_PAD) g_long_cap = 2 * PACK_PAD;
         g_packed_filter = (xdrop >= 0 && xdrop <= 16383 && (int64_t)std::max(mx, 0) * (((int64_t)g_long_cap + 63) / 64 * 64) <= 16383 &&
-                           !getenv("SEGALIGN_AMD_NO_PACKED_FILTER")) ? 1 : 0;
-        if (getenv("SEGALIGN_AMD_NO_FAST_FILTER")) { g_fast_filter = 0; g_packed_filter = 0; }
-        g_chain = getenv("SEGALIGN_AMD_NO_CHAIN") ? 0 : 1;
-        g_td = getenv("SEGALIGN_AMD_NO_TD") ? 0 : 1;
-        g_ctx = getenv("SEGALIGN_AMD_NO_CTX") ? 0 : 1;
-        g_nbr_two_stage = getenv("SEGALIGN_AMD_NBR_ONE_STAGE") ? 0 : 1;
-        g_chain_sort_threads = 256;
-        if (const char* e = getenv("SEGALIGN_AMD_CHAIN_SORT_THREADS")) g_chain_sort_threads = std::max(64, std::min(512, atoi(e) & ~63));
-        if (const char* e = getenv("SEGALIGN_AMD_CHAIN_CAP")) CHAIN_CAP = (uint32_t)std::max(1, atoi(e));
-        else CHAIN_CAP = 1u << 22;
-        g_no_small_dedup = getenv("SEGALIGN_AMD_NO_SMALL_DEDUP") ? 1 : 0;
-        g_chunks_per_call = SA_MAX_CHUNKS;
-        if (const char* e = getenv("SEGALIGN_AMD_CHUNKS_PER_CALL")) g_chunks_per_call = std::max(1, std::min(SA_MAX_CHUNKS, atoi(e)));
+                           !opt_value("no_packed_filter")) ? 1 : 0;
+        if (opt_value("no_fast_filter")) { g_fast_filter = 0; g_packed_filter = 0; }
     }
     std::lock_guard<std::mutex> lk(g_mu);
     g_tokens.clear();
@@ -1401,6 +1585,10 @@ static void release_device_state(DevCtx* dc) {
     dc->ref_rc.release("d_seq_rc");
     dc->ref4.release("d_seq 4-bit");
     dc->ref4_rc.release("d_seq_rc 4-bit");
+    dc->refq2.release("d_seq 2-bit shifted");
+    dc->refq2_rc.release("d_seq_rc 2-bit shifted");
+    dev_free(dc->d_present, "code presence");
+    dc->d_present = nullptr;
     dc->ref_host_ptr = nullptr;
     nbr_release(dc);
     dev_free(dc->nbr_ctx_alloc, "nbr_ctx");
@@ -1415,6 +1603,8 @@ static void release_device_state(DevCtx* dc) {
         dc->query_rc[b].release("d_query_rc_seq");
         dc->query4[b].release("d_query_seq 4-bit");
         dc->query4_rc[b].release("d_query_rc_seq 4-bit");
+        dc->query2[b].release("d_query_seq 2-bit");
+        dc->query2_rc[b].release("d_query_rc_seq 2-bit");
     }
     dc->up_tmp.release("upload staging");
     for (int k = 0; k < 2; k++) {
@@ -1462,9 +1652,11 @@ void sa_send_ref_write_request(const char* seq, size_t addr, uint32_t len) {  //
         dc->ref8.create(len, "ref_seq rows", dc->admin, true);
         launch_row_code(dc->ref.codes, dc->ref8.codes, len, dc->admin);
         dc->ref2.create(dc->ref.codes, len, 2, "ref_seq 2-bit", dc->admin);
+        presence_of(dc, dc->ref.codes, len, 0, &dc->ref_present);
         check_launch("compress_string");
         check_sync(dc->admin, "SendRefWriteRequest");
         dc->ref_host_ptr = seq + addr;
+        nbr_release(dc);  // a neighbourhood table built for another block must not survive (its context records are target bases)
     }
 }
 
@@ -1583,6 +1775,9 @@ void sa_send_query_write_request(const char* query_buffer, size_t addr, uint32_t
         launch_encode_rev_comp(tmp, dc->query[buffer].codes, dc->query_rc[buffer].codes, len, st);
         dc->query4[buffer].create(dc->query[buffer].codes, len, 4, "query_seq 4-bit", st);
         dc->query4_rc[buffer].create(dc->query_rc[buffer].codes, len, 4, "query_rc_seq 4-bit", st);
+        dc->query2[buffer].create_q2(dc->query[buffer].codes, len, "query_seq 2-bit", st);
+        dc->query2_rc[buffer].create_q2(dc->query_rc[buffer].codes, len, "query_rc_seq 2-bit", st);
+        presence_of(dc, dc->query[buffer].codes, len, 1 + (int)buffer, &dc->query_present[buffer]);
         check_launch("compress_string_rev_comp");
         check_sync(st, "SendQueryWriteRequest");
     }
@@ -1597,6 +1792,8 @@ void sa_clear_query(uint32_t buffer) {  // :921-930
         dc->query_rc[buffer].clear();
         dc->query4[buffer].clear();
         dc->query4_rc[buffer].clear();
+        dc->query2[buffer].clear();
+        dc->query2_rc[buffer].clear();
     }
 }
 
@@ -1615,6 +1812,7 @@ size_t sa_seed_and_filter(const uint64_t* seeds, size_t num_seeds, int rev, uint
     upload_seeds(sl, seeds, num_seeds);
     CoreArgs ca = {rev ? dc->query_rc[buffer].codes : dc->query[buffer].codes, g_query_len[buffer], 0, 0, 0, 0, 0, 0, nullptr, 0,
                    rev ? &dc->query4_rc[buffer] : &dc->query4[buffer]};  // :762-767
+    set_query2(ca, dc, buffer, rev);
     size_t n = saf_core(dc, sl, (uint32_t)num_seeds, ca, out);
     release_slot(sl);
     return n;
@@ -1642,6 +1840,7 @@ size_t sa_seed_and_filter_range(uint32_t start, uint32_t end, int rev, uint32_t 
     *out = nullptr;
     if (ns > 0) {  // seeder.cpp:76: the engine is only called for a non-empty seed vector
         CoreArgs ca = {q, qlen, 0, 0, 0, 0, start, end, nullptr, 0, q4};
+        set_query2(ca, dc, buffer, rev);
         ca.td = td ? 1 : 0;
         ca.td_words = words;
         n = saf_core(dc, sl, ns, ca, out);
@@ -1689,6 +1888,7 @@ size_t sa_seed_and_filter_chunks(uint32_t start, uint32_t end, int rev, uint32_t
     size_t total = 0;
     if (ns > 0) {
         CoreArgs ca = {q, qlen, 0, 0, 0, 0, start, send, nullptr, 0, q4};
+        set_query2(ca, dc, buffer, rev);
         ca.nchunks = K;
         ca.td = td ? 1 : 0;
         ca.td_words = words;
@@ -1728,6 +1928,7 @@ size_t sa_extend_hits(const uint32_t* ref_query_pairs, size_t num_hits, int rev,
         check_memcpy(hipMemcpyAsync(sl->hits.p, ref_query_pairs, num_hits * sizeof(Hit), hipMemcpyHostToDevice, sl->stream), "hits");
         CoreArgs ca = {rev ? dc->query_rc[buffer].codes : dc->query[buffer].codes, g_query_len[buffer], 0, 0, 0, 0, 0, 0, nullptr, 0,
                        rev ? &dc->query4_rc[buffer] : &dc->query4[buffer]};
+        set_query2(ca, dc, buffer, rev);
         ca.raw_hits = num_hits;
         n = saf_core(dc, sl, 1, ca, out);
     }
@@ -1842,6 +2043,8 @@ void sa_rm_send_query_write_request(void) {  // rm :951-961
         launch_rev_comp_codes(dc->ref.codes, dc->ref_rc.codes, dc->ref.len, dc->admin);
         dc->ref4.create(dc->ref.codes, dc->ref.len, 4, "seq 4-bit", dc->admin);
         dc->ref4_rc.create(dc->ref_rc.codes, dc->ref.len, 4, "seq_rc 4-bit", dc->admin);
+        dc->refq2.create_q2(dc->ref.codes, dc->ref.len, "seq 2-bit shifted", dc->admin);
+        dc->refq2_rc.create_q2(dc->ref_rc.codes, dc->ref.len, "seq_rc 2-bit shifted", dc->admin);
         check_launch("rev_comp_string");
         check_sync(dc->admin, "SendQueryWriteRequest");
     }
@@ -1852,6 +2055,8 @@ void sa_rm_clear_query(void) {  // rm :964-972
         dc->ref_rc.release("d_seq_rc");
         dc->ref4.release("d_seq 4-bit");
         dc->ref4_rc.release("d_seq_rc 4-bit");
+        dc->refq2.release("d_seq 2-bit shifted");
+        dc->refq2_rc.release("d_seq_rc 2-bit shifted");
     }
 }
 size_t sa_rm_seed_and_filter(const uint64_t* seeds, size_t num_seeds, int rev, uint32_t ref_start, uint32_t ref_end,
@@ -1869,6 +2074,7 @@ size_t sa_rm_seed_and_filter(const uint64_t* seeds, size_t num_seeds, int rev, u
     upload_seeds(sl, seeds, num_seeds);
     CoreArgs ca = {rev ? dc->ref_rc.codes : dc->ref.codes, dc->ref.len, 1, rev ? 1 : 0, ref_start, ref_end, 0, 0, nullptr, 0,
                    rev ? &dc->ref4_rc : &dc->ref4};  // rm :805-810
+    set_query2_rm(ca, dc, rev);
     size_t n = saf_core(dc, sl, (uint32_t)num_seeds, ca, out);
     release_slot(sl);
     return n;
@@ -2019,6 +2225,7 @@ size_t sa_rm_mask_interval(uint32_t start_pos, uint32_t end_pos, uint32_t ref_st
             if (!td) ns = device_seeds(sl, q, rs[a].s0, rs[a].s1);
             if (ns != 0) {  // :103,140
                 CoreArgs ca = {q, block_len, 1, rev, ref_start, ref_end, bp[0], bp[Kc], sl->cov_diff.p, block_len + 1, q4};
+                set_query2_rm(ca, dc, rev);
                 ca.td = td ? 1 : 0;
                 ca.td_words = words;
                 if (Kc > 1) {
@@ -2074,6 +2281,42 @@ void sa_set_max_hits(int64_t max_hits) {
     }
 }
 int64_t sa_get_max_hits(void) { return g_max_hits; }
+
+// One documented switchboard (include/segalign_amd.h): takes effect at the next InitializeProcessor.
+int sa_set_option(const char* name, int64_t value) {
+    Option* o = name ? find_option(name) : nullptr;
+    if (!o) return -1;
+    o->api_value = value;
+    o->api_set = true;
+    return 0;
+}
+int sa_reset_option(const char* name) {  // back to environment / default; NULL resets every option
+    if (!name) {
+        for (auto& o : g_opts) o.api_set = false;
+        return 0;
+    }
+    Option* o = find_option(name);
+    if (!o) return -1;
+    o->api_set = false;
+    return 0;
+}
+int64_t sa_get_option(const char* name) {  // the value the engine resolved at the last InitializeProcessor
+    Option* o = name ? find_option(name) : nullptr;
+    return o ? o->value : INT64_MIN;
+}
+int sa_option_count(void) { return (int)(sizeof(g_opts) / sizeof(g_opts[0])); }
+const char* sa_option_name(int i, int* test_only) {
+    if (i < 0 || i >= sa_option_count()) return nullptr;
+    if (test_only) *test_only = g_opts[i].test_only;
+    return g_opts[i].name;
+}
+// (tests, option audit_cap) the hits the X-drop filter levels REJECTED in the calling thread's last table-direct call, as
+// {ref_loc, query_loc} pairs; returns how many were recorded (<= audit_cap)
+size_t sa_get_audit(uint32_t* dst_pairs, size_t cap_pairs) {
+    const size_t n = std::min(cap_pairs, t_audit.size());
+    if (n) memcpy(dst_pairs, t_audit.data(), n * sizeof(uint2));
+    return t_audit.size();
+}
 int sa_max_hits_for_mem(uint64_t total_global_mem) { return max_hits_for_mem(total_global_mem); }
 
 // ---- introspection --------------------------------------------------------------------------------------------------
@@ -2088,7 +2331,7 @@ int sa_get_lookup_mode(void) {  // how device-seeded calls look seeds up on devi
     DevCtx* dc = g_dev[0];
     check_set_device(dc->dev, "lookup mode");
     if (!(g_td && g_packed_filter && !g_count_examined && dc->ref2.base && ensure_nbr(dc))) return 0;
-    return dc->nbr_ctx ? 2 : 1;
+    return (dc->nbr_ctx || dc->nbr_ctx28) ? 2 : 1;
 }
 uint64_t sa_get_neighbourhood_entries(void) { return (g_ndev > 0 && g_dev[0]->nbr_state == 1) ? g_dev[0]->nbr_total : 0; }
 void sa_profile_enable(int on) { g_prof_on = on != 0; }

@@ -736,6 +736,11 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
                 cr.ref_loc = ref_loc; cr.query_loc = query_loc; cr.hidx = hidx;
                 stage_append(stage, n_stage, cand, cr, a.cand_list, a.cand_count, a.cand_cap_recs, lane, lane_lt);
             }
+            if (a.audit_list) {  // (tests) the hits this level rejects
+                uint2 ar;
+                ar.x = ref_loc; ar.y = query_loc;
+                wave_append(phase == PH_FIN && has_hit && !cand, ar, a.audit_list, a.audit_count, a.audit_cap, lane, lane_lt);
+            }
             unsigned long long need = fin;
             bool got = false;
             Hit mine = {0u, 0u};
@@ -1016,6 +1021,233 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, PIPE == 2 ? 4 : 8) void extend_fil
             request_query(b, A);
             score(b, A);
         }
+    }
+    stage_flush(stage, n_stage, my_list, my_count, a.l2_cap, lane);
+}
+
+// =====================================================================================================================
+// 1d. the X-drop filter on 28-byte context records with CLASS scoring: 6 bases per table lookup
+// =====================================================================================================================
+// 1c is bound by instruction issue: two bases per LDS lookup, ~39 VALU + 8 LDS per 16 bases, 7 lockstep steps per hit
+// (profiles/r02: 365 VALU + 68 LDS wave-instructions per 64 hits, 0.49 of the HBM peak by counter bytes).  The filter
+// only needs an UPPER bound of every walk, and the pair score is bounded by a function of (target code XOR query code) alone:
+//     x = t ^ q :  0 = same base,  2 = transition (A<->G, C<->T),  1 / 3 = the two transversion classes,
+//     cls[x] = max of the matrix entries of that class (engine.hip class_scores(): for HOXD70 100 / -114 / -31 / -123 against
+//     the exact 91..100 / -114 / -31 / -123..-125 -- the drift of a random walk is -42.0 instead of -43.4 per base).
+// With target AND query at 2 bits per base one XOR per 16 bases yields the class string, and a 12-bit field of it -- SIX bases
+// -- indexes a 4096-entry table {sum of the six scores, maximum prefix sum}: 19 lookups per hit instead of 56, no byte permutes.
+// The walk is kept as (T, D): T = running score, D = best - T (the current drop):
+//     D = max(D, e.mx) - e.sum;  T += e.sum;  dropped |= D > xdrop          (4 VALU + 1 ds_read_b64 per six bases)
+// The drop test is looked at after every field; a side that has dropped is NOT frozen -- it walks on to the end of its context,
+// which can only raise its best score (still an upper bound, and the wave runs straight-line code: all 19 table reads of a
+// buffer are independent of the scores and are issued up front).  Why the bound holds: with u_i >= s_i pointwise the bounded
+// walk's drop max_i<=k(Q_i) - Q_k never exceeds the exact walk's, so it cannot stop earlier, and its best is taken over a
+// superset of positions.  Codes >= 4 (soft-masked, N, separators, other IUPAC letters) are stored as code 0 on both sides;
+// cls[] covers every matrix entry such a pair could have had, for the codes that occur in the two blocks (engine.hip).
+// Verdicts are those of 1c; a hit whose bound passes with both sides settled is sent to the second level as "walk both sides"
+// (flags 3), so the exact pair scoring of 1b gets a say before the hit becomes a candidate of the exact stage.
+// Records: Ctx28 (kernels.h) -- the stream is 28 bytes per hit; the seed position lives in a side array that only forwarded
+// hits (~4 %) and the repeat masker's window test read.
+constexpr int CLS_TAB = 4096;                       // 12-bit fields: six bases
+constexpr int CLS_TAIL = 256;                       // the left context ends with a four-base field (64 = 10 x 6 + 4)
+constexpr int CLS_LDS_DWORDS = 2 * (CLS_TAB + CLS_TAIL);
+
+__device__ __forceinline__ void cls_table_init(uint32_t* __restrict__ s_cls, const int* cls, int nthreads) {
+    const int c0 = cls[0], c1 = cls[1], c2 = cls[2], c3 = cls[3];
+    for (int i = threadIdx.x; i < CLS_TAB + CLS_TAIL; i += nthreads) {
+        const int nb = i < CLS_TAB ? 6 : 4;
+        const int f = i < CLS_TAB ? i : i - CLS_TAB;
+        int sum = 0, mx = INT32_MIN;
+        for (int k = 0; k < nb; k++) {
+            const int x = (f >> (2 * k)) & 3;
+            sum += x == 0 ? c0 : x == 1 ? c1 : x == 2 ? c2 : c3;
+            mx = max(mx, sum);
+        }
+        s_cls[2 * i] = (uint32_t)sum;
+        s_cls[2 * i + 1] = (uint32_t)mx;
+    }
+}
+
+// byte address (inside a table of 8-byte entries) of the 12-bit field that starts at bit O of the dword string w0 | w1 << 32
+template <int O>
+__device__ __forceinline__ uint32_t cls_field_addr(uint32_t w0, uint32_t w1) {
+    constexpr uint32_t MASK = 0x7FF8u;
+    if (O + 12 <= 32) return O >= 3 ? ((w0 >> (O - 3)) & MASK) : ((w0 << (3 - O)) & MASK);
+    return __builtin_amdgcn_alignbit(w1, w0, (uint32_t)(O - 3)) & MASK;  // the field straddles the two dwords
+}
+
+__device__ __forceinline__ uint32_t mul24(uint32_t x, uint32_t s_uniform) {  // full-rate 24-bit multiply (v_mul_lo_u32 is quarter rate)
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "s"(s_uniform), "v"(x));
+    return r;
+}
+
+__device__ __forceinline__ void cls_step(const uint32_t* __restrict__ s_tab, uint32_t addr, int xdrop, int& T, int& D, bool& dropped) {
+    const uint2 e = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(s_tab) + addr);  // one ds_read_b64
+    D = max(D, (int)e.y) - (int)e.x;
+    T += (int)e.x;
+    dropped = dropped || (D > xdrop);  // :374 / :523, looked at every six bases
+}
+
+__global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(ExtendArgs a) {
+    __shared__ uint32_t s_cls[CLS_LDS_DWORDS];  // {sum, max prefix} of every 6-base class field (32 KB) + the 4-base tail fields (2 KB)
+    extern __shared__ L2Rec s_l2_dyn[];          // [waves of the workgroup][CTX_STAGE_CAP]
+    cls_table_init(s_cls, a.cls, (int)blockDim.x);
+    __syncthreads();
+    const uint32_t* __restrict__ s_tail = s_cls + 2 * CLS_TAB;
+    L2Rec* stage = s_l2_dyn + (threadIdx.x >> 6) * CTX_STAGE_CAP;
+    int n_stage = 0;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    const int xdrop = a.xdrop;
+    const uint32_t* __restrict__ ctx = reinterpret_cast<const uint32_t*>(a.td_ctx28);
+
+    // a wave takes a contiguous range of TD_CHUNK_HITS-hit chunks (64 buffers each), exactly like 1c
+    const uint64_t num_buf = (a.num_hits + 63) >> 6;
+    const uint64_t n_chunks = (a.num_hits + TD_CHUNK_HITS - 1) / TD_CHUNK_HITS;
+    const uint64_t W = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint64_t wid = (uint64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    const uint64_t c_lo = (wid * n_chunks) / W, c_hi = ((wid + 1) * n_chunks) / W;
+    const uint64_t b_lo = c_lo * (TD_CHUNK_HITS / 64);
+    const uint64_t b_hi = min(c_hi * (TD_CHUNK_HITS / 64), num_buf);
+    if (b_lo >= b_hi) return;
+    const uint32_t my_sub = (uint32_t)wid & (uint32_t)(L2_NSUB - 1);
+    L2Rec* __restrict__ my_list = a.l2_list + (size_t)my_sub * a.l2_cap;
+    uint32_t* __restrict__ my_count = a.l2_count + my_sub * L2_CNT_STRIDE;
+    // Which record (query position) does hit g belong to?  The probe left a HEAD-BIT map of the call's hits (bit g set <=> a
+    // record starts at hit g), so the record index of hit g is (number of head bits in [0, g]) - 1: per 64-hit buffer ONE 64-bit
+    // word (a scalar load), a running scalar count and two v_mbcnt -- no search, no shuffles (the TdCursor of 1b / 1c spends six
+    // ds_bpermute + ~40 VALU per buffer on the same question).  td_chunk gives the count at the wave's first hit.
+    // The map is read through the constant address space: a wave-uniform address there is a SCALAR load (s_load_dwordx2), which
+    // costs no VALU slot and no vector-memory slot.  The loop runs two buffers ahead on the map and one ahead on the TdRec gather,
+    // so the only latency a wave waits for inside an iteration is its own record stream.
+    typedef const uint64_t __attribute__((address_space(4))) * HeadPtr;
+    HeadPtr head = (HeadPtr)a.td_bits;
+    const uint32_t stride16 = (uint32_t)(a.q2_stride >> 4) & 0xFFFFFFu;  // (the engine keeps copy strides below 2^28 bytes)
+    uint32_t cbefore;  // head bits in [0, first hit of the next buffer to be located)
+    auto locate = [&](uint64_t B) -> uint32_t {  // record index of hit (buffer start + lane), advances cbefore
+        const uint64_t Bs = B >> 1;              // bits 1..lane of B = the bits below `lane` of Bs
+        const uint32_t idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(Bs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Bs, cbefore - 1u + (uint32_t)(B & 1ull)));
+        cbefore += (uint32_t)__builtin_popcountll(B);
+        return idx;
+    };
+    // Latency: the head word is fetched three buffers ahead and the TdRec gather one buffer ahead, so inside an iteration a wave
+    // only waits for its own record stream, which the other seven waves of the SIMD cover.  (Requesting the records one buffer
+    // ahead as well -- two register sets, 55 VGPRs -- measured 4 % SLOWER: the kernel is bound by VALU issue, 77 % busy, not by
+    // bytes in flight; profiles/r03.)  Requests past the wave's range read valid memory (the next wave's buffers, the map's zero
+    // words, record 0) and are never used -- conditional loads would turn every s_waitcnt of the loop into a full drain.
+    struct Stage {
+        uint4 tl, ql;
+        uint32_t tr0, tr1, tr2, qr0, qr1, qr2;
+        uint64_t entry;
+        uint32_t query_loc;
+    };
+    uint64_t B2, B3;  // head words of the buffers one and two ahead of the one being requested
+    TdRec hnext;      // TdRec of this lane's hit in the NEXT buffer to be requested
+    auto advance_map = [&](uint64_t b_req) {  // after the request of buffer b_req: gather for b_req + 1, map word for b_req + 3
+        hnext = a.td_rec[locate(B2)];
+        B2 = B3;
+        B3 = head[b_req + 3];
+    };
+    auto request = [&](uint64_t b, Stage& S) {  // uses hnext = record of buffer b
+        const bool valid = (b << 6) + (uint64_t)lane < a.num_hits;
+        uint64_t entry = hnext.off + (uint64_t)((uint32_t)(b << 6) + (uint32_t)lane - hnext.prefix);  // run offset + index inside the run
+        if (!valid) entry = 0;  // (lanes past the call's last hit: any readable record, the verdict is discarded)
+        S.entry = entry;
+        // 7 dwords per record as shift + subtract (a 64-bit multiply is two quarter-rate v_mad_u64_u32; the asm keeps the
+        // compiler from folding the pair back into one)
+        uint64_t e8;
+        asm("v_lshlrev_b64 %0, 3, %1" : "=v"(e8) : "v"(entry));
+        const uint32_t* rec = ctx + (e8 - entry);
+        __builtin_memcpy(&S.tl, rec, 16);
+        uint3 t;
+        __builtin_memcpy(&t, rec + 4, 12);
+        S.tr0 = t.x; S.tr1 = t.y; S.tr2 = t.z;
+        const uint32_t query_loc = valid ? hnext.qpos + a.seed_size : a.seed_size;  // :204
+        S.query_loc = query_loc;
+        // copy (pos & 3, (pos >> 2) & 3) = copy number pos & 15, dword pos >> 4 (encode.hip); strides are multiples of 16 bytes
+        const uint8_t* p = a.q2_own + ((uint64_t)mul24(query_loc & 15u, stride16) << 4) + (size_t)((query_loc >> 4) << 2);
+        __builtin_memcpy(&t, __builtin_assume_aligned(p, 4), 12);
+        S.qr0 = t.x; S.qr1 = t.y; S.qr2 = t.z;
+        const uint32_t lp = a.query_len - query_loc;  // the left walk = the other strand's forward window at len - anchor (Ctx28)
+        const uint8_t* q = a.q2_other + ((uint64_t)mul24(lp & 15u, stride16) << 4) + (size_t)((lp >> 4) << 2);
+        __builtin_memcpy(&S.ql, __builtin_assume_aligned(q, 4), 16);
+    };
+    auto score = [&](uint64_t b, const Stage& S) {
+        const bool valid = (b << 6) + (uint64_t)lane < a.num_hits;
+        const uint64_t entry = S.entry;
+        const uint32_t query_loc = S.query_loc;
+        uint32_t ref_pos = 0;
+        bool skip = !valid;
+        if (a.rm) {  // rm :239-244,:305-333: hits outside the window are not extended, total stays 0
+            ref_pos = a.td_pos[entry];
+            const uint32_t ref_loc = ref_pos + a.seed_size;
+            skip = skip || !(ref_loc >= a.rm_win_start && ref_loc <= a.rm_win_end);
+        }
+        // ---- class strings ----
+        const uint32_t x0 = S.tr0 ^ S.qr0, x1 = S.tr1 ^ S.qr1, x2 = S.tr2 ^ S.qr2;
+        const uint32_t y0 = S.tl.x ^ S.ql.x, y1 = S.tl.y ^ S.ql.y, y2 = S.tl.z ^ S.ql.z, y3 = S.tl.w ^ S.ql.w;
+        // ---- right side (:326-453): 48 bases = 8 fields ----
+        int T = 0, D = 0;
+        bool dropped = false;
+        cls_step(s_cls, cls_field_addr<0>(x0, x1), xdrop, T, D, dropped);
+        cls_step(s_cls, cls_field_addr<12>(x0, x1), xdrop, T, D, dropped);
+        cls_step(s_cls, cls_field_addr<24>(x0, x1), xdrop, T, D, dropped);
+        cls_step(s_cls, cls_field_addr<4>(x1, x2), xdrop, T, D, dropped);
+        cls_step(s_cls, cls_field_addr<16>(x1, x2), xdrop, T, D, dropped);
+        cls_step(s_cls, cls_field_addr<28>(x1, x2), xdrop, T, D, dropped);
+        cls_step(s_cls, cls_field_addr<8>(x2, 0u), xdrop, T, D, dropped);
+        cls_step(s_cls, cls_field_addr<20>(x2, 0u), xdrop, T, D, dropped);
+        const bool r_alive = !dropped;
+        const int bestR = T + D;
+        // ---- left side (:478-604): 64 bases = 10 fields + a four-base tail ----
+        T = 0; D = 0; dropped = false;
+        cls_step(s_cls, cls_field_addr<0>(y0, y1), xdrop, T, D, dropped);
+        cls_step(s_cls, cls_field_addr<12>(y0, y1), xdrop, T, D, dropped);
+        cls_step(s_cls, cls_field_addr<24>(y0, y1), xdrop, T, D, dropped);
+        cls_step(s_cls, cls_field_addr<4>(y1, y2), xdrop, T, D, dropped);
+        cls_step(s_cls, cls_field_addr<16>(y1, y2), xdrop, T, D, dropped);
+        cls_step(s_cls, cls_field_addr<28>(y1, y2), xdrop, T, D, dropped);
+        cls_step(s_cls, cls_field_addr<8>(y2, y3), xdrop, T, D, dropped);
+        cls_step(s_cls, cls_field_addr<20>(y2, y3), xdrop, T, D, dropped);
+        cls_step(s_cls, cls_field_addr<0>(y3, 0u), xdrop, T, D, dropped);
+        cls_step(s_cls, cls_field_addr<12>(y3, 0u), xdrop, T, D, dropped);
+        cls_step(s_tail, (y3 >> 21) & 0x7F8u, xdrop, T, D, dropped);
+        const bool l_alive = !dropped;
+        const int bestL = T + D;
+        const bool fwd = !skip && (r_alive || l_alive || classify(a, bestR + bestL) != 0);
+        if (__ballot(fwd)) {
+            if (!a.rm && fwd) ref_pos = a.td_pos[entry];
+            L2Rec cr;  // what is known travels with the anchor (kernels.h): level 2 walks only what is still open
+            cr.ref_loc = ref_pos + a.seed_size;  // :220
+            cr.query_loc = query_loc;
+            cr.hidx = (uint32_t)(b << 6) + (uint32_t)lane;
+            const uint32_t fl = (r_alive ? 1u : 0u) | (l_alive ? 2u : 0u);
+            cr.flags = fl ? fl : 3u;             // both settled but the bound passes: level 2 re-walks both sides with exact pair scores
+            cr.known = r_alive ? bestL : bestR;  // flags 1: bestL; flags 2: bestR
+            cr.tm = (l_alive && !r_alive) ? (((uint32_t)T & 0xFFFFu) | ((uint32_t)bestL << 16)) : (uint32_t)bestL;  // flags 2: left walk state
+            stage_append<CTX_STAGE_FLUSH>(stage, n_stage, fwd, cr, my_list, my_count, a.l2_cap, lane, lane_lt);
+        }
+        if (a.audit_list) {  // (tests) the hits this level rejects
+            const bool rej = valid && !skip && !fwd;
+            uint2 ar;
+            ar.x = (rej ? a.td_pos[entry] : 0u) + a.seed_size;
+            ar.y = query_loc;
+            wave_append(rej, ar, a.audit_list, a.audit_count, a.audit_cap, lane, lane_lt);
+        }
+    };
+    {
+        const uint64_t B0 = head[b_lo], B1 = head[b_lo + 1];
+        cbefore = a.td_chunk[c_lo] + 1u - (uint32_t)(B0 & 1ull);
+        hnext = a.td_rec[locate(B0)];
+        B2 = B1;
+        B3 = head[b_lo + 2];
+    }
+    for (uint64_t b = b_lo; b < b_hi; b++) {
+        Stage S;
+        request(b, S);
+        advance_map(b);
+        score(b, S);
     }
     stage_flush(stage, n_stage, my_list, my_count, a.l2_cap, lane);
 }
@@ -1480,6 +1712,20 @@ void launch_extend_filter_ctx(const ExtendArgs& a, hipStream_t s) {
     const size_t lds = wpb * CTX_STAGE_CAP * sizeof(L2Rec);
     if (a.ctx_pipe == 2) hipLaunchKernelGGL(extend_filter_ctx_kernel<2>, dim3(blocks), dim3(threads), lds, s, a);
     else hipLaunchKernelGGL(extend_filter_ctx_kernel<1>, dim3(blocks), dim3(threads), lds, s, a);
+    hipLaunchKernelGGL(l2_prefix_kernel, dim3(1), dim3(L2_NSUB), 0, s, a);
+}
+
+// class filter (1d): table-direct calls whose neighbourhood table carries 28-byte context records; fills a.l2_list
+void launch_extend_filter_cls(const ExtendArgs& a, hipStream_t s) {
+    if (a.num_hits == 0) return;
+    uint64_t waves = (a.num_hits + TD_CHUNK_HITS - 1) / TD_CHUNK_HITS;  // at most one wave per chunk
+    if (a.ctx_waves && waves > a.ctx_waves) waves = a.ctx_waves;
+    uint32_t threads = a.ctx_threads ? a.ctx_threads : (uint32_t)CTX_THREADS;
+    threads = std::min<uint32_t>(CTX_THREADS_MAX, std::max<uint32_t>(64, threads & ~63u));
+    const uint32_t wpb = threads / 64;
+    const uint32_t blocks = (uint32_t)((waves + wpb - 1) / wpb);
+    const size_t lds = wpb * CTX_STAGE_CAP * sizeof(L2Rec);
+    hipLaunchKernelGGL(extend_filter_cls_kernel, dim3(blocks), dim3(threads), lds, s, a);
     hipLaunchKernelGGL(l2_prefix_kernel, dim3(1), dim3(L2_NSUB), 0, s, a);
 }
 

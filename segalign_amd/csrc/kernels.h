@@ -83,6 +83,19 @@ struct CtxRec {               // neighbourhood table WITH target context (probe.
     uint32_t l[4];            // 64 bases left of the anchor in WALKING order (anchor-1, anchor-2, ...), every dword bit-reversed
 };                            // (which also swaps the two bits of a code: the filter's pair table decodes that, extend.hip)
 
+// 28-byte form of the target context (class filter, extend.hip 1d): the seed position moves to a side array (td_pos), the
+// left context is stored in WALKING order with whole 2-bit fields reversed and COMPLEMENTED -- the reverse of a strand is the
+// complement of its reverse-complement strand, so l ^ (the other query strand's forward window) is the per-base XOR of target
+// and query in walking order without any query-side reversal.
+struct Ctx28 {
+    uint32_t l[4];            // ~(64 bases left of the anchor, base anchor-1-k in bits 2k..2k+1 of the 128-bit string)
+    uint32_t r[3];            // 48 bases right of the anchor (anchor+k in bits 2k..2k+1 of the 96-bit string)
+};
+static_assert(sizeof(Ctx28) == 28, "Ctx28 is a packed 28-byte record");
+
+constexpr int Q2_COPIES = 16;  // 2-bit query copies per strand: 4 base phases x 4 byte shifts (encode.hip)
+constexpr int Q2_TAIL = 32;    // zero bytes a window may read past the last base of a copy
+
 struct ExtendArgs {
     const uint8_t* ref2;      // packed filter: 2-bit target, phase copy k at ref2 + k*ref2_stride, overlapped-line layout
     size_t ref2_stride;
@@ -128,6 +141,18 @@ struct ExtendArgs {
     uint32_t td_m;
     const uint32_t* td_pos;     // neighbourhood table runs: seed START positions in the target (+ seed_size = anchor, :220)
     const CtxRec* td_ctx;       // != null: the runs carry their target context (then td_pos is unused): context filter + second level
+    // class filter (extend.hip 1d): 28-byte context records + td_pos as the side array of seed positions; the 2-bit shifted
+    // copies of this call's query strand (right windows) and of the OTHER strand (left windows, see Ctx28)
+    const Ctx28* td_ctx28;
+    const uint64_t* td_bits;    // head-bit map of the call's hits (probe.hip): bit g set <=> a record (query position) starts at hit g
+    const uint8_t* q2_own;
+    const uint8_t* q2_other;
+    size_t q2_stride;
+    int cls[4];                 // score of a base pair by class = (target code ^ query code): upper bounds of the matrix (engine.hip)
+    // audit (tests): every hit the filters REJECT is appended here as {ref_loc, query_loc}
+    uint2* audit_list;
+    uint32_t* audit_count;
+    uint32_t audit_cap;
     // hits the context filter could not decide (walk alive at the end of the context, or bound passes): L2_NSUB sub-lists of
     // l2_cap records each, sub-list s appended to through counter l2_count[s * L2_CNT_STRIDE] (a wave uses sub-list
     // wave id % L2_NSUB).  ONE list with ONE counter serialised the whole filter on a single L2 atomic address: 125 k
@@ -170,6 +195,7 @@ void launch_row_code(const uint8_t* codes, uint8_t* out, uint32_t len, hipStream
 // phase copies for the packed filter: out + k*copy_stride is copy k (4 copies at 2 bit/base, 2 copies at 4 bit/base)
 constexpr int PACK_PAD = 64;  // pad bytes in front of / behind every 4-bit copy
 constexpr int PACK4_COPIES = 8;  // 4-bit copies: 2 base phases x 4 byte shifts (encode.hip)
+constexpr int PACK4_FRONT = 4;   // bytes below 0 of every 4-bit copy that hold real bases of the block start (<= PACK_PAD)
 // 2-bit copies use overlapped 128-byte lines (encode.hip): 96 new bytes + the first 32 of the next line; logical byte =
 // PACK2_BIAS + group index, physical byte of logical jj in the line chosen for logical jb = jj + 32 * (jb / 96)
 constexpr int PACK2_PAYLOAD = 96;
@@ -177,6 +203,11 @@ constexpr int PACK2_BIAS = 96;
 uint32_t pack2_phys_bytes(uint32_t len);
 void launch_pack2_phases(const uint8_t* codes, uint32_t len, uint8_t* out, size_t copy_stride, uint32_t nphys, hipStream_t s);
 void launch_pack4_phases(const uint8_t* codes, uint32_t len, uint8_t* out, size_t copy_stride, uint32_t nbytes, hipStream_t s);
+// 2-bit query copies of the class filter: copy (p, s) byte j = bases [4 (j + s) + p, +4), codes >= 4 as 0, zero past the end
+size_t q2_copy_stride(uint32_t len);
+void launch_pack2_shifted(const uint8_t* codes, uint32_t len, uint8_t* out, size_t copy_stride, hipStream_t s);
+// *mask |= 1 << code for every code that occurs in codes[0, len)
+void launch_code_presence(const uint8_t* codes, uint32_t len, uint32_t* mask, hipStream_t s);
 
 // ---- scan.hip --------------------------------------------------------------------------------------------------
 // exclusive prefix of n u32 values; out_excl[n] receives the total.  OutT = uint32_t or uint64_t.
@@ -214,6 +245,7 @@ void launch_plan(const uint64_t* hit_prefix_excl, uint32_t num_seeds, uint64_t m
 // ---- extend.hip ------------------------------------------------------------------------------------------------
 void launch_extend_filter(const ExtendArgs& a, hipStream_t s);   // hits -> candidates
 void launch_extend_filter_ctx(const ExtendArgs& a, hipStream_t s);  // table-direct hits + their target context -> l2_list
+void launch_extend_filter_cls(const ExtendArgs& a, hipStream_t s);  // the same stage on 28-byte records, class scoring (1d)
 void launch_extend_exact(const ExtendArgs& a, hipStream_t s);    // candidates -> survivors + entropy records
 // chain shortcut: keys -> (sort, dedup.hip) -> links/run heads -> one exact extension per run
 void launch_chain_group(const ExtendArgs& a, hipStream_t s);

@@ -34,14 +34,22 @@ void launch_nbr_fill_ctx(const uint32_t* bucket_start, const uint32_t* pos_table
                          const uint64_t* nbr_start, const uint8_t* ref2, size_t ref2_stride, uint32_t seed_size, CtxRec* ctx,
                          CtxRec* scratch, uint32_t num_index, hipStream_t s);
 
+// the same table as 28-byte records (Ctx28) + the side array of seed positions; scratch: room for num_index records (nullptr:
+// every entry cuts its context out of the target itself)
+void launch_nbr_fill_ctx28(const uint32_t* bucket_start, const uint32_t* pos_table, uint32_t nkeys, uint32_t tmask, int weight,
+                           const uint64_t* nbr_start, const uint8_t* ref2, size_t ref2_stride, uint32_t seed_size, Ctx28* ctx,
+                           uint32_t* nbr_pos, Ctx28* scratch, uint32_t num_index, hipStream_t s);
+
 // position probe of n = end - start query positions; t_off/t_cnt: n entries of scratch; c_rec: n + 1 records
 size_t probe_partial_bytes(uint32_t n);
 size_t probe_bounds_bytes();
 void launch_probe_lookup(const uint8_t* query, uint32_t start, uint32_t n, SeedShape sh, const uint64_t* nbr_start, uint32_t nkeys,
                          uint64_t* t_off, uint32_t* t_cnt, void* partial_buf, hipStream_t s);
 // chunk_rec[k] (k < chunk_cap) = index of the record that holds hit k * TD_CHUNK_HITS of the call
+// head_bits (nullable): bit g of the map is set <=> a record starts at hit g of the call; only hits below 32 * head_words get a bit
 void launch_probe_compact(uint32_t start, uint32_t n, const uint64_t* t_off, const uint32_t* t_cnt, void* partial_buf, void* bounds_buf,
-                          TdRec* c_rec, uint32_t* chunk_rec, uint32_t chunk_cap, const TdBounds& bpos, hipStream_t s);
+                          TdRec* c_rec, uint32_t* chunk_rec, uint32_t chunk_cap, uint32_t* head_bits, uint32_t head_words,
+                          const TdBounds& bpos, hipStream_t s);
 void launch_probe_plan(const uint8_t* query, SeedShape sh, uint32_t tmask, const uint32_t* bucket_start, const void* bounds_buf, int nchunks,
                        const TdRec* c_rec, TdPlan* plan, hipStream_t s);
 

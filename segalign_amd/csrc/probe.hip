@@ -150,6 +150,95 @@ void launch_nbr_fill_ctx(const uint32_t* bucket_start, const uint32_t* pos_table
                        ref2_stride, seed_size, reinterpret_cast<uint4*>(ctx));
 }
 
+// ---- 28-byte records + side array of positions (class filter, extend.hip 1d) ------------------------------------------------
+// reverse the sixteen 2-bit fields of a dword (bit reversal also swaps the two bits of every field: swap them back)
+__device__ __forceinline__ uint32_t fieldrev16(uint32_t v) {
+    const uint32_t r = __builtin_bitreverse32(v);
+    return ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+}
+__device__ __forceinline__ void cut_ctx28(const uint8_t* __restrict__ ref2, size_t ref2_stride, uint32_t anchor, uint32_t out[7]) {
+    const uint32_t jj0 = (anchor >> 2) + (uint32_t)PACK2_BIAS;  // logical byte of the anchor's 4-base group in copy anchor & 3
+    const uint32_t line = (jj0 - 16u) / (uint32_t)PACK2_PAYLOAD;
+    const uint8_t* tp = ref2 + (size_t)(anchor & 3u) * ref2_stride + (jj0 + 32u * line);
+    const uint4 rw = load16u(tp), lw = load16u(tp - 16);
+    out[0] = ~fieldrev16(lw.w);  // bases anchor-1 .. anchor-16, walking order, complemented (Ctx28)
+    out[1] = ~fieldrev16(lw.z);
+    out[2] = ~fieldrev16(lw.y);
+    out[3] = ~fieldrev16(lw.x);
+    out[4] = rw.x;
+    out[5] = rw.y;
+    out[6] = rw.z;
+}
+// stage 1: the context of every seed position ONCE, in pos_table order (one random target line per position)
+__global__ __launch_bounds__(256) void ctx28_by_index_kernel(const uint32_t* __restrict__ pos_table, uint32_t num_index,
+                                                             const uint8_t* __restrict__ ref2, size_t ref2_stride, uint32_t seed_size,
+                                                             uint32_t* __restrict__ out /* 7 dwords per position */) {
+    for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < num_index; id += gridDim.x * blockDim.x) {
+        uint32_t r[7];
+        cut_ctx28(ref2, ref2_stride, pos_table[id] + seed_size, r);  // anchor (:220)
+#pragma unroll
+        for (int j = 0; j < 7; j++) out[(size_t)id * 7 + j] = r[j];
+    }
+}
+// stage 2: one 16-lane group per key copies the records (7 n dwords) and the positions (n dwords) of its source buckets
+__global__ __launch_bounds__(256) void nbr_copy28_kernel(const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ pos_table,
+                                                         uint32_t nkeys, uint32_t tmask, int weight, const uint64_t* __restrict__ nbr_start,
+                                                         const uint32_t* __restrict__ by_index, uint32_t* __restrict__ ctx,
+                                                         uint32_t* __restrict__ nbr_pos) {
+    const uint32_t gl = threadIdx.x & (NBR_GROUP - 1);
+    const uint32_t groups = gridDim.x * (blockDim.x / NBR_GROUP);
+    for (uint32_t k = blockIdx.x * (blockDim.x / NBR_GROUP) + threadIdx.x / NBR_GROUP; k < nkeys; k += groups) {
+        uint64_t o = nbr_start[k];
+        for (int j = -1; j < weight; j++) {
+            if (j >= 0 && !((tmask >> j) & 1u)) continue;
+            const uint32_t kk = j < 0 ? k : (k ^ (2u << (2 * j)));
+            const uint32_t b = bucket_start[kk], n = bucket_start[kk + 1] - b;
+            for (uint32_t i = gl; i < 7 * n; i += NBR_GROUP) ctx[7 * o + i] = by_index[7 * (size_t)b + i];
+            for (uint32_t i = gl; i < n; i += NBR_GROUP) nbr_pos[o + i] = pos_table[b + i];
+            o += n;
+        }
+    }
+}
+// one-stage form (no scratch): every table entry cuts its own context out of the target
+__global__ __launch_bounds__(256) void nbr_fill28_kernel(const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ pos_table,
+                                                         uint32_t nkeys, uint32_t tmask, int weight, const uint64_t* __restrict__ nbr_start,
+                                                         const uint8_t* __restrict__ ref2, size_t ref2_stride, uint32_t seed_size,
+                                                         uint32_t* __restrict__ ctx, uint32_t* __restrict__ nbr_pos) {
+    const uint32_t gl = threadIdx.x & (NBR_GROUP - 1);
+    const uint32_t groups = gridDim.x * (blockDim.x / NBR_GROUP);
+    for (uint32_t k = blockIdx.x * (blockDim.x / NBR_GROUP) + threadIdx.x / NBR_GROUP; k < nkeys; k += groups) {
+        uint64_t o = nbr_start[k];
+        for (int j = -1; j < weight; j++) {
+            if (j >= 0 && !((tmask >> j) & 1u)) continue;
+            const uint32_t kk = j < 0 ? k : (k ^ (2u << (2 * j)));
+            const uint32_t b = bucket_start[kk], n = bucket_start[kk + 1] - b;
+            for (uint32_t i = gl; i < n; i += NBR_GROUP) {
+                const uint32_t p = pos_table[b + i];
+                uint32_t r[7];
+                cut_ctx28(ref2, ref2_stride, p + seed_size, r);
+#pragma unroll
+                for (int q = 0; q < 7; q++) ctx[7 * (o + i) + q] = r[q];
+                nbr_pos[o + i] = p;
+            }
+            o += n;
+        }
+    }
+}
+
+void launch_nbr_fill_ctx28(const uint32_t* bucket_start, const uint32_t* pos_table, uint32_t nkeys, uint32_t tmask, int weight,
+                           const uint64_t* nbr_start, const uint8_t* ref2, size_t ref2_stride, uint32_t seed_size, Ctx28* ctx,
+                           uint32_t* nbr_pos, Ctx28* scratch, uint32_t num_index, hipStream_t s) {
+    if (scratch) {
+        hipLaunchKernelGGL(ctx28_by_index_kernel, dim3(8192), dim3(256), 0, s, pos_table, num_index, ref2, ref2_stride, seed_size,
+                           reinterpret_cast<uint32_t*>(scratch));
+        hipLaunchKernelGGL(nbr_copy28_kernel, dim3(8192), dim3(256), 0, s, bucket_start, pos_table, nkeys, tmask, weight, nbr_start,
+                           reinterpret_cast<const uint32_t*>(scratch), reinterpret_cast<uint32_t*>(ctx), nbr_pos);
+        return;
+    }
+    hipLaunchKernelGGL(nbr_fill28_kernel, dim3(8192), dim3(256), 0, s, bucket_start, pos_table, nkeys, tmask, weight, nbr_start, ref2,
+                       ref2_stride, seed_size, reinterpret_cast<uint32_t*>(ctx), nbr_pos);
+}
+
 void launch_nbr_count(const uint32_t* bucket_start, uint32_t nkeys, uint32_t tmask, int weight, uint32_t* cnt, uint32_t* overflow,
                       hipStream_t s) {
     hipLaunchKernelGGL(nbr_count_kernel, dim3(4096), dim3(256), 0, s, bucket_start, nkeys, tmask, weight, cnt, overflow);
@@ -258,6 +347,7 @@ __global__ __launch_bounds__(PR_THREADS) void probe_compact_kernel(uint32_t star
                                                                    const uint32_t* __restrict__ t_cnt, const Tri* __restrict__ partial,
                                                                    const Tri* __restrict__ total, TdRec* __restrict__ c_rec,
                                                                    uint32_t* __restrict__ chunk_rec, uint32_t chunk_cap,
+                                                                   uint32_t* __restrict__ head_bits, uint32_t head_words,
                                                                    TdBounds bpos, Tri* __restrict__ bounds) {
     const uint32_t skew = start & 3u;
     const uint32_t i0 = blockIdx.x * PR_TILE + threadIdx.x * PR_ITEMS - skew;  // (wraps below 0 for the first elements: i >= n then)
@@ -292,6 +382,9 @@ __global__ __launch_bounds__(PR_THREADS) void probe_compact_kernel(uint32_t star
             r.qpos = start + i;
             r.off = off[j] & ~PR_VALID;
             c_rec[run.ne] = r;
+            // head bit of the position's first hit: bit g of the call-wide bitmap <=> a record starts at hit g.  The class filter
+            // finds the record of every hit of a 64-hit buffer from ONE 64-bit word of it (extend.hip 1d)
+            if (head_bits && (uint32_t)(run.hits >> 5) < head_words) atomicOr(&head_bits[run.hits >> 5], 1u << (run.hits & 31u));
             // which record holds hit k * TD_CHUNK_HITS?  (the context filter's waves start there without searching)
             for (uint64_t k = (run.hits + TD_CHUNK_HITS - 1) / TD_CHUNK_HITS; k * TD_CHUNK_HITS < run.hits + cnt[j] && k < chunk_cap; k++)
                 chunk_rec[k] = run.ne;
@@ -346,6 +439,12 @@ __global__ void probe_plan_kernel(const uint8_t* __restrict__ query, SeedShape s
     plan[c] = p;
 }
 
+// zero the words of the head-bit map the call will use (its hit total is only known on the device at this point)
+__global__ __launch_bounds__(256) void head_bits_clear_kernel(const Tri* __restrict__ total, uint32_t* __restrict__ head_bits, uint32_t head_words) {
+    const uint64_t need = min((uint64_t)head_words, ((total->hits + 63) >> 6) * 2 + 16);  // (+ the words the filter reads ahead)
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < need; i += (uint64_t)gridDim.x * blockDim.x) head_bits[i] = 0u;
+}
+
 size_t probe_partial_bytes(uint32_t n) { return ((size_t)(n + 3 + PR_TILE - 1) / PR_TILE + 2) * sizeof(Tri); }
 size_t probe_bounds_bytes() { return (size_t)TD_MAX_BOUNDS * sizeof(Tri); }
 
@@ -357,13 +456,15 @@ void launch_probe_lookup(const uint8_t* query, uint32_t start, uint32_t n, SeedS
                        reinterpret_cast<Tri*>(partial_buf));
 }
 void launch_probe_compact(uint32_t start, uint32_t n, const uint64_t* t_off, const uint32_t* t_cnt, void* partial_buf, void* bounds_buf,
-                          TdRec* c_rec, uint32_t* chunk_rec, uint32_t chunk_cap, const TdBounds& bpos, hipStream_t s) {
+                          TdRec* c_rec, uint32_t* chunk_rec, uint32_t chunk_cap, uint32_t* head_bits, uint32_t head_words,
+                          const TdBounds& bpos, hipStream_t s) {
     Tri* partial = reinterpret_cast<Tri*>(partial_buf);
     const uint32_t nblocks = probe_blocks(start, n);
     Tri* total = partial + nblocks;
     hipLaunchKernelGGL(probe_partials_kernel, dim3(1), dim3(PR_THREADS), 0, s, partial, nblocks, total);
+    if (head_bits) hipLaunchKernelGGL(head_bits_clear_kernel, dim3(1024), dim3(256), 0, s, total, head_bits, head_words);
     hipLaunchKernelGGL(probe_compact_kernel, dim3(nblocks), dim3(PR_THREADS), 0, s, start, n, t_off, t_cnt, partial, total, c_rec, chunk_rec,
-                       chunk_cap, bpos, reinterpret_cast<Tri*>(bounds_buf));
+                       chunk_cap, head_bits, head_words, bpos, reinterpret_cast<Tri*>(bounds_buf));
 }
 void launch_probe_plan(const uint8_t* query, SeedShape sh, uint32_t tmask, const uint32_t* bucket_start, const void* bounds_buf, int nchunks,
                        const TdRec* c_rec, TdPlan* plan, hipStream_t s) {

@@ -37,6 +37,7 @@ C_ABI_SYMBOLS = [
     "sa_rm_mask_interval", "sa_rm_coverage_intervals", "sa_free_intervals", "sa_get_filter_mode",
     "sa_seed_interval", "sa_seed_and_filter_chunks", "sa_max_chunks_per_call", "sa_get_chunks_per_call", "sa_extend_hits",
     "sa_get_lookup_mode", "sa_get_neighbourhood_entries",
+    "sa_set_option", "sa_reset_option", "sa_get_option", "sa_option_count", "sa_option_name", "sa_get_audit",
 ]
 IVL_DTYPE = np.dtype([("query_start", "<u4"), ("len", "<u4")])  # struct Segment, repeat_masker_src/graph.h:32-35
 STRAND_PLUS, STRAND_MINUS, STRAND_BOTH = 1, 2, 3
@@ -114,6 +115,17 @@ def lib():
     L.sa_extend_hits.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]
     L.sa_get_neighbourhood_entries.restype = C.c_uint64
     L.sa_version.restype = C.c_char_p
+    L.sa_set_option.restype = C.c_int
+    L.sa_set_option.argtypes = [C.c_char_p, C.c_int64]
+    L.sa_reset_option.restype = C.c_int
+    L.sa_reset_option.argtypes = [C.c_char_p]
+    L.sa_get_option.restype = C.c_int64
+    L.sa_get_option.argtypes = [C.c_char_p]
+    L.sa_option_count.restype = C.c_int
+    L.sa_option_name.restype = C.c_char_p
+    L.sa_option_name.argtypes = [C.c_int, C.POINTER(C.c_int)]
+    L.sa_get_audit.restype = C.c_size_t
+    L.sa_get_audit.argtypes = [C.c_void_p, C.c_size_t]
     _lib = L
     return L
 
@@ -371,3 +383,33 @@ def device_make_seeds(start, end, rev, buffer, per=13):
     out = np.empty(cap, dtype=np.uint64)
     n = lib().sa_device_make_seeds(start, end, int(bool(rev)), buffer, out.ctypes.data, cap)
     return out[:min(n, cap)].copy()
+
+
+# ---- options (include/segalign_amd.h: one table, resolved at InitializeProcessor) -------------------------------
+def set_option(name, value):
+    if lib().sa_set_option(name.encode(), int(value)) != 0:
+        raise KeyError("unknown engine option %r" % name)
+
+
+def reset_option(name=None):
+    lib().sa_reset_option(name.encode() if name else None)
+
+
+def get_option(name):
+    return int(lib().sa_get_option(name.encode()))
+
+
+def options():
+    """{name: test_only} of every option the engine knows."""
+    out = {}
+    for i in range(lib().sa_option_count()):
+        t = C.c_int(0)
+        out[lib().sa_option_name(i, C.byref(t)).decode()] = bool(t.value)
+    return out
+
+
+def get_audit(cap=1 << 22):
+    """(ref_loc, query_loc) of the hits the filter levels rejected in this thread's last table-direct call (option audit_cap)."""
+    buf = np.empty((cap, 2), dtype=np.uint32)
+    n = lib().sa_get_audit(buf.ctypes.data, cap)
+    return buf[:min(n, cap)].copy(), int(n)

@@ -1,0 +1,71 @@
+"""GPU parity for HSPs that touch the START of a query block (both strands).
+
+The packed copies of the query the X-drop filters read (2-bit / 4-bit, phase- and byte-shifted, encode.hip) keep the
+first bases of a block in bytes BELOW byte 0 of a shifted copy.  A filter that sees pad codes there scores real bases as
+separators, its bound stops being an upper bound and a barely-passing HSP that reaches position 0 is lost -- but only when
+that HSP is carried by a single seed hit whose anchor sits at a shifted position (every other hit of an ordinary HSP would
+rescue it).  The cases below are built to be exactly that: one seed word on the diagonal, score a little above hspthresh,
+query_start == 0.  Reference behaviour: src/seed_filter.cu:478-488 (the left walk scores every base down to position 0).
+"""
+import numpy as np
+import pytest
+
+from helpers import Case, seg_equal, SHAPE_12OF19
+from segalign_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+_TV = {ord("A"): ord("C"), ord("C"): ord("A"), ord("G"): ord("T"), ord("T"): ord("G")}
+
+
+def block_start_case(O, seed, rev, homol=44, tx=5000):
+    """(target, query, seed position, expected HSP): the query's first `homol` bases (of the strand `rev`) are a copy of
+    target[tx:tx+homol] with a few transversions placed so that exactly ONE seed word of the diagonal hits."""
+    rng = np.random.default_rng(seed)
+    t = synth.random_dna(20000, 100 + seed)
+    O.generate_shape_pos(SHAPE_12OF19)
+    for trial in range(4000):
+        seg = t[tx:tx + homol].copy()
+        for p in rng.choice(homol, int(rng.integers(2, 6)), replace=False):
+            seg[p] = _TV[int(seg[p])]
+        hits = []
+        for p in range(0, homol - 19 + 1):
+            kq = O.kmer_index_at_pos(seg.tobytes(), p, 19)
+            kt = O.kmer_index_at_pos(t.tobytes(), tx + p, 19)
+            if kq == kt or any((kq ^ (2 << (2 * j))) == kt for j in range(12)):
+                hits.append(p)
+        if len(hits) != 1:
+            continue
+        a = hits[0] + 19
+        if ((a >> 1) & 3) == 0 and (a & 1) == 0:
+            continue  # windows aligned in the unshifted copy: not the case this test is after
+        q = np.concatenate([seg, synth.random_dna(3000, 999 + trial + 7 * seed)])
+        if rev:
+            q = synth.reverse_complement(q)
+        c = Case(t, q, chunk=q.size, noentropy=True).oracle_setup(O)
+        want, _ = c.oracle_saf(c.host_seeds(0, q.size - 19, rev), rev)
+        mine = [w for w in want[1:] if w["query_start"] <= 6]
+        if len(mine) == 1 and mine[0]["query_start"] == 0 and 3000 <= mine[0]["score"] <= 3150:
+            return c, hits[0], mine[0]
+    return None
+
+
+@pytest.mark.parametrize("seed", [0, 1, 3, 4, 5])
+@pytest.mark.parametrize("rev", [False, True])
+def test_single_seed_hsp_at_query_block_start(oracle, engine, seed, rev):
+    made = block_start_case(oracle, seed, rev)
+    if made is None:
+        pytest.skip("no single-seed block-start HSP for this PRNG seed")
+    c, seed_pos, hsp = made
+    c.engine_setup(engine)
+    try:
+        end = c.query.size - 19
+        seeds = c.host_seeds(0, end, rev)
+        want, _ = c.oracle_saf(seeds, rev)
+        assert any(w["query_start"] == 0 and w["score"] == hsp["score"] for w in want[1:])
+        got = engine.SeedAndFilter(seeds, rev, 0)                # drop-in entry
+        assert seg_equal(got, want), (seed_pos, tuple(hsp), got[:4], want[:4])
+        got2 = engine.SeedAndFilterRange(0, end, rev, 0)         # device-seeded (table-direct) entry
+        assert seg_equal(got2, want), (seed_pos, tuple(hsp), got2[:4], want[:4])
+    finally:
+        engine.ShutdownProcessor()

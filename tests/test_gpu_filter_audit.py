@@ -1,0 +1,75 @@
+"""GPU: the X-drop FILTER levels never reject a hit the reference would keep.
+
+Final-output parity cannot see a wrongly rejected hit whenever a sibling hit of the same HSP survives (every hit inside an HSP
+extends to the same record), so the filters are audited directly: with option audit_cap the engine records every hit its
+filter levels (class filter on the 28-byte context records, extend.hip 1d; packed second level, 1b; or the 32-byte pair-scoring
+form, 1c) REJECT, and each of them is extended here by the oracle's scalar find_hsps (src/seed_filter.cu:232-652) -- none
+may pass.  Hits near soft-masked runs, N runs, record separators and the block edges are all in the sample."""
+import numpy as np
+import pytest
+
+from helpers import Case, seg_equal
+from segalign_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def audited(engine):
+    engine.set_option("audit_cap", 1 << 22)
+    yield engine
+    engine.ShutdownProcessor()
+    engine.reset_option(None)
+
+
+def audit_case(O, E, c, chunks_per_call=1, strands=(False, True)):
+    rejected = 0
+    ch = c.chunks()
+    for rev in strands:
+        qcodes = c.o_qrc if rev else c.o_q
+        for g in range(0, len(ch), chunks_per_call):
+            grp = ch[g:g + chunks_per_call]
+            wants = [c.oracle_saf(c.host_seeds(s, e, rev), rev)[0] for (s, e) in grp]
+            if chunks_per_call == 1:
+                outs = [E.SeedAndFilterRange(grp[0][0], grp[0][1], rev, 0)]
+            else:
+                outs = E.SeedAndFilterChunks(grp[0][0], grp[-1][1], rev, 0)
+            for got, want in zip(outs, wants):
+                assert seg_equal(got, want)
+            pairs, n = E.get_audit()
+            assert n == pairs.shape[0], "audit list overflowed: raise audit_cap"
+            assert n <= int(E.last_call_stats()["num_hits"])
+            ok, recs = O.extend_hits_pass(c.o_ref, qcodes, c.sub_mat, pairs, xdrop=c.xdrop, hspthresh=c.hspthresh, noentropy=c.noentropy)
+            bad = np.nonzero(ok)[0]
+            assert bad.size == 0, (rev, grp[0], pairs[bad[:5]], recs[bad[:5]])
+            rejected += n
+    return rejected
+
+
+@pytest.mark.parametrize("env_opt", [{}, {"no_ctx": 1}])
+@pytest.mark.parametrize("noentropy", [False, True])
+def test_filters_reject_nothing_that_passes(oracle, audited, env_opt, noentropy):
+    for k, v in env_opt.items():
+        audited.set_option(k, v)
+    t, q = synth.make_pair(300000, 81, 82, sub_rate=0.13, mask_frac=0.2, records=3, indel_every=120, n_runs=3)
+    c = Case(t, q, chunk=60000, noentropy=noentropy).oracle_setup(oracle).engine_setup(audited)
+    assert audited.lookup_mode() == (1 if env_opt.get("no_ctx") else 2)
+    n = audit_case(oracle, audited, c)
+    assert n > 50000  # the bulk of the ~140 k hits is rejected by the filters, and all of them were checked
+
+
+@pytest.mark.parametrize("in_query", [False, True])
+def test_filters_on_a_multi_chunk_call_with_iupac_and_low_thresholds(oracle, audited, in_query):
+    """Other IUPAC letters (code X scores -100 against ACGT: the class bound has to cover it), a low hspthresh and xdrop (many
+    near-threshold hits), sixteen chunks per call.  With such letters in the QUERY only the plus strand is comparable: the
+    reference's host RevComp shifts the minus-strand arena there (hazard H14)."""
+    t, q = synth.make_pair(200000, 91, 92, sub_rate=0.10, mask_frac=0.1, records=2, indel_every=200)
+    q = q.copy()
+    t = t.copy()
+    rng = np.random.default_rng(5)
+    for arr in ((t, q) if in_query else (t,)):
+        pos = rng.integers(0, arr.size, 400)
+        arr[pos] = np.frombuffer(b"RYKMSW", dtype=np.uint8)[rng.integers(0, 6, 400)]
+    c = Case(t, q, chunk=8000, xdrop=500, hspthresh=2200).oracle_setup(oracle).engine_setup(audited)
+    n = audit_case(oracle, audited, c, chunks_per_call=16, strands=(False,) if in_query else (False, True))
+    assert n > 5000

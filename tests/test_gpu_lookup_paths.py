@@ -1,5 +1,6 @@
 """GPU: the three seed-lookup paths of the device-seeded entry points give the oracle's result bit for bit:
-  2  table-direct with target context (neighbourhood table of 32-byte records, context filter + second level; default)
+  2  table-direct with target context (neighbourhood table of 28-byte records + class filter + second level: default;
+     32-byte records + pair-scoring context filter with option ctx32)
   1  table-direct, positions only (SEGALIGN_AMD_NO_CTX=1; what a target block too large for the context table gets)
   0  general path: seed words -> bucket lookup -> hit list (SEGALIGN_AMD_NO_TD=1; also every drop-in call)
 src/seed_filter.cu:157-230 + :682-828 (lookup, iteration plan, hits) on every path; repeat-masker variant included."""
@@ -14,11 +15,11 @@ from test_gpu_rm_mask import as_list, model_mask_interval
 
 pytestmark = pytest.mark.gpu
 
-MODES = [(2, {}), (1, {"SEGALIGN_AMD_NO_CTX": "1"}), (0, {"SEGALIGN_AMD_NO_TD": "1"})]
+MODES = [(2, {}), (2, {"SEGALIGN_AMD_CTX32": "1"}), (1, {"SEGALIGN_AMD_NO_CTX": "1"}), (0, {"SEGALIGN_AMD_NO_TD": "1"})]
 
 
 def with_env(env):
-    for k in ("SEGALIGN_AMD_NO_CTX", "SEGALIGN_AMD_NO_TD", "SEGALIGN_AMD_SPEC_RECS", "SEGALIGN_AMD_DEDUP_SEG_MAX",
+    for k in ("SEGALIGN_AMD_NO_CTX", "SEGALIGN_AMD_NO_TD", "SEGALIGN_AMD_CTX32", "SEGALIGN_AMD_SPEC_RECS", "SEGALIGN_AMD_DEDUP_SEG_MAX",
               "SEGALIGN_AMD_SPEC_DEDUP", "SEGALIGN_AMD_NO_SMALL_DEDUP", "SEGALIGN_AMD_CTX_PIPE", "SEGALIGN_AMD_L2_CAP"):
         os.environ.pop(k, None)
     os.environ.update(env)

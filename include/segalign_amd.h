@@ -195,7 +195,8 @@ const char* sa_option_name(int i, int* test_only /* nullable */);
 
 /* With option audit_cap = N > 0: every hit the X-drop FILTER levels reject in a table-direct call is recorded (up to N per call).
  * Returns how many the calling thread's last call recorded and copies min(that, cap_pairs) {ref_loc, query_loc} pairs.  The
- * parity tests extend each of them with the oracle and require that none passes: the filters' bounds are upper bounds. */
+ * parity tests extend each of them with the CPU restatement of find_hsps and require that none passes: the filters' bounds are
+ * upper bounds. */
 size_t sa_get_audit(uint32_t* dst_pairs, size_t cap_pairs);
 
 typedef struct sa_call_stats {

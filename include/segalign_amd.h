@@ -175,12 +175,14 @@ int sa_max_hits_for_mem(uint64_t total_global_mem);
  *   chunks_per_call   wga_chunk-sized chunks sa_seed_interval / sa_rm_mask_interval hand to one pass (default 16 = maximum)
  *   no_ctx            1: neighbourhood table without target context (lookup mode 1)
  *   no_td             1: no neighbourhood table (lookup mode 0: seed words -> buckets -> hit list, the reference's shape)
- *   ctx32             1: 32-byte context records + pair-scoring context filter instead of 28-byte records + class filter
+ *   arena_gb          GiB of table arena the engine starts mapping in the background at sa_initialize_processor (default 40:
+ *                     the table of a ~100 Mbp block; 0: only on demand).  A larger block raises the goal by itself; setting it
+ *                     beforehand (e.g. 180 for 500 Mbp blocks) takes the allocation off the table build's critical path
  *   no_chain          1: every candidate is extended on its own (no chain shortcut, DESIGN.md 4.5')
  *   no_packed_filter / no_fast_filter   1: fall back to the byte-coded / the exact per-base X-drop filter kernels
  *   debug             1: table-build timings on stderr
  * Launch geometry (defaults are the measured optima, tools/sweep_*.sh)
- *   fin_batch, bufs_per_wave, long_cap, long_blocks, max_waves, packed_waves, l2_blocks, ctx_waves, ctx_threads, ctx_pipe,
+ *   fin_batch, bufs_per_wave, long_cap, long_blocks, max_waves, packed_waves, l2_blocks, ctx_waves, ctx_threads,
  *   chain_sort_threads, dedup_threads, nbr_one_stage
  * Test-only options (small capacities that force the overflow / fallback branches of the orchestration)
  *   l2_cap, spec_dedup, spec_recs, dedup_seg_max, no_small_dedup, chain_cap, audit_cap

@@ -277,6 +277,143 @@ struct Slot {
     size_t events_used = 0;
 };
 
+// ------------------------------------------------------------------------------------------------------------------
+// Table arena: the device memory of the neighbourhood table, obtained through the virtual-memory API in 1 GiB chunks that a
+// BACKGROUND thread maps behind each other into one reserved address range.  Why: the first allocation of tens of GB in a process
+// costs 25-60 ms per GiB on this platform (tools/micro/alloc_cost*.hip: the driver hands out cleared pages) -- 1 s for the 36 GB
+// table of a 100 Mbp block, ~6 s for a 500 Mbp block -- and a plain hipMalloc pays it inside GenerateSeedPosTable.  The arena
+// starts growing at InitializeProcessor (option arena_gb), i.e. while the host is still reading its FASTA files
+// (src/main.cpp:298 comes before :300-549), the table build only waits for the bytes it needs, a larger block just raises the
+// goal (no reallocation, no copy), and a block that needs less keeps what is mapped.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr size_t ARENA_CHUNK = (size_t)1 << 30;
+struct Arena {
+    int dev = 0;
+    uint8_t* base = nullptr;   // reserved virtual range (VMM) or the plain allocation (fallback)
+    size_t va_bytes = 0;
+    std::vector<hipMemGenericAllocationHandle_t> chunks;
+    size_t mapped = 0;         // bytes usable from `base` on (guarded by mu)
+    size_t goal = 0;           // the worker maps until mapped >= goal
+    bool failed = false;       // a chunk could not be obtained: out of memory at `mapped`
+    bool stop = false;
+    bool busy = false;         // the worker thread is running
+    bool vmm = true;           // false: no virtual-memory API here -> one synchronous hipMalloc per growth
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv;
+};
+
+static void arena_worker(Arena* A) {
+    hipSetDevice(A->dev);
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = A->dev;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    std::unique_lock<std::mutex> lk(A->mu);
+    while (!A->stop && !A->failed && A->mapped < A->goal && A->mapped + ARENA_CHUNK <= A->va_bytes) {
+        uint8_t* at = A->base + A->mapped;
+        lk.unlock();
+        hipMemGenericAllocationHandle_t h;
+        bool ok = hipMemCreate(&h, ARENA_CHUNK, &prop, 0) == hipSuccess;
+        if (ok && hipMemMap(at, ARENA_CHUNK, 0, h, 0) != hipSuccess) { hipMemRelease(h); ok = false; }
+        if (ok && hipMemSetAccess(at, ARENA_CHUNK, &acc, 1) != hipSuccess) { hipMemUnmap(at, ARENA_CHUNK); hipMemRelease(h); ok = false; }
+        lk.lock();
+        if (ok) {
+            A->chunks.push_back(h);
+            A->mapped += ARENA_CHUNK;
+        } else {
+            (void)hipGetLastError();
+            A->failed = true;
+        }
+        A->cv.notify_all();
+    }
+    A->busy = false;
+    A->cv.notify_all();
+}
+
+// ask for `bytes` usable bytes (asynchronously); never shrinks
+static void arena_request(Arena& A, size_t bytes) {
+    std::unique_lock<std::mutex> lk(A.mu);
+    if (!A.vmm) return;
+    if (!A.base) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = (size_t)288 << 30;
+        A.va_bytes = (total_b + ARENA_CHUNK - 1) / ARENA_CHUNK * ARENA_CHUNK;
+        void* va = nullptr;
+        if (hipMemAddressReserve(&va, A.va_bytes, 0, nullptr, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            A.vmm = false;
+            A.va_bytes = 0;
+            return;
+        }
+        A.base = (uint8_t*)va;
+    }
+    const size_t want = std::min(A.va_bytes, (bytes + ARENA_CHUNK - 1) / ARENA_CHUNK * ARENA_CHUNK);
+    if (want > A.goal) {
+        A.goal = want;
+        A.failed = false;
+    } else if (A.failed && want > A.mapped) {
+        A.failed = false;  // (memory may have been given back since the last attempt)
+    }
+    if (!A.busy && !A.failed && A.mapped < A.goal) {
+        if (A.worker.joinable()) { lk.unlock(); A.worker.join(); lk.lock(); }
+        A.busy = true;
+        A.stop = false;
+        A.worker = std::thread(arena_worker, &A);
+    }
+}
+// block until `bytes` are usable; false: they cannot be had (out of memory)
+static bool arena_wait(Arena& A, size_t bytes) {
+    arena_request(A, bytes);
+    std::unique_lock<std::mutex> lk(A.mu);
+    if (!A.vmm) {  // fallback: a plain allocation of exactly what is needed, kept while it is large enough
+        if (A.mapped >= bytes) return true;
+        if (A.base) { hipFree(A.base); A.base = nullptr; A.mapped = 0; }
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+        A.base = (uint8_t*)p;
+        A.mapped = bytes;
+        return true;
+    }
+    A.cv.wait(lk, [&] { return A.mapped >= bytes || A.failed || !A.busy; });
+    return A.mapped >= bytes;
+}
+// give everything beyond `keep` bytes back to the device (the worker is stopped first)
+static void arena_trim(Arena& A, size_t keep) {
+    std::unique_lock<std::mutex> lk(A.mu);
+    A.stop = true;
+    A.goal = std::min(A.goal, (keep + ARENA_CHUNK - 1) / ARENA_CHUNK * ARENA_CHUNK);
+    if (A.worker.joinable()) { lk.unlock(); A.worker.join(); lk.lock(); }
+    A.stop = false;
+    if (!A.vmm) {
+        if (keep == 0 && A.base) { hipFree(A.base); A.base = nullptr; A.mapped = 0; }
+        return;
+    }
+    while (A.mapped >= ARENA_CHUNK && A.mapped - ARENA_CHUNK >= keep) {
+        A.mapped -= ARENA_CHUNK;
+        hipMemUnmap(A.base + A.mapped, ARENA_CHUNK);
+        hipMemRelease(A.chunks.back());
+        A.chunks.pop_back();
+    }
+    A.failed = false;
+}
+static void arena_destroy(Arena& A) {
+    arena_trim(A, 0);
+    std::lock_guard<std::mutex> lk(A.mu);
+    if (A.vmm && A.base) hipMemAddressFree(A.base, A.va_bytes);
+    A.base = nullptr;
+    A.va_bytes = 0;
+    A.goal = 0;
+    A.vmm = true;
+}
+static size_t arena_mapped(Arena& A) {
+    std::lock_guard<std::mutex> lk(A.mu);
+    return A.mapped;
+}
+
 struct DevCtx {
     int dev = 0;
     hipStream_t admin = nullptr;
@@ -309,11 +446,9 @@ struct DevCtx {
     std::mutex nbr_mu;
     uint64_t* nbr_start = nullptr;       // nkeys + 1
     uint32_t* nbr_pos = nullptr;         // == pos_table when no transition word exists (nbr_alias); null when nbr_ctx is built
-    CtxRec* nbr_ctx = nullptr;           // the runs WITH their target context (32 B per entry): context filter, extend.hip 1c
-    Ctx28* nbr_ctx28 = nullptr;          // ... or as 28-byte records + nbr_pos as the side array: class filter, extend.hip 1d (default)
-    bool nbr_pos_in_arena = false;       // nbr_pos lies inside the context allocation (not freed on its own)
-    CtxRec* nbr_ctx_alloc = nullptr;     // its allocation outlives a target block (hipMalloc of 150 GB takes ~4 s): grow-only
-    size_t nbr_ctx_cap = 0;              // bytes
+    Ctx28* nbr_ctx28 = nullptr;          // the runs WITH their target context: 28-byte records + nbr_pos as the side array (class filter, extend.hip 1d)
+    bool nbr_pos_in_arena = false;       // nbr_pos lies inside the arena (not freed on its own)
+    Arena arena;                         // memory of the context table: outlives a target block, grown in the background
     bool nbr_alias = false;
     uint64_t nbr_total = 0;
     uint32_t nbr_tmask = 0;
@@ -347,7 +482,7 @@ static int g_packed_waves = 4096; // SEGALIGN_AMD_PACKED_WAVES: waves of the pac
 static int g_ctx_waves = 0;       // SEGALIGN_AMD_CTX_WAVES: wave budget of the context filter; 0 = one 4096-hit chunk per wave (measured best)
 static uint32_t g_l2_cap_test = 0; // SEGALIGN_AMD_L2_CAP
 static int g_nbr_two_stage = 1;   // SEGALIGN_AMD_NBR_ONE_STAGE=1: every table entry cuts its own context out of the target
-static int g_ctx_pipe = 1;        // SEGALIGN_AMD_CTX_PIPE: 1 = no prefetch, 53 VGPRs (measured best by 1-3 %), 2 = ping-pong prefetch
+static int64_t g_arena_gb = 40;   // option arena_gb: GiB of table arena the engine starts mapping at InitializeProcessor (0: on demand only)
 static int g_ctx_threads = 0;     // SEGALIGN_AMD_CTX_THREADS: workgroup size of the context filter (0 = kernel default)
 static int g_dedup_threads = 0;   // SEGALIGN_AMD_DEDUP_THREADS: workgroup size of the per-segment LDS chain (0 = 1024)
 static int g_spec_dedup = 1;      // SEGALIGN_AMD_SPEC_DEDUP=0: wait for the survivor count before the LDS chain (one more host sync)
@@ -359,7 +494,6 @@ static int g_chain_sort_threads = 256;  // SEGALIGN_AMD_CHAIN_SORT_THREADS
 static int g_chunks_per_call = SA_MAX_CHUNKS;  // SEGALIGN_AMD_CHUNKS_PER_CALL: chunks sa_seed_interval hands to one multi-chunk call
 static int g_no_small_dedup = 0;  // SEGALIGN_AMD_NO_SMALL_DEDUP=1: always use the library sorts
 static int g_ctx = 1;             // neighbourhood table with target context when it fits (SEGALIGN_AMD_NO_CTX=1: positions only)
-static int g_ctx32 = 0;           // SEGALIGN_AMD_CTX32=1: 32-byte records + pair-scoring context filter (extend.hip 1c) instead of the class filter
 static uint32_t g_audit_cap = 0;  // SEGALIGN_AMD_AUDIT_CAP (tests): record up to this many hits the filter levels reject per call
 static int g_td = 1;              // table-direct lookup (neighbourhood table + position probe, probe.hip); SEGALIGN_AMD_NO_TD=1 turns it off
 static int g_chain = 1;           // chain shortcut of the exact stage (SEGALIGN_AMD_NO_CHAIN=1 turns it off)
@@ -698,7 +832,6 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     ea.td_chunk = sl->td_chunk.p;
                     ea.td_m = sl->h_td_plan[K - 1].m_hi;
                     ea.td_pos = dc->nbr_pos;
-                    ea.td_ctx = dc->nbr_ctx;
                     ea.seed_size = g_seed_size;
                     if (dc->nbr_ctx28 && ca.q2_own && ca.q2_own->base && ca.q2_other && ca.q2_other->base) {
                         ea.td_ctx28 = dc->nbr_ctx28;
@@ -708,7 +841,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                         ea.q2_stride = ca.q2_own->stride;
                         class_scores(dc->ref_present, ca.q_present, ea.cls);
                     }
-                    if (ea.td_ctx || ea.td_ctx28) {
+                    if (ea.td_ctx28) {
                         // (a sub-list can take a whole chunk; SEGALIGN_AMD_L2_CAP: tests start small to reach the regrow-and-rerun path)
                         sl->l2_list.ensure(g_l2_cap_test ? (size_t)g_l2_cap_test
                                                          : (size_t)std::max<uint64_t>((uint64_t)L2_NSUB * TD_CHUNK_HITS, bh / 8), "second-level list");
@@ -722,7 +855,6 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     ea.l2_blocks = (uint32_t)g_l2_blocks;
                     ea.ctx_waves = (uint32_t)g_ctx_waves;
                     ea.ctx_threads = (uint32_t)g_ctx_threads;
-                    ea.ctx_pipe = (uint32_t)g_ctx_pipe;
                 } else if (!ca.raw_hits) {
                     sl->hits.ensure((size_t)bh, "hits");
                     ProfScope p(sl, "expand_hits");
@@ -812,12 +944,12 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     ea.cand_cap_recs = (uint32_t)std::min<size_t>(sl->cand_list.cap, 0xFFFFFFFFu);
                     ea.ent_list = sl->ent_list.p;
                     ea.ent_cap_recs = (uint32_t)std::min<size_t>(sl->ent_list.cap, 0xFFFFFFFFu);
-                    if (ea.td && (ea.td_ctx || ea.td_ctx28)) {
+                    if (ea.td && ea.td_ctx28) {
                         // context / class filter over the table's own records, then the packed filter on what it could not decide
                         ea.l2_list = sl->l2_list.p;
                         ea.l2_cap = (uint32_t)std::min<size_t>(sl->l2_list.cap / L2_NSUB, 0xFFFFFFu);  // per sub-list
                         check_memcpy(hipMemsetAsync(sl->l2_counts.p, 0, (size_t)L2_NSUB * L2_CNT_STRIDE * sizeof(uint32_t), st), "second-level counters");
-                        { ProfScope p(sl, "extend_filter"); if (ea.td_ctx28) launch_extend_filter_cls(ea, st); else launch_extend_filter_ctx(ea, st); }
+                        { ProfScope p(sl, "extend_filter"); launch_extend_filter_cls(ea, st); }
                         ExtendArgs e2 = ea;
                         e2.td = 0;
                         e2.src_cand = 1;
@@ -869,7 +1001,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                         check_sync(st, "extend (no chain)");
                     }
                     const Counters& c = *sl->h_cnt;
-                    const bool l2_ok = !(ea.td && (ea.td_ctx || ea.td_ctx28)) || c.n_l2_max <= ea.l2_cap;
+                    const bool l2_ok = !(ea.td && ea.td_ctx28) || c.n_l2_max <= ea.l2_cap;
                     if (c.survivors <= ea.out_cap && c.n_long <= ea.cand_cap_recs && c.n_ent <= ea.ent_cap_recs && l2_ok) break;
                     if (!l2_ok)  // (the later stages saw a truncated list)
                         sl->l2_list.ensure((size_t)c.n_l2_max * L2_NSUB + ((size_t)c.n_l2_max * L2_NSUB) / 4, "second-level list(grow)");
@@ -1133,8 +1265,7 @@ static void nbr_release(DevCtx* dc) {
     dc->nbr_start = nullptr;
     dc->nbr_pos = nullptr;
     dc->nbr_pos_in_arena = false;
-    dc->nbr_ctx = nullptr;  // (the allocation stays: nbr_ctx_alloc)
-    dc->nbr_ctx28 = nullptr;
+    dc->nbr_ctx28 = nullptr;  // (the memory stays with the arena)
     dc->nbr_alias = false;
     dc->nbr_total = 0;
     dc->nbr_state = 0;
@@ -1191,57 +1322,36 @@ static bool ensure_nbr(DevCtx* dc) {
     const size_t rec28 = (((size_t)std::max<uint64_t>(total, 1) * sizeof(Ctx28)) + 255) & ~(size_t)255;
     const size_t pos28 = (need_pos + 255) & ~(size_t)255;
     const size_t scratch28 = (size_t)dc->num_index * sizeof(Ctx28);
-    // (+ num_index records behind the table: scratch of the two-stage fill, part of the same allocation)
-    const size_t need_ctx = (size_t)(std::max<uint64_t>(total, 1) + dc->num_index) * sizeof(CtxRec);
-    if (g_ctx && !g_ctx32 && dc->ref2.base && rec28 + pos28 + reserve <= free_b + dc->nbr_ctx_cap) {
-        const bool two_stage = g_nbr_two_stage && tmask != 0 && rec28 + pos28 + scratch28 + reserve <= free_b + dc->nbr_ctx_cap;
+    const size_t have = arena_mapped(dc->arena);  // (already ours: does not count against the free memory)
+    bool built = false;
+    if (g_ctx && dc->ref2.base && rec28 + pos28 + reserve <= free_b + have) {
+        const bool two_stage = g_nbr_two_stage && tmask != 0 && rec28 + pos28 + scratch28 + reserve <= free_b + have;
         const size_t need = rec28 + pos28 + (two_stage ? scratch28 : 0);
-        if (dc->nbr_ctx_cap < need) {
-            dev_free(dc->nbr_ctx_alloc, "nbr_ctx");
-            dc->nbr_ctx_alloc = nullptr;
-            dc->nbr_ctx_cap = 0;
-            dc->nbr_ctx_alloc = (CtxRec*)dev_malloc(need, "nbr_ctx");
-            dc->nbr_ctx_cap = need;
+        if (arena_wait(dc->arena, need)) {
+            uint8_t* arena = dc->arena.base;
+            dc->nbr_ctx28 = reinterpret_cast<Ctx28*>(arena);
+            dc->nbr_pos = reinterpret_cast<uint32_t*>(arena + rec28);
+            dc->nbr_pos_in_arena = true;
+            if (dbg) fprintf(stderr, "neighbourhood table: %.1f M entries, waited %.1f ms for %.1f GB of arena\n", total / 1e6, now() - t_a, need / 1e9);
+            const double t_b = now();
+            launch_nbr_fill_ctx28(dc->bucket_start, dc->pos_table, nkeys, tmask, g_shape.weight, dc->nbr_start, dc->ref2.base, dc->ref2.stride,
+                                  g_seed_size, dc->nbr_ctx28, dc->nbr_pos, two_stage ? reinterpret_cast<Ctx28*>(arena + rec28 + pos28) : nullptr,
+                                  (uint32_t)dc->num_index, st);
+            check_launch("nbr fill ctx28");
+            check_sync(st, "nbr fill ctx28");
+            if (dbg) fprintf(stderr, "neighbourhood table: context fill (%s) took %.1f ms\n", two_stage ? "two-stage" : "one-stage", now() - t_b);
+            built = true;
         }
-        uint8_t* arena = reinterpret_cast<uint8_t*>(dc->nbr_ctx_alloc);
-        dc->nbr_ctx28 = reinterpret_cast<Ctx28*>(arena);
-        dc->nbr_pos = reinterpret_cast<uint32_t*>(arena + rec28);
-        dc->nbr_pos_in_arena = true;
-        if (dbg) fprintf(stderr, "neighbourhood table: %.1f M entries, hipMalloc of %.1f GB took %.1f ms\n", total / 1e6, need / 1e9, now() - t_a);
-        const double t_b = now();
-        launch_nbr_fill_ctx28(dc->bucket_start, dc->pos_table, nkeys, tmask, g_shape.weight, dc->nbr_start, dc->ref2.base, dc->ref2.stride,
-                              g_seed_size, dc->nbr_ctx28, dc->nbr_pos, two_stage ? reinterpret_cast<Ctx28*>(arena + rec28 + pos28) : nullptr,
-                              (uint32_t)dc->num_index, st);
-        check_launch("nbr fill ctx28");
-        check_sync(st, "nbr fill ctx28");
-        if (dbg) fprintf(stderr, "neighbourhood table: context fill (%s) took %.1f ms\n", two_stage ? "two-stage" : "one-stage", now() - t_b);
-    } else if (g_ctx && g_ctx32 && dc->ref2.base && need_ctx + reserve <= free_b + dc->nbr_ctx_cap) {
-        // runs with their target context: 32 bytes per entry (33 GB for a 100 Mbp block with transitions)
-        if (dc->nbr_ctx_cap < need_ctx) {
-            dev_free(dc->nbr_ctx_alloc, "nbr_ctx");
-            dc->nbr_ctx_alloc = nullptr;
-            dc->nbr_ctx_cap = 0;
-            dc->nbr_ctx_alloc = (CtxRec*)dev_malloc(need_ctx, "nbr_ctx");
-            dc->nbr_ctx_cap = need_ctx;
-        }
-        dc->nbr_ctx = dc->nbr_ctx_alloc;
-        if (dbg) fprintf(stderr, "neighbourhood table: %.1f M entries, hipMalloc of %.1f GB took %.1f ms\n", total / 1e6, need_ctx / 1e9, now() - t_a);
-        const double t_b = now();
-        launch_nbr_fill_ctx(dc->bucket_start, dc->pos_table, nkeys, tmask, g_shape.weight, dc->nbr_start, dc->ref2.base, dc->ref2.stride,
-                            g_seed_size, dc->nbr_ctx, (g_nbr_two_stage && tmask != 0) ? dc->nbr_ctx + std::max<uint64_t>(total, 1) : nullptr,
-                            (uint32_t)dc->num_index, st);
-        check_launch("nbr fill ctx");
-        check_sync(st, "nbr fill ctx");
-        if (dbg) fprintf(stderr, "neighbourhood table: context fill took %.1f ms\n", now() - t_b);
+    }
+    if (built) {
+        // (nothing else to do)
     } else if (tmask == 0) {
         dc->nbr_pos = dc->pos_table;
         dc->nbr_alias = true;
-    } else if ([&] {  // positions only: a context allocation kept from an earlier (smaller) block gives its memory back first
-                   if (dc->nbr_ctx_alloc) {
-                       dev_free(dc->nbr_ctx_alloc, "nbr_ctx");
-                       dc->nbr_ctx_alloc = nullptr;
-                       dc->nbr_ctx_cap = 0;
-                       hipMemGetInfo(&free_b, &total_b);
+    } else if ([&] {  // positions only: an arena kept from an earlier (smaller) block gives its memory back first
+                   if (arena_mapped(dc->arena)) {
+                       arena_trim(dc->arena, 0);
+                       if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
                    }
                    return need_pos + reserve <= free_b;
                }()) {
@@ -1387,13 +1497,13 @@ static Option g_opts[] = {
     {"no_chain", 0, 0, 1, 0},                          // 1: every candidate is extended on its own (no chain shortcut)
     {"no_packed_filter", 0, 0, 1, 0},                  // 1: byte-coded filter kernels only (also disables table-direct lookup)
     {"no_fast_filter", 0, 0, 1, 0},                    // 1: exact per-base filter only
-    {"ctx32", 0, 0, 1, 0},                             // 1: 32-byte context records + pair-scoring context filter (round-2 form)
+    {"arena_gb", 40, 0, 1024, 0},                      // GiB of table arena mapped in the background from InitializeProcessor on
     {"debug", 0, 0, 1, 0},                             // 1: table-build timings on stderr
     // launch geometry (swept by tools/sweep_*.sh; the defaults are the measured optima)
     {"fin_batch", 48, 1, 64, 0}, {"bufs_per_wave", 8, 1, 1 << 20, 0}, {"long_cap", 128, 0, 2 * PACK_PAD, 0},
     {"long_blocks", 1792, 1, 1 << 20, 0}, {"max_waves", 4096, 4, 1 << 20, 0}, {"packed_waves", 4096, 8, 1 << 20, 0},
     {"l2_blocks", 512, 1, 1 << 20, 0}, {"ctx_waves", 0, 0, 1 << 20, 0}, {"ctx_threads", 0, 0, 1024, 0},
-    {"ctx_pipe", 1, 1, 2, 0}, {"chain_sort_threads", 256, 64, 512, 0}, {"dedup_threads", 0, 0, 1024, 0},
+    {"chain_sort_threads", 256, 64, 512, 0}, {"dedup_threads", 0, 0, 1024, 0},
     {"nbr_one_stage", 0, 0, 1, 0},
     // test-only: small capacities that force the overflow / fallback branches
     {"l2_cap", 0, 0, 1 << 30, 1}, {"spec_dedup", 1, 0, 1, 1}, {"spec_recs", 16384, 1, 16384, 1}, {"dedup_seg_max", 0, 0, 1 << 30, 1},
@@ -1428,7 +1538,7 @@ static void resolve_options() {
     g_ctx = opt_value("no_ctx") ? 0 : 1;
     g_td = opt_value("no_td") ? 0 : 1;
     g_chain = opt_value("no_chain") ? 0 : 1;
-    g_ctx32 = (int)opt_value("ctx32");
+    g_arena_gb = opt_value("arena_gb");
     g_fin_batch = (int)opt_value("fin_batch");
     g_bufs_per_wave = (int)opt_value("bufs_per_wave");
     g_long_cap = (int)opt_value("long_cap") & ~7;
@@ -1438,7 +1548,6 @@ static void resolve_options() {
     g_l2_blocks = (int)opt_value("l2_blocks");
     g_ctx_waves = (int)opt_value("ctx_waves");
     g_ctx_threads = (int)opt_value("ctx_threads");
-    g_ctx_pipe = (int)opt_value("ctx_pipe");
     g_chain_sort_threads = (int)opt_value("chain_sort_threads") & ~63;
     g_dedup_threads = (int)opt_value("dedup_threads");
     g_nbr_two_stage = opt_value("nbr_one_stage") ? 0 : 1;
@@ -1518,6 +1627,7 @@ int sa_initialize_interface(int num_gpu) {  // seed_filter_interface.cu:49-80
         check_set_device(ord, "InitializeInterface");
         DevCtx* dc = new DevCtx();
         dc->dev = ord;
+        dc->arena.dev = ord;
         hipStreamCreateWithFlags(&dc->admin, hipStreamNonBlocking);
         hipDeviceProp_t prop;
         hipGetDeviceProperties(&prop, ord);
@@ -1567,6 +1677,16 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
             if (!dc->slots[k].stream) slot_init(dc->slots[k], dc->dev);
             dc->slots[k].seeds.ensure((size_t)g_max_seeds, "seed_offsets");
         }
+        // start mapping the table arena now: the host still has its FASTA files to read (src/main.cpp:300-549)
+        if (g_arena_gb > 0 && g_td && g_ctx && g_packed_filter) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const size_t reserve = ((size_t)8 << 30) + ((size_t)4 << 30) * (size_t)SLOTS_PER_DEVICE;
+                const size_t have = arena_mapped(dc->arena);
+                const size_t room = free_b + have > reserve ? free_b + have - reserve : 0;
+                arena_request(dc->arena, std::min<size_t>((size_t)g_arena_gb << 30, room));
+            }
+        }
     }
     // LIFO pool like available_gpus (:895): slot-major so that concurrent callers spread over devices first
     for (int k = SLOTS_PER_DEVICE - 1; k >= 0; k--)
@@ -1591,9 +1711,9 @@ static void release_device_state(DevCtx* dc) {
     dc->d_present = nullptr;
     dc->ref_host_ptr = nullptr;
     nbr_release(dc);
-    dev_free(dc->nbr_ctx_alloc, "nbr_ctx");
-    dc->nbr_ctx_alloc = nullptr;
-    dc->nbr_ctx_cap = 0;
+    // (the table arena stays mapped: it is a cache of cleared device pages that cost seconds to get -- destroy_interface and
+    //  option arena_gb = 0 give it back)
+    if (g_arena_gb == 0) arena_destroy(dc->arena);
     dev_free(dc->bucket_start, "d_index_table");
     dev_free(dc->pos_table, "d_pos_table");
     dc->bucket_start = dc->pos_table = nullptr;
@@ -1634,6 +1754,7 @@ static void destroy_interface() {  // re-initialisation of the interface: contex
     sa_shutdown_processor();
     for (auto* dc : g_dev) {
         check_set_device(dc->dev, "InitializeInterface");
+        arena_destroy(dc->arena);
         if (dc->admin) hipStreamDestroy(dc->admin);
         delete dc;
     }
@@ -2331,7 +2452,7 @@ int sa_get_lookup_mode(void) {  // how device-seeded calls look seeds up on devi
     DevCtx* dc = g_dev[0];
     check_set_device(dc->dev, "lookup mode");
     if (!(g_td && g_packed_filter && !g_count_examined && dc->ref2.base && ensure_nbr(dc))) return 0;
-    return (dc->nbr_ctx || dc->nbr_ctx28) ? 2 : 1;
+    return dc->nbr_ctx28 ? 2 : 1;
 }
 uint64_t sa_get_neighbourhood_entries(void) { return (g_ndev > 0 && g_dev[0]->nbr_state == 1) ? g_dev[0]->nbr_total : 0; }
 void sa_profile_enable(int on) { g_prof_on = on != 0; }

@@ -441,12 +441,7 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 constexpr int PK_THREADS = 512;
 constexpr int PK_TAB = 4096;
 
-// ---- pair table: entry (4 target bits | query byte << 4) = {s0, s0 + s1} as two int16 (see above) ---------------------
-// WIDE (context filter): 8-byte entries {s0 + s1, max(s0, s0 + s1)} as two int32 at BYTE ADDRESS (query byte << 8) | (target
-// nibble << 4) | (8 for the reversed walk) -- the 16-bit field the address arithmetic of ctx_step16 produces IS the address,
-// forward and reversed entries of a pair share 16 bytes; query codes are <= 7, so the table ends at 0x7800 (30 KB).
-// else: {s0, s0 + s1} as two int16, entry index (query byte << 4) | target nibble, reversed walk = query byte | 0x88
-template <bool WIDE>
+// ---- pair table: entry (query byte << 4) | 4 target bits = {s0, s0 + s1} as two int16 (see above); reversed walk = query byte | 0x88
 __device__ __forceinline__ void pk_table_init(uint32_t* __restrict__ s_pk, const int* __restrict__ sub_mat, int nthreads) {
     // the 64 matrix entries go through LDS first (the 4096 pair entries read ~10 of them each): the row-0 maximum over
     // the rows {A, L, N, X, E} is folded in there, scores are raised to -16383
@@ -469,16 +464,7 @@ __device__ __forceinline__ void pk_table_init(uint32_t* __restrict__ s_pk, const
             r1 = ((r1 & 1) << 1) | (r1 >> 1);
         }
         const int s0 = s_m[r0 * 8 + q0], s1 = s_m[r1 * 8 + q1];
-        if (WIDE) {
-            const int fl = qb & 0x88;
-            if (fl == 0 || fl == 0x88) {  // (query bytes with one flag bit do not occur)
-                const int w = ((qb & 0x77) << 6) | (rp << 2) | (rev ? 2 : 0);  // dword index of the entry
-                s_pk[w] = (uint32_t)(s0 + s1);
-                s_pk[w + 1] = (uint32_t)max(s0, s0 + s1);
-            }
-        } else {
-            s_pk[i] = ((uint32_t)s0 & 0xffffu) | ((uint32_t)(s0 + s1) << 16);
-        }
+        s_pk[i] = ((uint32_t)s0 & 0xffffu) | ((uint32_t)(s0 + s1) << 16);
     }
 }
 
@@ -545,7 +531,7 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
     __shared__ uint32_t s_pk[PK_TAB];
     __shared__ CandRec s_cand[PK_THREADS / 64][STAGE_CAP];
     __shared__ uint32_t s_l2pre[SRC == SRC_CAND ? L2_NSUB + 1 : 1];  // SRC_CAND: prefix of the sub-lists of the second-level list
-    pk_table_init<false>(s_pk, a.sub_mat, PK_THREADS);
+    pk_table_init(s_pk, a.sub_mat, PK_THREADS);
     if (SRC == SRC_CAND)
         for (int i = threadIdx.x; i <= L2_NSUB; i += PK_THREADS) s_l2pre[i] = a.l2_prefix[i];
     __syncthreads();
@@ -831,199 +817,12 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
     stage_flush(stage, n_stage, a.cand_list, a.cand_count, a.cand_cap_recs, lane);
 }
 
-// =====================================================================================================================
-// 1c. the X-drop filter on the CONTEXT table: the target bases travel with the seed table entry, no random target access
-// =====================================================================================================================
-// The packed filter (1b) is priced in random 128-byte target lines: one per hit, ~57 G lines/s on the whole chip (tools/micro/
-// gather_bw.hip) -- 52 M hits of a four-chunk call cannot take less than ~0.9 ms however little arithmetic they need.  With
-// 288 GB of HBM the neighbourhood table (probe.hip) can afford to carry, next to every seed position, the 2-bit target bases
-// the filter looks at: 48 to the right of the anchor and 64 to the left (CtxRec, 32 bytes).  The hits of a call are then ONE
-// SEQUENTIAL STREAM of 32-byte records, the query window of a wave's 64 hits is a couple of L1-resident lines, and the filter
-// becomes an arithmetic kernel.  Because every hit now costs the same (3 + 4 steps of 16 bases, no refill), the persistent-
-// lane machinery of 1b disappears: a wave walks its contiguous range of 64-hit buffers in lockstep.
-// Verdicts (all conservative -- the scores are the same upper bounds as in 1b):
-//   both sides dropped inside the context and bestR + bestL cannot pass (:608-633)  -> rejected here (~96 % of all hits)
-//   (scores are int32 here: the int16 limits of 1b do not apply to this level)
-//   a side still alive at the end of its context (1.6 % right, 2.4 % left on random hits), or the bound passes
-//                                                          -> {ref_loc, query_loc, hidx} to the second level: kernel 1b on
-//                                                             that list (SRC_CAND), which decides between reject and the
-//                                                             exact kernels exactly as before.
-// one 16-base step: td = 16 target bases (2 bit each) in walking order; qa | qb = the 16 query bases (4 bit each) as they lie
-// in memory -- REV = false: walking order (right side); REV = true: the bytes run against the walk (left side; qa holds the
-// first four pairs in bytes 3..0), scored with the reversed-walk half of every table entry.
-// Instruction choice follows tools/micro/valu_rate.hip: on gfx950 plain 32-bit VOP2 ops (v_add_u32, v_max_i32, v_and_b32,
-// shifts) issue in ~2.8 cycles per wave, everything packed / SDWA / VOP3 (v_pk_add_i16, v_pk_max_i16, v_perm_b32, v_bfe)
-// in ~4.6.  So the context filter scores in int32 -- table entries are 8 bytes {sum = s0 + s1, mx = max(s0, s0 + s1)}, per
-// pair M = max(M, T + mx); T += sum: three full-rate ops, no saturation, no int16 limits -- and the table is laid out so that
-// the address arithmetic needs no slow op beyond the four byte permutes of a step: the 8 target nibbles are spread into the
-// high nibbles of two dwords (even / odd pairs: 3 ops), the permutes zip them with the query bytes into 16-bit fields
-// (query byte << 8) | (target nibble << 4), and that field IS the entry's byte address (pk_table_init<true>): one v_and /
-// v_lshrrev per pair picks it out of its dword.
-template <bool REV>
-__device__ __forceinline__ void ctx_step16(const uint32_t* __restrict__ s_tab, uint32_t td, uint32_t qa, uint32_t qb, int& T, int& M) {
-    const uint32_t ev = (td << 4) & 0xF0F0F0F0u;  // pairs 0, 2, 4, 6
-    const uint32_t od = td & 0xF0F0F0F0u;         // pairs 1, 3, 5, 7
-    // fields: low word = (query byte << 8) | nibble of the earlier pair, high word = the pair two steps later
-    const uint32_t f02 = __builtin_amdgcn_perm(qa, ev, REV ? 0x05010700u : 0x06010400u);
-    const uint32_t f13 = __builtin_amdgcn_perm(qa, od, REV ? 0x04010600u : 0x07010500u);
-    const uint32_t f46 = __builtin_amdgcn_perm(qb, ev, REV ? 0x05030702u : 0x06030402u);
-    const uint32_t f57 = __builtin_amdgcn_perm(qb, od, REV ? 0x04030602u : 0x07030502u);
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const uint32_t f = j == 0 || j == 2 ? f02 : j == 1 || j == 3 ? f13 : j == 4 || j == 6 ? f46 : f57;
-        const uint32_t addr = (j & 2) == 0 ? (f & 0xFFFFu) : (f >> 16);  // plain VOP2 (full rate), no SDWA
-        const uint2 e = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(s_tab) + addr + (REV ? 8 : 0));  // one ds_read_b64
-        M = max(M, T + (int)e.y);
-        T += (int)e.x;
-    }
-}
-
-// Workgroup size: 1024 threads (two workgroups per CU = 8 waves per SIMD at 53 VGPRs; the pair table is built once per 16 waves).
-// Since the second-level list is appended to through 256 counters instead of one, the kernel is no longer serialised on an
-// atomic and the extra occupancy is worth ~3 % over 512 threads (tools/sweep_pipe.sh)
-constexpr int CTX_THREADS = 1024;      // default; ExtendArgs::ctx_threads (SEGALIGN_AMD_CTX_THREADS) overrides it per launch
+// ---- launch constants of the record-stream filter (1d) ---------------------------------------------------------------------
+// Workgroup size: 1024 threads (two workgroups per CU = 8 waves per SIMD; the class table is built once per 16 waves).
+constexpr int CTX_THREADS = 1024;      // default; ExtendArgs::ctx_threads (option ctx_threads) overrides it per launch
 constexpr int CTX_THREADS_MAX = 1024;
 constexpr int CTX_STAGE_FLUSH = 32;                    // forwards are rare (~4 % of the hits): flush early, keep the stage small
-constexpr int CTX_STAGE_CAP = CTX_STAGE_FLUSH - 1 + 64 + 1;  // 96 records of 24 bytes per wave: three workgroups per CU still fit
-// PIPE: how a wave covers the latency of its stream.  1 (default) = no prefetch, 53 VGPRs, up to 8 waves per SIMD; 2 = records +
-// query windows of buffer b + 1 requested before buffer b is scored (two full register sets, 77 VGPRs, 6 waves per SIMD).
-// Measured within 2 % of each other (tools/sweep_pipe.sh; a third variant that prefetched only the records spilled and lost
-// 25 %): the kernel is not waiting for its stream, see DESIGN.md 4.5a
-template <int PIPE>
-__global__ __launch_bounds__(CTX_THREADS_MAX, PIPE == 2 ? 4 : 8) void extend_filter_ctx_kernel(ExtendArgs a) {
-    __shared__ uint32_t s_pk[2 * PK_TAB];  // 8-byte entries {sum, max prefix} (32 KB)
-    extern __shared__ L2Rec s_l2_dyn[];  // [waves of the workgroup][CTX_STAGE_CAP]
-    pk_table_init<true>(s_pk, a.sub_mat, (int)blockDim.x);
-    __syncthreads();
-    L2Rec* stage = s_l2_dyn + (threadIdx.x >> 6) * CTX_STAGE_CAP;
-    int n_stage = 0;
-    const int lane = threadIdx.x & 63;
-    const unsigned long long lane_lt = (1ull << lane) - 1ull;
-    const int xdrop = a.xdrop;
-    const uint4* __restrict__ ctx = reinterpret_cast<const uint4*>(a.td_ctx);
-
-    // a wave takes a contiguous range of TD_CHUNK_HITS-hit chunks (64 buffers each); the record that holds a chunk's first hit
-    // was noted by the probe (td_chunk), so no wave has to search for its starting point
-    const uint64_t num_buf = (a.num_hits + 63) >> 6;
-    const uint64_t n_chunks = (a.num_hits + TD_CHUNK_HITS - 1) / TD_CHUNK_HITS;
-    const uint64_t W = (uint64_t)gridDim.x * (blockDim.x >> 6);
-    const uint64_t wid = (uint64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    const uint64_t c_lo = (wid * n_chunks) / W, c_hi = ((wid + 1) * n_chunks) / W;
-    const uint64_t b_lo = c_lo * (TD_CHUNK_HITS / 64);
-    const uint64_t b_hi = min(c_hi * (TD_CHUNK_HITS / 64), num_buf);
-    if (b_lo >= b_hi) return;
-    const uint32_t my_sub = (uint32_t)wid & (uint32_t)(L2_NSUB - 1);  // this wave's sub-list of the second-level list
-    L2Rec* __restrict__ my_list = a.l2_list + (size_t)my_sub * a.l2_cap;
-    uint32_t* __restrict__ my_count = a.l2_count + my_sub * L2_CNT_STRIDE;
-    TdCursor cursor = {0u, {0u, 0u, 0ull}, 0u};
-    cursor.m0 = a.td_chunk[c_lo];
-    cursor.load_window(a, lane);
-
-    // software pipeline: the records and query windows of buffer b + 1 are requested before buffer b is scored, so the HBM
-    // latency of the stream is covered by ~2000 cycles of arithmetic instead of by occupancy alone.  The loop is unrolled by
-    // two over a pair of register sets (no register-to-register copies between iterations).
-    struct Loaded { uint4 c0, c1, qr0, ql0, ql1; uint2 qr1; uint32_t qp; };
-    auto request_ctx = [&](uint64_t b, Loaded& L) {
-        if (b >= b_hi) return;  // (wave-uniform)
-        const uint64_t rem = a.num_hits - (b << 6);
-        const int cnt = rem >= 64 ? 64 : (int)rem;
-        uint64_t entry;
-        cursor.locate(a, lane, (uint32_t)(b << 6), entry, L.qp);
-        if (lane >= cnt) return;  // the lane sits out this buffer; its registers keep stale (unused) values
-        L.c0 = ctx[2 * entry];      // pos, r0, r1, r2
-        L.c1 = ctx[2 * entry + 1];  // l0 .. l3
-    };
-    auto request_query = [&](uint64_t b, Loaded& L) {
-        if (b >= b_hi) return;  // (wave-uniform)
-        const uint64_t rem = a.num_hits - (b << 6);
-        if (lane >= (rem >= 64 ? 64 : (int)rem)) return;
-        // query windows: 48 bases from the anchor on, 64 bases before it, from the 4-bit copy in which both are DWORD aligned
-        // (encode.hip: byte-aligned 16-byte loads take the slow path of the texture addresser)
-        const uint32_t query_loc = L.qp + a.seed_size;  // :204
-        const uint32_t o = query_loc >> 1, sh = o & 3u;  // first byte of the right window in copy (query_loc & 1, 0)
-        const uint8_t* qb = a.query4 + (size_t)((query_loc & 1u) + 2u * sh) * a.query4_stride + (o - sh);  // dword aligned
-        L.qr0 = load16u(qb);
-        uint2 t;
-        __builtin_memcpy(&t, qb + 16, 8);
-        L.qr1 = t;
-        L.ql0 = load16u(qb - 32);
-        L.ql1 = load16u(qb - 16);
-    };
-    auto score = [&](uint64_t b, const Loaded& cur) {
-        const uint64_t rem = a.num_hits - (b << 6);
-        const int cnt = rem >= 64 ? 64 : (int)rem;
-        const bool valid = lane < cnt;
-        const uint4 c0 = cur.c0, c1 = cur.c1, qr0 = cur.qr0, ql0 = cur.ql0, ql1 = cur.ql1;
-        const uint2 qr1 = cur.qr1;
-        const uint32_t ref_loc = c0.x + a.seed_size;       // :220
-        const uint32_t query_loc = cur.qp + a.seed_size;   // :204
-        bool skip = !valid;
-        if (a.rm) skip = skip || !(ref_loc >= a.rm_win_start && ref_loc <= a.rm_win_end);  // rm :239-244,:305-333: total stays 0
-        // ---- right side (:326-453): 3 steps ----
-        int T = 0, M = 0;  // running score, best score of the side (upper bounds, see 1b)
-        bool alive = !skip;
-#pragma unroll
-        for (int st = 0; st < 3; st++) {
-            if (alive) {
-                const uint32_t td = st == 0 ? c0.y : st == 1 ? c0.z : c0.w;
-                const uint32_t q0 = st == 0 ? qr0.x : st == 1 ? qr0.z : qr1.x;
-                const uint32_t q1 = st == 0 ? qr0.y : st == 1 ? qr0.w : qr1.y;
-                ctx_step16<false>(s_pk, td, q0, q1, T, M);
-                alive = (M - T) <= xdrop;  // :374, looked at once per 16 bases
-            }
-        }
-        const bool r_alive = alive;  // still walking at the end of the context
-        const int bestR = M;
-        // ---- left side (:478-604): 4 steps on the pre-reversed context; the query bytes run against the walk ----
-        T = 0;
-        M = 0;
-        alive = !skip;
-        {
-#pragma unroll
-            for (int st = 0; st < 4; st++) {
-                if (alive) {
-                    const uint32_t td = st == 0 ? c1.x : st == 1 ? c1.y : st == 2 ? c1.z : c1.w;
-                    const uint32_t a0 = st == 0 ? ql1.w : st == 1 ? ql1.y : st == 2 ? ql0.w : ql0.y;
-                    const uint32_t a1 = st == 0 ? ql1.z : st == 1 ? ql1.x : st == 2 ? ql0.z : ql0.x;
-                    ctx_step16<true>(s_pk, td, a0, a1, T, M);
-                    alive = (M - T) <= xdrop;  // :523
-                }
-            }
-        }
-        const bool l_alive = alive;
-        const bool fwd = !skip && (r_alive || l_alive || classify(a, bestR + M) != 0);
-        L2Rec cr;  // what is known travels with the anchor (kernels.h): level 2 walks only what is still open
-        cr.ref_loc = ref_loc; cr.query_loc = query_loc; cr.hidx = (uint32_t)(b << 6) + (uint32_t)lane;
-        cr.flags = (r_alive ? 1u : 0u) | (l_alive ? 2u : 0u);
-        cr.known = r_alive ? M : bestR;  // flags 1: bestL; flags 0 / 2: bestR
-        cr.tm = (l_alive && !r_alive) ? (((uint32_t)T & 0xFFFFu) | ((uint32_t)M << 16)) : (uint32_t)M;  // flags 2: left walk state; flags 0: bestL
-        stage_append<CTX_STAGE_FLUSH>(stage, n_stage, fwd, cr, my_list, my_count, a.l2_cap, lane, lane_lt);
-    };
-    Loaded A, B;
-    A.c0 = A.c1 = A.qr0 = A.ql0 = A.ql1 = make_uint4(0u, 0u, 0u, 0u);
-    A.qr1 = make_uint2(0u, 0u);
-    A.qp = 0;
-    B = A;
-    if (PIPE == 2) {
-        request_ctx(b_lo, A);
-        request_query(b_lo, A);
-        for (uint64_t b = b_lo; b < b_hi; b += 2) {
-            request_ctx(b + 1, B);
-            request_query(b + 1, B);
-            score(b, A);
-            request_ctx(b + 2, A);
-            request_query(b + 2, A);
-            if (b + 1 < b_hi) score(b + 1, B);
-        }
-    } else {
-        for (uint64_t b = b_lo; b < b_hi; b++) {
-            request_ctx(b, A);
-            request_query(b, A);
-            score(b, A);
-        }
-    }
-    stage_flush(stage, n_stage, my_list, my_count, a.l2_cap, lane);
-}
+constexpr int CTX_STAGE_CAP = CTX_STAGE_FLUSH - 1 + 64 + 1;  // 96 records of 24 bytes per wave: two workgroups per CU fit
 
 // =====================================================================================================================
 // 1d. the X-drop filter on 28-byte context records with CLASS scoring: 6 bases per table lookup
@@ -1698,21 +1497,6 @@ void launch_extend_filter(const ExtendArgs& a, hipStream_t s) {
     if (a.examined) hipLaunchKernelGGL((extend_filter_kernel<true, false>), dim3(blocks), dim3(EXT_THREADS), 0, s, a);
     else if (a.fast_filter) hipLaunchKernelGGL((extend_filter_kernel<false, true>), dim3(blocks), dim3(EXT_THREADS), 0, s, a);
     else hipLaunchKernelGGL((extend_filter_kernel<false, false>), dim3(blocks), dim3(EXT_THREADS), 0, s, a);
-}
-
-// context filter (1c): table-direct calls whose neighbourhood table carries the target context; fills a.l2_list
-void launch_extend_filter_ctx(const ExtendArgs& a, hipStream_t s) {
-    if (a.num_hits == 0) return;
-    uint64_t waves = (a.num_hits + TD_CHUNK_HITS - 1) / TD_CHUNK_HITS;  // at most one wave per chunk
-    if (a.ctx_waves && waves > a.ctx_waves) waves = a.ctx_waves;         // resident waves each walk a contiguous range of chunks
-    uint32_t threads = a.ctx_threads ? a.ctx_threads : (uint32_t)CTX_THREADS;
-    threads = std::min<uint32_t>(CTX_THREADS_MAX, std::max<uint32_t>(64, threads & ~63u));
-    const uint32_t wpb = threads / 64;
-    const uint32_t blocks = (uint32_t)((waves + wpb - 1) / wpb);
-    const size_t lds = wpb * CTX_STAGE_CAP * sizeof(L2Rec);
-    if (a.ctx_pipe == 2) hipLaunchKernelGGL(extend_filter_ctx_kernel<2>, dim3(blocks), dim3(threads), lds, s, a);
-    else hipLaunchKernelGGL(extend_filter_ctx_kernel<1>, dim3(blocks), dim3(threads), lds, s, a);
-    hipLaunchKernelGGL(l2_prefix_kernel, dim3(1), dim3(L2_NSUB), 0, s, a);
 }
 
 // class filter (1d): table-direct calls whose neighbourhood table carries 28-byte context records; fills a.l2_list

@@ -77,13 +77,8 @@ struct TdRec {                // table-direct lookup (probe.hip): a non-empty qu
     uint64_t off;             // offset of the position's run in the neighbourhood table
 };
 
-struct CtxRec {               // neighbourhood table WITH target context (probe.hip): the X-drop filter never touches the target
-    uint32_t pos;             // seed START position in the target (+ seed_size = anchor)
-    uint32_t r[3];            // 48 bases right of the anchor (anchor, anchor+1, ...), 2 bits per base, first base in the low bits
-    uint32_t l[4];            // 64 bases left of the anchor in WALKING order (anchor-1, anchor-2, ...), every dword bit-reversed
-};                            // (which also swaps the two bits of a code: the filter's pair table decodes that, extend.hip)
-
-// 28-byte form of the target context (class filter, extend.hip 1d): the seed position moves to a side array (td_pos), the
+// Neighbourhood table WITH target context (probe.hip; class filter, extend.hip 1d): 28 bytes of 2-bit target bases per run entry,
+// so the X-drop filter never touches the target; the seed position lives in a side array (td_pos).  The
 // left context is stored in WALKING order with whole 2-bit fields reversed and COMPLEMENTED -- the reverse of a strand is the
 // complement of its reverse-complement strand, so l ^ (the other query strand's forward window) is the per-base XOR of target
 // and query in walking order without any query-side reversal.
@@ -140,9 +135,8 @@ struct ExtendArgs {
     const TdRec* td_rec;        // [td_m + 1] one record per NON-EMPTY query position, in query order; td_rec[td_m].prefix = num_hits
     uint32_t td_m;
     const uint32_t* td_pos;     // neighbourhood table runs: seed START positions in the target (+ seed_size = anchor, :220)
-    const CtxRec* td_ctx;       // != null: the runs carry their target context (then td_pos is unused): context filter + second level
-    // class filter (extend.hip 1d): 28-byte context records + td_pos as the side array of seed positions; the 2-bit shifted
-    // copies of this call's query strand (right windows) and of the OTHER strand (left windows, see Ctx28)
+    // class filter (extend.hip 1d), != null: the runs carry their target context as 28-byte records, td_pos is the side array of
+    // seed positions; the 2-bit shifted copies of this call's query strand (right windows) and of the OTHER strand (left windows)
     const Ctx28* td_ctx28;
     const uint64_t* td_bits;    // head-bit map of the call's hits (probe.hip): bit g set <=> a record (query position) starts at hit g
     const uint8_t* q2_own;
@@ -167,7 +161,6 @@ struct ExtendArgs {
     uint32_t ctx_waves;         // wave budget of the context filter (0: one chunk of TD_CHUNK_HITS hits per wave)
     uint32_t chain_q_bits;      // chain sort key = iteration | diagonal (32) | query position (chain_q_bits) relative to chain_q_base
     uint32_t chain_q_base;
-    uint32_t ctx_pipe;          // latency-hiding variant of the context filter (see extend_filter_ctx_kernel)
     uint32_t ctx_threads;       // workgroup size of the context filter (0: its default)
     uint32_t l2_blocks;         // grid of the second level (its hit count is known on the device only)
     uint32_t seed_size;
@@ -244,8 +237,7 @@ void launch_plan(const uint64_t* hit_prefix_excl, uint32_t num_seeds, uint64_t m
 
 // ---- extend.hip ------------------------------------------------------------------------------------------------
 void launch_extend_filter(const ExtendArgs& a, hipStream_t s);   // hits -> candidates
-void launch_extend_filter_ctx(const ExtendArgs& a, hipStream_t s);  // table-direct hits + their target context -> l2_list
-void launch_extend_filter_cls(const ExtendArgs& a, hipStream_t s);  // the same stage on 28-byte records, class scoring (1d)
+void launch_extend_filter_cls(const ExtendArgs& a, hipStream_t s);  // table-direct hits + their 28-byte target context -> l2_list (1d)
 void launch_extend_exact(const ExtendArgs& a, hipStream_t s);    // candidates -> survivors + entropy records
 // chain shortcut: keys -> (sort, dedup.hip) -> links/run heads -> one exact extension per run
 void launch_chain_group(const ExtendArgs& a, hipStream_t s);

@@ -68,88 +68,6 @@ __global__ __launch_bounds__(256) void nbr_fill_kernel(const uint32_t* __restric
     }
 }
 
-// The same fill, but every entry becomes a 32-byte CtxRec: the seed position plus the 2-bit target bases the X-drop filter
-// may look at -- 48 right of the anchor, 64 left of it -- cut out of the 2-bit phase copies of the target (encode.hip; the
-// anchor's [-64, +64) bases are 32 contiguous bytes of ONE overlapped line of copy `anchor & 3`).  13 x the positions x 32
-// bytes is what turns the filter's one-random-line-per-hit into a sequential stream.
-__global__ __launch_bounds__(256) void nbr_fill_ctx_kernel(const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ pos_table,
-                                                           uint32_t nkeys, uint32_t tmask, int weight, const uint64_t* __restrict__ nbr_start,
-                                                           const uint8_t* __restrict__ ref2, size_t ref2_stride, uint32_t seed_size,
-                                                           uint4* __restrict__ ctx /* 2 x uint4 per entry */) {
-    const uint32_t gl = threadIdx.x & (NBR_GROUP - 1);
-    const uint32_t groups = gridDim.x * (blockDim.x / NBR_GROUP);
-    for (uint32_t k = blockIdx.x * (blockDim.x / NBR_GROUP) + threadIdx.x / NBR_GROUP; k < nkeys; k += groups) {
-        uint64_t o = nbr_start[k];
-        for (int j = -1; j < weight; j++) {
-            if (j >= 0 && !((tmask >> j) & 1u)) continue;
-            const uint32_t kk = j < 0 ? k : (k ^ (2u << (2 * j)));
-            const uint32_t b = bucket_start[kk], n = bucket_start[kk + 1] - b;
-            for (uint32_t i = gl; i < n; i += NBR_GROUP) {
-                const uint32_t p = pos_table[b + i];
-                const uint32_t a = p + seed_size;                       // anchor (:220)
-                const uint32_t jj0 = (a >> 2) + (uint32_t)PACK2_BIAS;   // logical byte of the anchor's 4-base group in copy a & 3
-                const uint32_t line = (jj0 - 16u) / (uint32_t)PACK2_PAYLOAD;
-                const uint8_t* tp = ref2 + (size_t)(a & 3u) * ref2_stride + (jj0 + 32u * line);
-                const uint4 rw = load16u(tp), lw = load16u(tp - 16);
-                ctx[2 * (o + i)] = make_uint4(p, rw.x, rw.y, rw.z);
-                ctx[2 * (o + i) + 1] = make_uint4(__builtin_bitreverse32(lw.w), __builtin_bitreverse32(lw.z),
-                                                  __builtin_bitreverse32(lw.y), __builtin_bitreverse32(lw.x));
-            }
-            o += n;
-        }
-    }
-}
-
-// Two-stage form of the same fill (used when `scratch` holds num_index records): stage 1 cuts the context of every seed position
-// ONCE, in pos_table order (one random target line per POSITION instead of one per table entry: 13 x fewer); stage 2 copies
-// the records of the 13 source buckets of a key into its run -- every source is a contiguous piece of the scratch array.
-__global__ __launch_bounds__(256) void ctx_by_index_kernel(const uint32_t* __restrict__ pos_table, uint32_t num_index,
-                                                           const uint8_t* __restrict__ ref2, size_t ref2_stride, uint32_t seed_size,
-                                                           uint4* __restrict__ out /* 2 x uint4 per position */) {
-    for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < num_index; id += gridDim.x * blockDim.x) {
-        const uint32_t p = pos_table[id];
-        const uint32_t a = p + seed_size;                       // anchor (:220)
-        const uint32_t jj0 = (a >> 2) + (uint32_t)PACK2_BIAS;   // logical byte of the anchor's 4-base group in copy a & 3
-        const uint32_t line = (jj0 - 16u) / (uint32_t)PACK2_PAYLOAD;
-        const uint8_t* tp = ref2 + (size_t)(a & 3u) * ref2_stride + (jj0 + 32u * line);
-        const uint4 rw = load16u(tp), lw = load16u(tp - 16);
-        out[2 * (size_t)id] = make_uint4(p, rw.x, rw.y, rw.z);
-        out[2 * (size_t)id + 1] = make_uint4(__builtin_bitreverse32(lw.w), __builtin_bitreverse32(lw.z),
-                                             __builtin_bitreverse32(lw.y), __builtin_bitreverse32(lw.x));
-    }
-}
-__global__ __launch_bounds__(256) void nbr_copy_ctx_kernel(const uint32_t* __restrict__ bucket_start, uint32_t nkeys, uint32_t tmask, int weight,
-                                                           const uint64_t* __restrict__ nbr_start, const uint4* __restrict__ by_index,
-                                                           uint4* __restrict__ ctx) {
-    const uint32_t gl = threadIdx.x & (NBR_GROUP - 1);
-    const uint32_t groups = gridDim.x * (blockDim.x / NBR_GROUP);
-    for (uint32_t k = blockIdx.x * (blockDim.x / NBR_GROUP) + threadIdx.x / NBR_GROUP; k < nkeys; k += groups) {
-        uint64_t o = nbr_start[k];
-        for (int j = -1; j < weight; j++) {
-            if (j >= 0 && !((tmask >> j) & 1u)) continue;
-            const uint32_t kk = j < 0 ? k : (k ^ (2u << (2 * j)));
-            const uint32_t b = bucket_start[kk], n = bucket_start[kk + 1] - b;
-            // 2 * n uint4 words, consecutive lanes take consecutive words (32 bytes per record, 16 per lane)
-            for (uint32_t i = gl; i < 2 * n; i += NBR_GROUP) ctx[2 * o + i] = by_index[2 * (size_t)b + i];
-            o += n;
-        }
-    }
-}
-
-void launch_nbr_fill_ctx(const uint32_t* bucket_start, const uint32_t* pos_table, uint32_t nkeys, uint32_t tmask, int weight,
-                         const uint64_t* nbr_start, const uint8_t* ref2, size_t ref2_stride, uint32_t seed_size, CtxRec* ctx,
-                         CtxRec* scratch, uint32_t num_index, hipStream_t s) {
-    if (scratch) {
-        hipLaunchKernelGGL(ctx_by_index_kernel, dim3(8192), dim3(256), 0, s, pos_table, num_index, ref2, ref2_stride, seed_size,
-                           reinterpret_cast<uint4*>(scratch));
-        hipLaunchKernelGGL(nbr_copy_ctx_kernel, dim3(8192), dim3(256), 0, s, bucket_start, nkeys, tmask, weight, nbr_start,
-                           reinterpret_cast<const uint4*>(scratch), reinterpret_cast<uint4*>(ctx));
-        return;
-    }
-    hipLaunchKernelGGL(nbr_fill_ctx_kernel, dim3(8192), dim3(256), 0, s, bucket_start, pos_table, nkeys, tmask, weight, nbr_start, ref2,
-                       ref2_stride, seed_size, reinterpret_cast<uint4*>(ctx));
-}
-
 // ---- 28-byte records + side array of positions (class filter, extend.hip 1d) ------------------------------------------------
 // reverse the sixteen 2-bit fields of a dword (bit reversal also swaps the two bits of every field: swap them back)
 __device__ __forceinline__ uint32_t fieldrev16(uint32_t v) {
@@ -180,22 +98,58 @@ __global__ __launch_bounds__(256) void ctx28_by_index_kernel(const uint32_t* __r
         for (int j = 0; j < 7; j++) out[(size_t)id * 7 + j] = r[j];
     }
 }
-// stage 2: one 16-lane group per key copies the records (7 n dwords) and the positions (n dwords) of its source buckets
+// stage 2: one WAVE per key, one lane per run ENTRY.  The lanes 0..weight hold the key's source buckets {start, length}, a wave
+// prefix gives every piece its offset inside the run, and entry t of the run finds its piece with a few shuffles; it then moves
+// its whole 28-byte record (16 + 12 byte load / store) and its position.  Consecutive lanes read consecutive records of a piece
+// and write consecutive records of the run: both sides are coalesced, 64 entries per wave instruction (the 16-lane-per-key,
+// dword-per-lane form of the first version ran at 1.3 TB/s of the ~68 GB this kernel moves per 100 Mbp block).
 __global__ __launch_bounds__(256) void nbr_copy28_kernel(const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ pos_table,
                                                          uint32_t nkeys, uint32_t tmask, int weight, const uint64_t* __restrict__ nbr_start,
                                                          const uint32_t* __restrict__ by_index, uint32_t* __restrict__ ctx,
                                                          uint32_t* __restrict__ nbr_pos) {
-    const uint32_t gl = threadIdx.x & (NBR_GROUP - 1);
-    const uint32_t groups = gridDim.x * (blockDim.x / NBR_GROUP);
-    for (uint32_t k = blockIdx.x * (blockDim.x / NBR_GROUP) + threadIdx.x / NBR_GROUP; k < nkeys; k += groups) {
-        uint64_t o = nbr_start[k];
-        for (int j = -1; j < weight; j++) {
-            if (j >= 0 && !((tmask >> j) & 1u)) continue;
-            const uint32_t kk = j < 0 ? k : (k ^ (2u << (2 * j)));
-            const uint32_t b = bucket_start[kk], n = bucket_start[kk + 1] - b;
-            for (uint32_t i = gl; i < 7 * n; i += NBR_GROUP) ctx[7 * o + i] = by_index[7 * (size_t)b + i];
-            for (uint32_t i = gl; i < n; i += NBR_GROUP) nbr_pos[o + i] = pos_table[b + i];
-            o += n;
+    const int lane = threadIdx.x & 63;
+    const uint32_t waves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); k < nkeys; k += waves) {
+        // piece j of the run (seed word order, seeder.cpp:60-69): j = 0 the key itself, then one per transition position
+        uint32_t pb = 0, pn = 0;
+        if (lane <= weight) {
+            const int j = lane - 1;
+            if (j < 0 || ((tmask >> j) & 1u)) {
+                const uint32_t kk = j < 0 ? k : (k ^ (2u << (2 * j)));
+                pb = bucket_start[kk];
+                pn = bucket_start[kk + 1] - pb;
+            }
+        }
+        uint32_t pre = pn;  // inclusive prefix of the piece lengths over lanes 0..16
+#pragma unroll
+        for (int off = 1; off <= 16; off <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)pre, off, 64);
+            if (lane >= off) pre += v;
+        }
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)pre, MAX_CARE);  // (lanes past `weight` add nothing)
+        const uint32_t excl = pre - pn;
+        const uint64_t o = nbr_start[k];
+        for (uint32_t t0 = 0; t0 < total; t0 += 64) {
+            const uint32_t t = t0 + (uint32_t)lane;
+            // the piece that holds entry t: the last lane p <= weight with excl[p] <= t and a non-empty piece
+            uint32_t src = 0;
+#pragma unroll
+            for (int p = 0; p <= MAX_CARE; p++) {
+                const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)excl, p), n = (uint32_t)__builtin_amdgcn_readlane((int)pn, p),
+                               bb = (uint32_t)__builtin_amdgcn_readlane((int)pb, p);  // (wave-uniform: scalar registers, no LDS traffic)
+                if (p <= weight && n && t >= e) src = bb + (t - e);
+            }
+            if (t < total) {
+                const uint32_t* sp = by_index + (size_t)src * 7;
+                uint32_t* dp = ctx + (o + t) * 7;
+                uint4 a;
+                uint3 b;
+                __builtin_memcpy(&a, sp, 16);
+                __builtin_memcpy(&b, sp + 4, 12);
+                __builtin_memcpy(dp, &a, 16);
+                __builtin_memcpy(dp + 4, &b, 12);
+                nbr_pos[o + t] = pos_table[src];
+            }
         }
     }
 }

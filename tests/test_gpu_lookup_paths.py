@@ -1,6 +1,5 @@
 """GPU: the three seed-lookup paths of the device-seeded entry points give the oracle's result bit for bit:
-  2  table-direct with target context (neighbourhood table of 28-byte records + class filter + second level: default;
-     32-byte records + pair-scoring context filter with option ctx32)
+  2  table-direct with target context (neighbourhood table of 28-byte records, class filter + second level; default)
   1  table-direct, positions only (SEGALIGN_AMD_NO_CTX=1; what a target block too large for the context table gets)
   0  general path: seed words -> bucket lookup -> hit list (SEGALIGN_AMD_NO_TD=1; also every drop-in call)
 src/seed_filter.cu:157-230 + :682-828 (lookup, iteration plan, hits) on every path; repeat-masker variant included."""
@@ -15,12 +14,12 @@ from test_gpu_rm_mask import as_list, model_mask_interval
 
 pytestmark = pytest.mark.gpu
 
-MODES = [(2, {}), (2, {"SEGALIGN_AMD_CTX32": "1"}), (1, {"SEGALIGN_AMD_NO_CTX": "1"}), (0, {"SEGALIGN_AMD_NO_TD": "1"})]
+MODES = [(2, {}), (1, {"SEGALIGN_AMD_NO_CTX": "1"}), (0, {"SEGALIGN_AMD_NO_TD": "1"})]
 
 
 def with_env(env):
-    for k in ("SEGALIGN_AMD_NO_CTX", "SEGALIGN_AMD_NO_TD", "SEGALIGN_AMD_CTX32", "SEGALIGN_AMD_SPEC_RECS", "SEGALIGN_AMD_DEDUP_SEG_MAX",
-              "SEGALIGN_AMD_SPEC_DEDUP", "SEGALIGN_AMD_NO_SMALL_DEDUP", "SEGALIGN_AMD_CTX_PIPE", "SEGALIGN_AMD_L2_CAP"):
+    for k in ("SEGALIGN_AMD_NO_CTX", "SEGALIGN_AMD_NO_TD", "SEGALIGN_AMD_SPEC_RECS", "SEGALIGN_AMD_DEDUP_SEG_MAX",
+              "SEGALIGN_AMD_SPEC_DEDUP", "SEGALIGN_AMD_NO_SMALL_DEDUP", "SEGALIGN_AMD_L2_CAP"):
         os.environ.pop(k, None)
     os.environ.update(env)
 
@@ -87,7 +86,6 @@ def test_lookup_paths_under_a_max_hits_split(oracle, clean, mode, env):
                                  {"SEGALIGN_AMD_DEDUP_SEG_MAX": "4"},     # a segment too large for the LDS chain: library sorts
                                  {"SEGALIGN_AMD_SPEC_DEDUP": "0"},        # chain launched after the survivor count is known
                                  {"SEGALIGN_AMD_NO_SMALL_DEDUP": "1"},    # library sorts only
-                                 {"SEGALIGN_AMD_CTX_PIPE": "2"},          # the prefetching variant of the context filter
                                  {"SEGALIGN_AMD_L2_CAP": "1024"}])        # 4 records per sub-list: overflow, regrow, rerun
 def test_every_output_path_of_a_multi_chunk_call(oracle, clean, env):
     """The ways the survivors of a call can reach the host -- speculative LDS chain with one or two copies, the same chain after

@@ -20,9 +20,12 @@ of configs[2] (a 500 Mbp target block, the size at which the reference closes a 
 %-diverged shuffled pieces; every rank of an N-GPU run holds its own block pair, as the 6 x 6 block pairs of a 3 Gbp x 3 Gbp
 run are independent), `plumbing` = configs[0] (1 Mbp x 1 Mbp).
 
-Multi-GPU: query intervals are independent shards: in every step rank r walks the interval list starting at
-interval r (r, r+1, ... wrapping), so per-GPU work is fixed => "scaling": "weak"; every rank holds target + tables; there
-is NO data-path collective (torch.distributed only carries the barrier and the max/sum of the timing).
+Multi-GPU: the unit of work is one engine CALL (up to sixteen 250 kbp chunks of one strand of one interval, 60
+calls per pass of the default workload); calls are independent and their output position is fixed by the host loop.  Default
+`--scaling strong`: the calls of ONE pass are dealt round-robin to the N ranks -- every call on exactly one GPU, total work fixed,
+`value` = query bases of the block / max-rank time, and the order-independent HSP checksum of the pass must equal the 1-GPU
+checksum.  `--scaling weak`: every rank runs the whole pass (rank-dependent start).  Every rank holds target + tables; there is
+NO data-path collective (torch.distributed only carries the barrier and the max / sum of the timing and counts).
 """
 import argparse
 import glob
@@ -53,9 +56,10 @@ SCOPE_KERNELS = {
     "chain_link": ["chain_link_kernel"], "extend_exact_chain": ["extend_exact_chain_kernel"],
     "extend_exact": ["extend_exact_kernel"], "extend_entropy": ["extend_entropy_kernel"], "dedup_seg": ["dedup_seg_kernel"],
 }
-# context-table calls (lookup mode 2): the filter is two kernels -- level 1 on the context records, level 2 (the packed kernel)
-# on the few hits level 1 could not decide
-CTX_SCOPE_KERNELS = {"extend_filter": ["extend_filter_ctx_kernel"], "extend_filter2": ["extend_filter_packed_kernel"]}
+# context-table calls (lookup mode 2): the filter is two kernels -- level 1, the class filter on the 28-byte context records, and
+# level 2 (the packed kernel) on the few hits level 1 could not decide; these are the symbols profile_check compares
+PROFILE_SCOPE_KERNELS = dict(SCOPE_KERNELS, extend_filter=["extend_filter_cls_kernel", "l2_prefix_kernel"],
+                             extend_filter2=["extend_filter_packed_kernel"])
 EXTENSION_SCOPES = ["extend_filter", "extend_filter2", "chain_group", "chain_link", "extend_exact_chain", "extend_exact", "extend_entropy"]
 
 
@@ -81,6 +85,8 @@ def parse():
                          "the engine has 2 slots per device so one call's syncs overlap another call's kernels)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not record per-kernel HIP events in the timed region (roofline block from the untimed passes only)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = the calls of ONE pass are dealt to the ranks (total work fixed); weak = every rank runs the whole pass")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU-only rehearsal of the launch/shard/reduce/JSON contract (gloo, no GPU): real shard + chunk "
                          "arithmetic around a stub engine")
@@ -142,10 +148,13 @@ def make_workload(args, rank=0):
                       "1.2%%-diverged shuffled 1-10 Mbp pieces, 12of19 + transitions" % (tlen / 1e6, total / 1e6))
 
 
-def my_intervals(items, rank, step):
-    """Weak scaling: every rank walks ALL items each step, rank r starting at item r (+ the step number)."""
-    n = len(items)
-    return [items[(rank + step + i) % n] for i in range(n)]
+CHECK_MOD = 1 << 55  # HSP checksums are summed modulo this (8 ranks x 2^55 fits the int64 all_reduce)
+
+
+def rotate(seq, k):
+    """Weak-scaling walk: every rank takes the WHOLE list each step, rank r (+ the step number) positions in."""
+    n = len(seq)
+    return [seq[(k + i) % n] for i in range(n)] if n else []
 
 
 def main():
@@ -170,27 +179,34 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # "nccl" IS RCCL on ROCm
     elif not args.dry_run:
         torch.cuda.set_device(local_rank)
+    # human: every rank holds its own block pair (the 6 x 6 block pairs of a 3 Gbp x 3 Gbp run are independent) => weak
+    scaling = "weak" if (args.scaling == "weak" or args.workload == "human") else "strong"
 
     if args.dry_run:
-        return dry_run(args, rank, world, dist, torch, shard)
+        return dry_run(args, rank, world, dist, torch, shard, scaling)
 
     from segalign_amd import engine as E
+
+    # default parameters of the reference (src/main.cpp:61-124)
+    xdrop, hspthresh, seed_size = 910, 3000, len(SHAPE)
+    sub_mat = default_sub_mat(xdrop)
+    inflight = max(1, args.host_threads) * max(1, args.intervals_in_flight)
+
+    # engine first, data second -- the reference's order (src/main.cpp:297-298 before :300-549): the table arena is mapped in the
+    # background while the host produces its sequences
+    E.select_devices([local_rank])
+    E.InitializeInterface(1)
+    kmer = E.GenerateShapePos(SHAPE)
+    os.environ.setdefault("SEGALIGN_AMD_SLOTS", str(max(2, inflight)))  # one engine slot per call in flight (default 2)
+    if args.workload == "human":
+        os.environ.setdefault("SEGALIGN_AMD_ARENA_GB", "180")
+    E.InitializeProcessor(args.workload != "notransition", args.chunk, seed_size, sub_mat, xdrop, hspthresh, False)
 
     t_gen0 = time.time()
     wl = make_workload(args, rank)
     target, query = wl["target"], wl["query"]
     t_gen = time.time() - t_gen0
 
-    # default parameters of the reference (src/main.cpp:61-124)
-    xdrop, hspthresh, seed_size = 910, 3000, len(SHAPE)
-    sub_mat = default_sub_mat(xdrop)
-
-    E.select_devices([local_rank])
-    E.InitializeInterface(1)
-    kmer = E.GenerateShapePos(SHAPE)
-    # one engine slot per call in flight (the engine's default is 2)
-    os.environ.setdefault("SEGALIGN_AMD_SLOTS", str(max(2, max(1, args.host_threads) * max(1, args.intervals_in_flight))))
-    E.InitializeProcessor(wl["transition"], args.chunk, seed_size, sub_mat, xdrop, hspthresh, False)
     t0 = time.time()
     keep = E.SendRefWriteRequest(target, 0, target.size)
     t_ref = time.time() - t0
@@ -204,54 +220,55 @@ def main():
         E.SendQueryWriteRequest(query, 0, query.size, 0)
     t_query = time.time() - t0
 
-    if wl["rm"]:
-        items = [(t["start"], t["end"], t["ref_start"], t["ref_end"]) for t in shard.rm_plan(target.size, seed_size=seed_size,
-                                                                                             lastz_interval_size=args.interval)]
-    else:
-        items = shard.plan_intervals(query.size, seed_size, args.interval)  # src/main.cpp:383-393 over [0, len - seed_size)
     q_block_len = query.size - seed_size  # q_len handed to the seeder (main.cpp:708)
+    if wl["rm"]:
+        # repeat masker: the unit of work is one interval task of the reference's plan (repeat_masker_src/main.cpp:316-436)
+        jobs = [dict(rm=True, a=t["start"], b=t["end"], ref_start=t["ref_start"], ref_end=t["ref_end"], rev=False)
+                for t in shard.rm_plan(target.size, seed_size=seed_size, lastz_interval_size=args.interval)]
+        intervals = jobs
+    else:
+        intervals = shard.plan_intervals(query.size, seed_size, args.interval)  # src/main.cpp:383-393 over [0, len - seed_size)
+        jobs = shard.call_jobs(intervals, q_block_len, args.chunk, E.lib().sa_get_chunks_per_call())
 
-    def run_item(it, collect=None, threads=None):
-        """one interval: seeder_body::operator() (src/seeder.cpp:12-127; repeat_masker_src/seeder.cpp:28-195 for rm) -- every
-        250 kbp chunk of both strands through the engine, chunk calls issued by the library's own C++ threads"""
-        if wl["rm"]:
-            iv, tot = E.RmMaskInterval(it[0], it[1], it[2], it[3], E.STRAND_BOTH, 1)
+    def run_job(job, collect=None):
+        """one engine call: up to sixteen 250 kbp chunks of one strand of one interval (src/seeder.cpp:47-121), or one interval task
+        of the repeat masker (repeat_masker_src/seeder.cpp:28-195).  -> (query bases counted once, HSPs, checksum)"""
+        if job.get("rm"):
+            iv, tot = E.RmMaskInterval(job["a"], job["b"], job["ref_start"], job["ref_end"], E.STRAND_BOTH, 1)
             if collect is not None:
-                collect.append(dict(num_seeds=tot["num_seeds"], num_hits=tot["num_hits"], num_survivors=tot["num_hsps"],
-                                    num_candidates=0, num_examined=0, num_examined_filter=0))
-            return it[1] - it[0], int(iv.size)
-        fw, rc, st = E.SeedInterval(it[0], it[1], q_block_len, E.STRAND_BOTH, 0, max(1, threads or args.host_threads))
+                st = E.last_call_stats()
+                collect.append(dict(num_seeds=tot["num_seeds"], num_hits=tot["num_hits"], num_survivors=tot["num_hsps"], num_candidates=0,
+                                    num_examined=st["num_examined"], num_examined_filter=st["num_examined_filter"]))
+            chk = int(np.sum(iv["query_start"].astype(np.uint64) * np.uint64(31) + iv["len"].astype(np.uint64), dtype=np.uint64) % np.uint64(CHECK_MOD)) if iv.size else 0
+            return job["b"] - job["a"], int(iv.size), chk
+        outs, st = E.SeedCalls([(job["a"], job["b"], job["rev"])], 0, 1)
         if collect is not None:
             collect.append(st)
-        return it[1] - it[0], int(fw.size + rc.size)
+        return (0 if job["rev"] else job["b"] - job["a"]), int(outs[0].size), shard.hsp_checksum(outs[0], job["rev"]) % CHECK_MOD
+
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(inflight)  # the reference keeps one seeder body per TBB thread in flight (src/main.cpp:565-573)
 
     def run_step(k, collect=None, threads=None):
-        todo = my_intervals(items, rank, k)
-        nt = max(1, threads or args.host_threads)
-        if wl["rm"] and nt > 1:
-            # sa_rm_mask_interval walks the chunks of ONE interval on one engine slot; intervals are independent
-            # (repeat_masker_src/main.cpp hands them to parallel seeder bodies): keep `nt` of them in flight
-            from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(nt) as pool:
-                res = list(pool.map(lambda it: run_item(it, collect, threads), todo))
-            return sum(r[0] for r in res), sum(r[1] for r in res)
-        if args.intervals_in_flight > 1 and threads is None and len(todo) > 1:
-            # the reference host keeps several seeder bodies (intervals) in flight (src/main.cpp:601-737, one per TBB thread):
-            # the calls of one interval finish together, a second interval fills the gap
-            from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(args.intervals_in_flight) as pool:
-                res = list(pool.map(lambda it: run_item(it, collect, threads), todo))
-            return sum(r[0] for r in res), sum(r[1] for r in res)
-        b = h = 0
-        for it in todo:
-            bb, hh = run_item(it, collect, threads)
-            b += bb
-            h += hh
-        return b, h
+        """strong: this rank's share of the calls of ONE pass over the query block; weak: all of them, from a rank-dependent start.
+        Plain workloads hand the call list to the engine's own worker pool (sa_seed_calls: `inflight` calls in flight on C++
+        threads, like the reference's TBB seeder bodies); the repeat masker's interval tasks are issued from a Python pool."""
+        todo = shard.partition(jobs, rank, world) if scaling == "strong" else rotate(jobs, rank + k)
+        if wl["rm"]:
+            res = [run_job(j, collect) for j in todo] if threads == 1 else list(pool.map(lambda j: run_job(j, collect), todo))
+            return sum(r[0] for r in res), sum(r[1] for r in res), sum(r[2] for r in res) % CHECK_MOD
+        outs, st = E.SeedCalls([(j["a"], j["b"], j["rev"]) for j in todo], 0, threads or inflight)
+        if collect is not None:
+            collect.append(st)
+        chk = 0
+        for j, o in zip(todo, outs):
+            chk = (chk + shard.hsp_checksum(o, j["rev"])) % CHECK_MOD
+        return sum(j["b"] - j["a"] for j in todo if not j["rev"]), sum(int(o.size) for o in outs), chk
 
     if args.one_interval:
-        nb, nh = run_item(items[0], None, 1)
-        print(json.dumps({"one_interval": True, "bases": nb, "hsps": nh, "workload": args.workload}))
+        first = [j for j in jobs if j.get("rm") or j["interval"] == 0] if not wl["rm"] else jobs[:1]
+        res = [run_job(j) for j in first]
+        print(json.dumps({"one_interval": True, "bases": sum(r[0] for r in res), "hsps": sum(r[1] for r in res), "workload": args.workload}))
         E.ShutdownProcessor()
         return
 
@@ -271,23 +288,25 @@ def main():
     barrier()
     t0 = time.perf_counter()
     bases = hsps = 0
+    check = 0
     for k in range(args.steps):
-        b, h = run_step(k, call_stats)
+        b, h, c = run_step(k, call_stats)
         bases += b
         hsps += h
+        check = c  # (every step is the same pass: keep one)
     barrier()
     elapsed = time.perf_counter() - t0
     E.profile_enable(False)
     prof = E.profile_entries()
 
-    # max over ranks, sum of bases
+    # max over ranks, sums of bases / HSPs / checksum
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        tb = torch.tensor([bases, hsps], dtype=torch.int64, device=dev)
+        tb = torch.tensor([bases, hsps, check], dtype=torch.int64, device=dev)
         dist.all_reduce(tb, op=dist.ReduceOp.SUM)
-        bases, hsps = int(tb[0].item()), int(tb[1].item())
+        bases, hsps, check = int(tb[0].item()), int(tb[1].item()), int(tb[2].item()) % CHECK_MOD
 
     if rank == 0 and not prof and args.no_kernel_events:  # event-free timed region: kernel times from one extra (untimed) pass
         E.profile_reset()
@@ -298,7 +317,9 @@ def main():
         prof = E.profile_entries()
     roof = None
     if rank == 0 and prof:
-        roof = roofline(args, E, wl, prof, call_stats, run_step, run_item, items)
+        roof = roofline(args, E, wl, prof, call_stats, run_step, run_job, jobs, elapsed, world)
+        if not wl["rm"]:
+            roof["dropin"] = dropin_leg(E, jobs, args, seed_size, 13 if wl["transition"] else 1)
 
     # ---------------- CPU baseline (rank 0, N == 1 only, bounded sample) ----------------
     cpu = None
@@ -307,36 +328,44 @@ def main():
 
     if rank == 0:
         value = bases / elapsed / 1e9
+        steps_eff = max(args.steps, 1)
         line = {
             "metric": "Gbp query seeded+filtered+extended per sec", "value": round(value, 5), "unit": "Gbp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * elapsed / steps_eff, 3), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "int32", "data": wl["data"],
             "config": {"workload": wl["label"] + ", HOXD70, xdrop 910, hspthresh 3000; step = one pass over the whole %d bp query "
                                                  "block (%d intervals of %d bp), both strands, %d bp chunks (%d chunks of a strand share one "
-                                                 "pass over the kernels), device-side seeding" % (query.size, len(items), args.interval, args.chunk,
+                                                 "pass over the kernels), device-side seeding" % (query.size, len(intervals), args.interval, args.chunk,
                                                                                                  E.lib().sa_get_chunks_per_call()),
                        "workload_key": args.workload,
-                       "parallelism": "query-interval shards x%d (every rank walks the interval list from its own offset), no collective" % world,
-                       "hsps_per_step": hsps // max(args.steps * world, 1)},
+                       "parallelism": ("the %d engine calls of one pass dealt round-robin to %d rank(s): every call on exactly one GPU, target + "
+                                       "tables on every GPU, no collective" % (len(jobs), world)) if scaling == "strong" else
+                                      ("every one of %d rank(s) runs all %d calls of a pass (own block pair per rank for `human`), no collective"
+                                       % (world, len(jobs))),
+                       "calls_per_step": len(jobs), "calls_in_flight_per_gpu": inflight,
+                       "hsps_per_step": hsps // (steps_eff * (world if scaling == "weak" else 1)),
+                       # order-independent checksum of one pass's HSP multiset: an N-GPU strong-scaling run reproduces the 1-GPU value
+                       "hsp_checksum": check if scaling == "strong" else None},
             "setup_s": {"generate": round(t_gen, 2), "target_upload_encode": round(t_ref, 3),
                         "seed_table_build": round(t_table, 3), "query_upload_encode": round(t_query, 3)},
             "roofline": roof, "cpu_baseline": cpu,
         }
         # table build (setup, once per target block): algorithmic bytes of the reference-layout table, and the bytes
-        # this build writes on top of it -- the neighbourhood table, 4-byte positions or 32-byte context records
+        # this build writes on top of it -- the neighbourhood table: 4-byte positions, or 28-byte context records + positions
         lm, nent = E.lookup_mode(), E.neighbourhood_entries()
         tv = float(target.size)
         alg_tb = tv + 8.0 * 4 ** 12 + 8.0 * tv
         impl_tb = alg_tb + nent * {0: 0, 1: 4, 2: 32}[lm]
         line["table_build"] = {
             "seconds": round(t_table, 4), "lookup_mode": lm, "neighbourhood_entries": nent,
-            "bytes": "1*T + 8*4^12 + 8*T_valid (reference-layout table) [+ 32 B (context) or 4 B per neighbourhood entry]",
+            "bytes": "1*T + 8*4^12 + 8*T_valid (reference-layout table) [+ 32 B (28-byte context record + position) or 4 B per neighbourhood entry]",
             "algorithmic_bytes": int(alg_tb), "algorithmic_frac": round(alg_tb / max(t_table, 1e-9) / 1e9 / HBM_PEAK_GBS, 5),
             "written_bytes": int(impl_tb), "written_frac": round(impl_tb / max(t_table, 1e-9) / 1e9 / HBM_PEAK_GBS, 4),
-            "note": "includes hipMalloc of the tables (first block of a process) and every sync of the build"}
+            "note": "wall time of GenerateSeedPosTable incl. every sync; the table arena is mapped in the background from InitializeProcessor on"}
         print(json.dumps(line))
         sys.stdout.flush()
+    pool.shutdown()
     E.ShutdownProcessor()
     if dist is not None:
         dist.destroy_process_group()
@@ -345,152 +374,203 @@ def main():
 # ------------------------------------------------------------------------------------------------------------------
 # roofline block
 # ------------------------------------------------------------------------------------------------------------------
-def roofline(args, E, wl, prof, call_stats, run_step, run_item, items):
-    """Per-kernel time from HIP events on the engine's own streams; algorithmic bytes per SURVEY 8(d) / DESIGN.md 4."""
-    # the same kernels without a second call overlapping them: one extra (untimed) pass issued by ONE host thread
+def roofline(args, E, wl, prof, call_stats, run_step, run_job, jobs, elapsed, world):
+    """The dominant kernel against the HBM roofline, honest by construction.
+
+    `achieved` = bytes the kernel's data layout makes it MOVE per launch (stated per unit in DESIGN.md 4.5: 28 B of context record
+    per hit + 16 B of position record per non-empty query position + 1 bit per hit of head map + 24 B per forwarded hit), from the
+    exact per-call counts, divided by the kernel's average launch duration from HIP events on the engine's own streams over the
+    timed region.  These are bytes that really cross the memory system, so frac <= 1; the PMC-measured HBM bytes of the committed
+    rocprofv3 collection stand beside it (`traffic`).  SURVEY 8(d)'s reference-layout figure (8*H + 2*E + 20*A: one byte per
+    examined base and sequence) is kept as `algorithmic_equiv` -- the packed design deliberately never moves those bytes, so it
+    is an equivalence, not a bandwidth."""
+    # the same kernels without a second call overlapping them: one extra (untimed) pass with ONE call in flight
     E.profile_reset()
     E.profile_enable(True)
     solo_stats = []
     run_step(0, solo_stats, threads=1)
     E.profile_enable(False)
     solo = E.profile_entries()
-    # per-hit ratios E/H and E_filter/H from one instrumented (untimed) interval: deterministic, identical work
-    e_all = e_flt = 0.0
-    if not wl["rm"]:
-        E.set_count_examined(True)
-        sample = []
-        run_item(items[0], sample)
-        E.set_count_examined(False)
-        sH = max(sum(s["num_hits"] for s in sample), 1)
-        e_all = sum(s["num_examined"] for s in sample) / sH          # E per hit (reference algorithm)
-        e_flt = sum(s["num_examined_filter"] for s in sample) / sH   # bases per hit scored by the filter kernel
+    # per-hit ratios E/H and E_filter/H (the reference algorithm's examined bases) from one instrumented, untimed slice
+    E.set_count_examined(True)
+    sample = []
+    for j in jobs[:max(1, len(jobs) // 10)]:
+        run_job(j, sample)
+    E.set_count_examined(False)
+    sH = max(sum(s["num_hits"] for s in sample), 1)
+    e_all = sum(s["num_examined"] for s in sample) / sH          # E per hit (reference algorithm)
+    e_flt = sum(s["num_examined_filter"] for s in sample) / sH   # bases per hit the per-base filter kernel scores
 
     def totals(stats):
         return (sum(s["num_hits"] for s in stats), sum(s["num_survivors"] for s in stats), sum(s["num_seeds"] for s in stats),
                 sum(s["num_candidates"] for s in stats))
 
     H, A, S, Cn = totals(call_stats)
-    sH, sA, sS, sC = totals(solo_stats)
+    sH2, sA, sS, sC = totals(solo_stats)
     table_direct = "seed_probe" in prof
-    ctx_filter = "extend_filter2" in prof   # context-table calls: filter = level 1 (context records) + level 2 (packed kernel)
-    scope_kernels = dict(SCOPE_KERNELS, **(CTX_SCOPE_KERNELS if ctx_filter else {}))
-    filter_scopes = ["extend_filter", "extend_filter2"] if ctx_filter else ["extend_filter"]
-    # algorithmic bytes (SURVEY 8d, restated per kernel in DESIGN.md 4):
-    #   seed lookup                      : 16*S            (8 B seed word + 8 B bucket extent per seed word)
-    #   lookup + expansion               : 16*S + 12*H     (hit list materialised)   /  16*S + 4*H  (fused into extension)
-    #   X-drop filter                    : h*H + 2*E_filter + 12*C   with h = 8 (hit records in) or 4 (table-direct: run entries in)
-    #   extension as a whole             : h*H + 2*E + 20*A
-    hin = 4.0 if table_direct else 8.0
-
-    def alg(h, a, s, c):
-        return {"seed_lookup": 16.0 * s, "expand_hits": 12.0 * h, "extend_filter": hin * h + 2.0 * e_flt * h + 12.0 * c,
-                "extension_total": hin * h + 2.0 * e_all * h + 20.0 * a,
-                "lookup_expand": 16.0 * s + (4.0 if table_direct else 12.0) * h}
-
-    alg_t, alg_s = alg(H, A, S, Cn), alg(sH, sA, sS, sC)
+    ctx_filter = "extend_filter2" in prof   # context-table calls: level 1 (class filter on the records) + level 2 (packed kernel)
+    words = 13 if wl["transition"] else 1
     lookup_scope = "seed_probe" if table_direct else "seed_lookup"
 
     def ms_of(p, scopes):
         return sum(p[k][0] for k in scopes if k in p)
 
     def rate(nbytes, ms):
-        return (nbytes / (ms * 1e-3) / 1e9) if ms > 0 else None
+        return (nbytes / (ms * 1e-3) / 1e9) if ms and ms > 0 else None
 
-    def block(name, scopes, nbytes_t, nbytes_s, formula):
-        a_t, a_s = rate(nbytes_t, ms_of(prof, scopes)), rate(nbytes_s, ms_of(solo, scopes))
-        return {"scopes": scopes, "bytes": formula,
-                "achieved": round(a_t, 1) if a_t else None, "frac": round(a_t / HBM_PEAK_GBS, 4) if a_t else None,
-                "single_stream": {"achieved": round(a_s, 1) if a_s else None, "frac": round(a_s / HBM_PEAK_GBS, 4) if a_s else None}}
+    def frac(r):
+        return round(r / HBM_PEAK_GBS, 4) if r else None
 
     kernels = {k: {"ms_total": round(v[0], 3), "launches": v[1], "avg_us": round(1e3 * v[0] / max(v[1], 1), 2)}
                for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
     gpu_ms = sum(v[0] for v in prof.values())
     name, (ms, launches) = max(prof.items(), key=lambda kv: kv[1][0])
-    if name == "extend_filter" and ctx_filter:
-        # 4*H + 2*E_filter + 12*C is the work of the WHOLE filter stage (every hit scored until it drops), so it is divided by
-        # the time of both levels: level 1 alone only looks at the 48 + 64 context bases of a hit
-        ms = ms_of(prof, filter_scopes)
-    per_scope_bytes = {"extend_filter": ("extend_filter", "%g*H + 2*E_filter + 12*C" % hin), lookup_scope: ("seed_lookup", "16*S"),
-                       "expand_hits": ("expand_hits", "12*H")}
-    key, formula = per_scope_bytes.get(name, (None, None))
-    achieved = rate(alg_t[key], ms) if key else None
-    traffic_db, traffic_src, kstats = committed_profile(args, E)
-    check = profile_check(prof, solo, kstats, args, scope_kernels)
-    if name == "extend_filter":
-        symbol = "extend_filter_ctx_kernel" if ctx_filter else FILTER_KERNELS.get(E.filter_mode())
-    else:
-        symbol = (scope_kernels.get(name) or [None])[0]
+    symbol = {"extend_filter": "extend_filter_cls_kernel" if ctx_filter else FILTER_KERNELS.get(E.filter_mode()),
+              "extend_filter2": "extend_filter_packed_kernel"}.get(name) or (SCOPE_KERNELS.get(name) or [None])[0]
 
-    def traffic_of(sym, launches_in_scope=1):
-        if not traffic_db or not sym or sym not in traffic_db or not check["ok"]:
-            return None
-        return int(traffic_db[sym]["hbm_bytes"])
+    # bytes the layout moves, per scope, from exact counts (h = hits, s = seed words, c = candidates, a = survivors)
+    def moved(h, a, s, c):
+        pos = s / words                                   # valid query positions (non-empty ones are fewer: upper bound on TdRec bytes)
+        fwd = 0.045 * h                                   # hits level 1 forwards (measured 4.3-4.5 %; 24-byte L2Rec each)
+        return {"extend_filter": (28.0 * h + 16.0 * pos + h / 8.0 + 24.0 * fwd) if ctx_filter else ((4.0 if table_direct else 8.0) * h + 12.0 * c),
+                "extend_filter2": 24.0 * fwd + 12.0 * c,
+                lookup_scope: (9.0 * pos + 12.0 * pos + 16.0 * pos) if table_direct else 16.0 * s,
+                "expand_hits": 12.0 * h}
 
-    def first_class(scope, alg_key, formula):
-        """a kernel of its own standing: algorithmic fraction (timed region + single stream) and measured-traffic ratio"""
+    mv_t, mv_s = moved(H, A, S, Cn), moved(sH2, sA, sS, sC)
+    formula = {"extend_filter": "28*H + 16*P + H/8 + 24*F  (context records + position records + head bits + forwarded records)" if ctx_filter
+                                else "%g*H + 12*C" % (4.0 if table_direct else 8.0),
+               "extend_filter2": "24*F + 12*C", lookup_scope: "37*P  (9 B codes + 12 B scratch + 16 B extent per position)" if table_direct else "16*S",
+               "expand_hits": "12*H"}.get(name)
+    achieved = rate(mv_t[name], ms) if name in mv_t else None
+    s_ms = solo[name][0] if name in solo else None
+    s_n = solo[name][1] if name in solo else 0
+    single = None
+    if name in mv_s and s_ms:
+        sg = rate(mv_s[name], s_ms)
+        single = {"avg_launch_us": round(1e3 * s_ms / max(s_n, 1), 2), "achieved": round(sg, 1), "frac": frac(sg),
+                  "note": "same kernel, one call in flight (no second stream sharing the GPU); untimed extra pass"}
+
+    traffic_db, traffic_src, kstats, pmc = committed_profile(args, E)
+    check = profile_check(prof, solo, kstats, args)
+    traffic = int(traffic_db[symbol]["hbm_bytes"]) if (traffic_db and symbol in traffic_db and check["ok"]) else None
+    counters = None
+    bound = "hbm"
+    if pmc and symbol in pmc and check["ok"]:
+        c = pmc[symbol]
+        hits_per_launch = (sH2 / max(s_n, 1)) if s_n else None
+        counters = {
+            "source": traffic_src.replace("traffic.json", "pmc*.txt") if traffic_src else None,
+            "valu_insts_per_hit": round(c["SQ_INSTS_VALU"] * 64.0 / hits_per_launch / 64.0, 3) if (hits_per_launch and "SQ_INSTS_VALU" in c) else None,
+            "valu_wave_insts_per_64_hits": round(c["SQ_INSTS_VALU"] / (hits_per_launch / 64.0), 1) if (hits_per_launch and "SQ_INSTS_VALU" in c) else None,
+            "lds_wave_insts_per_64_hits": round(c["SQ_INSTS_LDS"] / (hits_per_launch / 64.0), 1) if (hits_per_launch and "SQ_INSTS_LDS" in c) else None,
+            "lds_conflict_frac": round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], 3) if c.get("SQ_LDS_IDX_ACTIVE") else None,
+            "wait_frac": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3) if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in c else None,
+            # VALU busy share of a SIMD: active VALU quad-cycles over the quad-cycles its (up to) 8 resident waves existed / 8
+            "valu_busy_frac": round(8.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"], 3) if c.get("SQ_WAVE_CYCLES") and "SQ_ACTIVE_INST_VALU" in c else None,
+        }
+        hb = (traffic / (1e3 * s_ms / max(s_n, 1) * 1e-6) / 1e9 / HBM_PEAK_GBS) if (traffic and s_ms) else 0.0
+        if (counters["valu_busy_frac"] or 0.0) > max(hb, 0.5):
+            bound = "valu_issue"
+    per_step_scale = 1.0 / max(args.steps, 1)
+
+    def first_class(scope, key, alg_bytes_t, alg_bytes_s, alg_formula):
+        """a kernel of its own standing (the seed lookup north_star names): moved bytes and reference-form bytes, both fractions"""
         if scope not in prof or not prof[scope][1]:
             return None
-        sym = scope_kernels[scope][0]
-        n_t, n_s = prof[scope][1], max(solo.get(scope, (0, 0))[1], 1)
-        a_t = rate(alg_t[alg_key], prof[scope][0])
-        a_s = rate(alg_s[alg_key], solo[scope][0]) if scope in solo else None
-        tr = traffic_of(sym)
-        abl = alg_t[alg_key] / n_t
-        return {"kernel_symbol": sym, "bytes": formula, "algorithmic_bytes_per_launch": round(abl),
-                "avg_launch_us": round(1e3 * prof[scope][0] / n_t, 2), "algorithmic_frac": round(a_t / HBM_PEAK_GBS, 4) if a_t else None,
-                "single_stream": {"avg_launch_us": round(1e3 * solo[scope][0] / n_s, 2) if scope in solo else None,
-                                  "algorithmic_frac": round(a_s / HBM_PEAK_GBS, 4) if a_s else None},
-                "traffic": tr, "traffic_ratio": round(tr / abl, 3) if (tr and abl) else None}
+        sym = SCOPE_KERNELS[scope][0]
+        n_t = prof[scope][1]
+        tr = int(traffic_db[sym]["hbm_bytes"]) if (traffic_db and sym in traffic_db and check["ok"]) else None
+        s_us = 1e3 * solo[scope][0] / max(solo[scope][1], 1) if scope in solo else None
+        return {"kernel_symbol": sym, "avg_launch_us": round(1e3 * prof[scope][0] / n_t, 2),
+                "bytes": formula if scope == name else moved_formula(scope, table_direct), "frac": frac(rate(mv_t[key], prof[scope][0])),
+                "single_stream": {"avg_launch_us": round(s_us, 2) if s_us else None,
+                                  "frac": frac(rate(mv_s[key], solo[scope][0])) if scope in solo else None,
+                                  "traffic_frac": round(tr / (s_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if (tr and s_us) else None},
+                "traffic": tr,
+                "algorithmic_equiv": {"bytes": alg_formula, "frac": frac(rate(alg_bytes_t, prof[scope][0])),
+                                      "single_stream_frac": frac(rate(alg_bytes_s, solo[scope][0])) if scope in solo else None,
+                                      "note": "SURVEY 8(d) reference-form bytes (8 B seed word + 8 B extent per seed word); one probe per POSITION "
+                                              "replaces 13 per position, so fewer bytes really move"}}
 
-    traffic = traffic_of(symbol)
-    solo_ms = (ms_of(solo, filter_scopes) if (name == "extend_filter" and ctx_filter) else solo[name][0]) if name in solo else None
-    s_avg_us = 1e3 * solo_ms / max(solo[name][1], 1) if name in solo else None
-    single = None
-    if key and name in solo and solo[name][1]:
-        sg = rate(alg_s[key], solo_ms)
-        single = {"avg_launch_us": round(s_avg_us, 2), "achieved": round(sg, 1), "frac": round(sg / HBM_PEAK_GBS, 4),
-                  "note": "same kernel, one call in flight (no overlap with a second stream); untimed extra pass"}
+    ext_scopes = [s for s in EXTENSION_SCOPES if s in prof]
     return {
-        "bound": "hbm", "kernel": name, "kernel_symbol": symbol, "bytes": formula,
-        "kernel_scopes": filter_scopes if name == "extend_filter" else [name],
-        "note": ("context-table filter: the bytes are the algorithmic figure of the whole filter stage (1 byte per examined base and "
-                 "sequence), the duration is level 1 + level 2; the kernel itself streams 32-byte context records + 4-bit query "
-                 "windows (measured traffic below the algorithmic bytes) and is bound by VALU / LDS / address path, not HBM -- DESIGN.md 4"
-                 ) if (name == "extend_filter" and ctx_filter) else None,
-        "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-        "traffic": traffic, "traffic_source": traffic_src, "profile_check": check,
-        "traffic_ratio": round(traffic / (alg_t[key] / max(launches, 1)), 3) if (traffic and key) else None,
-        # the same traffic counted in 128-byte lines against the measured random-gather ceiling of the chip
-        "random_line_roofline": ({"lines_per_launch": int(traffic // 128), "peak_lines_per_s": RANDOM_LINES_PER_S,
-                                  "frac_single_stream": round(traffic / 128 / (s_avg_us * 1e-6) / RANDOM_LINES_PER_S, 4)}
-                                 if (traffic and s_avg_us) else None),
-        "calls_in_flight": max(1, args.host_threads) * max(1, args.intervals_in_flight), "single_stream": single,
+        "bound": bound, "kernel": name, "kernel_symbol": symbol, "bytes": formula,
+        "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac(achieved),
         "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
-        "algorithmic_bytes_per_launch": round(alg_t[key] / max(launches, 1)) if key else None,
+        "bytes_per_launch": round(mv_t[name] / max(launches, 1)) if name in mv_t else None,
+        "note": "timed region: %d calls in flight share the GPU, so a launch's duration includes the time it waits for CUs held by "
+                "the other calls' kernels; single_stream is the same kernel alone" % (max(1, args.host_threads) * max(1, args.intervals_in_flight)),
+        "single_stream": single,
+        "traffic": traffic, "traffic_source": traffic_src, "profile_check": check,
+        "traffic_frac_single_stream": round(traffic / (1e3 * s_ms / max(s_n, 1) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if (traffic and s_ms and s_n) else None,
+        "counters": counters,
         "dominant_share_of_gpu_time": round(ms / gpu_ms, 4) if gpu_ms else None,
-        "table_direct": table_direct,
+        "per_step": {"ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 3),
+                     "moved_bytes_dominant": round(mv_t.get(name, 0.0) * per_step_scale),
+                     "counter_bytes_dominant": round(traffic * launches * per_step_scale) if traffic else None,
+                     "dominant_kernel_ms_single_stream": round((s_ms / max(s_n, 1)) * launches * per_step_scale, 3) if s_ms else None,
+                     "hits": round(H * per_step_scale)},
+        "algorithmic_equiv": {
+            "bytes": "%g*H + 2*E + 20*A over the whole extension stage (SURVEY 8d: one byte per examined base and sequence)" % (4.0 if table_direct else 8.0),
+            "equiv_gbs": round(rate((4.0 if table_direct else 8.0) * H + 2.0 * e_all * H + 20.0 * A, ms_of(prof, ext_scopes)) or 0.0, 1),
+            "note": "what the reference's byte-per-base layout would have to move for the same work in the same time; NOT a bandwidth of "
+                    "this engine (2-bit / 4-bit packing and the context records move a fraction of it) and therefore not compared with the peak"},
         "per_hit": {"examined_bases_E": round(e_all, 2), "examined_by_filter": round(e_flt, 2),
                     "candidate_frac": round(Cn / max(H, 1), 5), "survivor_frac": round(A / max(H, 1), 5),
                     "hits_per_seed_word": round(H / max(S, 1), 3)},
-        # the kernel north_star names: seed lookup.  Table-direct: probe_kernel (one probe per query POSITION into the
-        # neighbourhood table; the 13 seed words of a position are never materialised, so its traffic is BELOW 16*S)
-        "seed_lookup": first_class(lookup_scope, "seed_lookup", "16*S"),
-        "expand_hits": first_class("expand_hits", "expand_hits", "12*H"),
-        "lookup_expand": block("lookup_expand", [lookup_scope, "probe_compact", "hit_prefix_scan", "expand_hits"], alg_t["lookup_expand"],
-                               alg_s["lookup_expand"], "16*S + 4*H over probe + compact (run entries are read by the filter)"
-                               if table_direct else "16*S + 12*H over lookup + prefix scan + expansion"),
-        "extension_total": block("extension_total", EXTENSION_SCOPES, alg_t["extension_total"], alg_s["extension_total"],
-                                 "%g*H + 2*E + 20*A over filter + chain grouping/link + exact + entropy kernels" % hin),
+        "table_direct": table_direct,
+        # the kernel north_star names: seed lookup.  Table-direct: probe_kernel -- one probe per query POSITION into the neighbourhood table
+        "seed_lookup": first_class(lookup_scope, lookup_scope, 16.0 * S, 16.0 * sS, "16*S"),
         "kernels": kernels,
     }
 
 
+def moved_formula(scope, table_direct):
+    return {"seed_probe": "37*P  (9 B codes + 12 B scratch + 16 B extent per position)", "seed_lookup": "16*S", "expand_hits": "12*H"}.get(scope)
+
+
+def dropin_leg(E, jobs, args, seed_size, words):
+    """What an UNMODIFIED reference host gets: g_SeedAndFilter with host seed vectors (src/seeder.cpp:57-78), one 250 kbp chunk per
+    call, 26 MB of seed words over PCIe per call.  Untimed w.r.t. `value`; measured here on the chunks of the first interval, with the
+    same number of calls in flight.  The vectors are produced by the engine's own device seeder and copied to the host first (they are
+    word for word what the host loop emits, tests/test_gpu_parity.py); the host's own seeding loop is NOT in this time."""
+    from concurrent.futures import ThreadPoolExecutor
+    chunks = []
+    for j in [j for j in jobs if j["interval"] == 0]:
+        for a in range(j["a"], j["b"], args.chunk):
+            chunks.append((a, min(a + args.chunk, j["b"]), j["rev"]))
+    vecs = [E.device_make_seeds(a, b, rev, 0, per=words) for (a, b, rev) in chunks]
+    paths = []
+
+    def one(i):
+        a, b, rev = chunks[i]
+        if vecs[i].size == 0:
+            return 0
+        out = E.SeedAndFilter(vecs[i], rev, 0)
+        paths.append(E.last_call_stats()["lookup_path"])
+        return out.size - 1
+
+    nthreads = max(1, args.host_threads) * max(1, args.intervals_in_flight)
+    with ThreadPoolExecutor(nthreads) as p:
+        list(p.map(one, range(min(len(chunks), 8))))  # warm the slots' buffers
+        paths.clear()
+        t0 = time.perf_counter()
+        n = sum(p.map(one, range(len(chunks))))
+        dt = time.perf_counter() - t0
+    bases = sum(b - a for (a, b, rev) in chunks if not rev)
+    return {"value_gbps": round(bases / dt / 1e9, 4), "calls": len(chunks), "calls_in_flight": nthreads, "hsps": int(n),
+            "pcie_bytes_per_call": int(np.mean([v.size for v in vecs]) * 8), "mode": int(max(set(paths), key=paths.count)) if paths else None,
+            "mode_note": "sa_call_stats.lookup_path of the calls: 2 = the host vector was verified on the device and looked up table-direct "
+                         "with target context; 0 = reference-shaped seed-word path",
+            "note": "drop-in entry sa_seed_and_filter = g_SeedAndFilter: one chunk per call, seed vector over PCIe; first interval, both strands"}
+
+
 def committed_profile(args, E):
-    """(traffic per kernel symbol, source path, kernel_stats averages) of the newest profiles/rNN collected on THIS workload
-    shape; (None, None, None) if there is none.  bench.py cannot run the PMC passes on itself (separate rocprofv3 runs,
-    tools/profile_bench.sh), so measured HBM traffic comes from the committed collection and is only quoted while the
-    collection matches the run: same workload key, and kernel durations that agree (profile_check)."""
+    """(traffic per kernel symbol, source path, kernel_stats averages, PMC counters per kernel symbol) of the newest profiles/rNN
+    collected on THIS workload shape; Nones if there is none.  bench.py cannot run the PMC passes on itself (separate rocprofv3
+    runs, tools/profile_bench.sh), so measured HBM traffic and counters come from the committed collection and are only quoted
+    while the collection matches the run: same workload key, and kernel durations that agree (profile_check)."""
     other = None
     for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*")), reverse=True):
         tj, ks, wk = os.path.join(d, "traffic.json"), os.path.join(d, "kernel_stats.txt"), os.path.join(d, "workload.json")
@@ -509,13 +589,24 @@ def committed_profile(args, E):
                 if m and m.group(1) not in stats:
                     stats[m.group(1)] = (int(m.group(2)), float(m.group(4)))
             stats["__single_stream__"] = bool(key.get("single_stream"))
-            return json.load(open(tj)), os.path.relpath(tj, ROOT), stats
+            pmc = {}
+            for pf in sorted(glob.glob(os.path.join(d, "pmc*.txt"))):
+                cur = None
+                for line in open(pf):
+                    m = re.match(r"\s+(?:sa::)?(\w+).*dispatches=(\d+)", line)
+                    if m:
+                        cur = m.group(1)
+                        continue
+                    m = re.match(r"\s+(\w+)\s+sum=(\S+)\s+per_dispatch=(\S+)", line)
+                    if m and cur:
+                        pmc.setdefault(cur, {}).setdefault(m.group(1), float(m.group(3)))
+            return json.load(open(tj)), os.path.relpath(tj, ROOT), stats, pmc
         except Exception:
             continue
-    return None, other, None
+    return None, other, None, None
 
 
-def profile_check(prof, solo, kstats, args, scope_kernels=SCOPE_KERNELS):
+def profile_check(prof, solo, kstats, args):
     """Does the committed rocprofv3 collection describe the kernels of THIS run?  (With several calls in flight a kernel's
     duration depends on what it overlaps with, which a tracer perturbs: collections made with ONE call in flight -- workload.json
     "single_stream" -- are compared with this run's own single-stream launches instead.)  Per scope, the committed
@@ -530,7 +621,7 @@ def profile_check(prof, solo, kstats, args, scope_kernels=SCOPE_KERNELS):
     for scope in ("extend_filter", "extend_filter2", "seed_probe", "seed_lookup", "expand_hits"):
         if scope not in prof or not prof[scope][1]:
             continue
-        committed = sum(kstats[k][1] for k in scope_kernels[scope] if k in kstats)
+        committed = sum(kstats[k][1] for k in PROFILE_SCOPE_KERNELS[scope] if k in kstats)
         scale = (args.steps + args.warmup) / max(args.steps, 1)
         s_ms, s_n = solo.get(scope, (0.0, 0))
         if single:
@@ -549,23 +640,26 @@ def profile_check(prof, solo, kstats, args, scope_kernels=SCOPE_KERNELS):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-def dry_run(args, rank, world, dist, torch, shard):
-    """Everything of the bench contract that does not need a GPU: the REAL interval plan, rank walk and chunk arithmetic
-    around a stub engine whose 'HSP count' is a checksum of the chunk bounds it was handed -- a wrong shard, walk or
-    reduction changes the output."""
+def dry_run(args, rank, world, dist, torch, shard, scaling):
+    """Everything of the bench contract that does not need a GPU: the REAL interval plan, call list, rank partition (strong) or
+    rank walk (weak) and chunk arithmetic around a stub engine whose 'HSPs' are a checksum of the chunk bounds it was handed -- a
+    wrong partition, walk or reduction changes the output.  In the strong mode the checksum of a pass is independent of the
+    number of ranks (every call exactly once), which tests/test_multi_rank.py checks for world 1 / 2 / 3."""
     qlen = int((args.target_mbp or 100.0) * 1e6)
     seed_size = len(SHAPE)
     items = shard.plan_intervals(qlen, seed_size, args.interval)
+    jobs = shard.call_jobs(items, qlen - seed_size, args.chunk, 16)
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
     bases, check = 0, 0
     for k in range(args.steps):
-        for i, iv in enumerate(my_intervals(items, rank, k)):
-            bases += iv[1] - iv[0]
-            for rev in (False, True):  # the stub engine: "HSPs" = a checksum of the chunk bounds, weighted by the walk position
-                for (a, b) in shard.chunks_of(iv, args.chunk, qlen - seed_size, rev):
-                    check += (i + 1) * ((a * 31 + b * 17 + int(rev)) % 1000003)
+        todo = shard.partition(jobs, rank, world) if scaling == "strong" else rotate(jobs, rank + k)
+        for i, j in enumerate(todo):
+            bases += 0 if j["rev"] else j["b"] - j["a"]
+            w = 1 if scaling == "strong" else (i + 1)  # (weak: weighted by the walk position, so the walk order is checked too)
+            for a in range(j["a"], j["b"], args.chunk):  # the stub engine: a checksum of the chunk bounds of the call
+                check += w * ((a * 31 + min(a + args.chunk, j["b"]) * 17 + int(j["rev"])) % 1000003)
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -579,8 +673,8 @@ def dry_run(args, rank, world, dist, torch, shard):
     if rank == 0:
         print(json.dumps({"metric": "Gbp query seeded+filtered+extended per sec", "value": bases / max(elapsed, 1e-9) / 1e9,
                           "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": "int32", "data": "dry-run", "config": {"workload": "dry-run"},
+                          "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True, "scaling": scaling,
+                          "vs_baseline": None, "dtype": "int32", "data": "dry-run", "config": {"workload": "dry-run", "calls_per_step": len(jobs)},
                           "bases": bases, "checksum": check}))
     if dist is not None:
         dist.destroy_process_group()

@@ -86,7 +86,9 @@ void sa_clear_query(uint32_t buffer);
 /* ---- the hot call ---------------------------------------------------------------------------------------- */
 
 /* g_SeedAndFilter, src/seed_filter.h:6 ; def src/seed_filter.cu:682-828.
- * seeds[i] = (key << 32) + query_position (src/seeder.cpp:60-61).  Returns the element count of *out
+ * seeds[i] = (key << 32) + query_position (src/seeder.cpp:60-61).  A vector that is what src/seeder.cpp:57-74 emits for the
+ * positions it spans (checked on the device) is looked up table-direct like sa_seed_and_filter_range; any other vector takes the
+ * reference-shaped path (sa_call_stats.lookup_path tells which).  Returns the element count of *out
  * (>= 1): out[0] is the header {len = total anchors, score = (int)num_hits} (seed_filter.cu:806-809), followed by
  * the HSPs of each iteration in order.  *out is owned by the caller; release with sa_free_segments. */
 size_t sa_seed_and_filter(const uint64_t* seeds, size_t num_seeds, int rev, uint32_t buffer, sa_segment_pair** out);
@@ -116,6 +118,23 @@ struct sa_call_stats; /* defined below */
 size_t sa_seed_interval(uint32_t start, uint32_t end, uint32_t q_len, int strands, uint32_t buffer, int threads,
                         sa_segment_pair** out_fw, size_t* n_fw, sa_segment_pair** out_rc, size_t* n_rc,
                         struct sa_call_stats* totals);
+
+/* Additive: a LIST of independent calls, each up to sa_max_chunks_per_call() consecutive chunks [start, end) of strand `rev` (in
+ * that strand's coordinates), run with `threads` of them in flight on the engine's persistent worker pool (the reference keeps one
+ * seeder body per TBB worker in flight, src/main.cpp:565-573).  results[i].hsps: the HSPs of call i -- its chunks concatenated in
+ * order, headers removed -- owned by the caller (sa_free_segments).  This is the unit a multi-GPU host deals out: every call of a
+ * pass is independent, so any partition of the list over devices or processes gives identical results. */
+typedef struct sa_call_desc {
+    uint32_t start, end;
+    int rev;
+} sa_call_desc;
+typedef struct sa_call_result {
+    sa_segment_pair* hsps;
+    size_t num_hsps;
+    uint64_t num_hits;
+} sa_call_result;
+size_t sa_seed_calls(const sa_call_desc* calls, size_t num_calls, uint32_t buffer, int threads, sa_call_result* results,
+                     struct sa_call_stats* totals /* nullable: sums over the calls */);
 
 /* ---- repeat-masker variant (repeat_masker_src/seed_filter.h:4-8) ----------------------------------------- */
 
@@ -214,6 +233,9 @@ typedef struct sa_call_stats {
     uint64_t num_entropy;   /* hits that needed the entropy factor */
     uint32_t num_iter;
     int device;
+    int lookup_path;        /* seed lookup path the call took: 0 general (seed words -> buckets -> hit list), 1 table-direct,
+                               2 table-direct with target context (sa_get_lookup_mode) */
+    int reserved;
 } sa_call_stats;
 void sa_get_last_call_stats(sa_call_stats* out); /* stats of the calling thread's most recent hot call */
 void sa_set_count_examined(int on);

@@ -17,6 +17,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <functional>
+#include <memory>
 #include <atomic>
 #include <mutex>
 #include <thread>
@@ -258,6 +261,8 @@ struct Slot {
     TdPlan* h_td_plan = nullptr;      // pinned
     IterPlan* d_plan = nullptr;       // SA_MAX_CHUNKS plans (one per chunk of a multi-chunk call)
     Counters* d_cnt = nullptr;
+    uint32_t* d_verify = nullptr;     // drop-in calls: "the host seed vector is what the device seeder would emit" (seeds.hip)
+    uint32_t* h_verify = nullptr;     // pinned
     DevBuf<uint32_t> out_seg;         // segment id of every final record (multi-chunk calls split their output by it)
     uint32_t* d_seg_info = nullptr;   // per-segment counts / offsets of the LDS dedup (dedup.hip)
     uint32_t* h_seg_info = nullptr;   // pinned
@@ -413,6 +418,19 @@ static size_t arena_mapped(Arena& A) {
     std::lock_guard<std::mutex> lk(A.mu);
     return A.mapped;
 }
+// One arena per device ordinal for the life of the process: cleared device pages cost seconds to get, so they are kept across
+// ShutdownProcessor / InitializeInterface cycles (option arena_gb = 0 gives them back at ShutdownProcessor).
+static Arena& arena_of(int ordinal) {
+    static std::mutex mu;
+    static std::vector<Arena*> arenas;  // (never destroyed: worker threads may outlive static destruction)
+    std::lock_guard<std::mutex> lk(mu);
+    if ((int)arenas.size() <= ordinal) arenas.resize((size_t)ordinal + 1, nullptr);
+    if (!arenas[ordinal]) {
+        arenas[ordinal] = new Arena();
+        arenas[ordinal]->dev = ordinal;
+    }
+    return *arenas[ordinal];
+}
 
 struct DevCtx {
     int dev = 0;
@@ -448,7 +466,9 @@ struct DevCtx {
     uint32_t* nbr_pos = nullptr;         // == pos_table when no transition word exists (nbr_alias); null when nbr_ctx is built
     Ctx28* nbr_ctx28 = nullptr;          // the runs WITH their target context: 28-byte records + nbr_pos as the side array (class filter, extend.hip 1d)
     bool nbr_pos_in_arena = false;       // nbr_pos lies inside the arena (not freed on its own)
-    Arena arena;                         // memory of the context table: outlives a target block, grown in the background
+    Arena& arena;                        // memory of the context table: outlives target blocks AND engine contexts (a process-wide
+                                         // cache per device ordinal, see arena_of), grown in the background
+    explicit DevCtx(Arena& a) : arena(a) {}
     bool nbr_alias = false;
     uint64_t nbr_total = 0;
     uint32_t nbr_tmask = 0;
@@ -599,6 +619,7 @@ static void slot_init(Slot& s, int dev) {
     hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
     s.d_plan = (IterPlan*)dev_malloc(sizeof(IterPlan) * SA_MAX_CHUNKS, "plan");
     s.d_cnt = (Counters*)dev_malloc(sizeof(Counters), "counters");
+    s.d_verify = (uint32_t*)dev_malloc(sizeof(uint32_t), "seed verify flag");
     s.d_cov_range = (uint32_t*)dev_malloc(2 * sizeof(uint32_t), "coverage range");
     s.d_td_bounds = dev_malloc(probe_bounds_bytes(), "probe bounds");
     s.d_seg_info = (uint32_t*)dev_malloc(dedup_seg_info_words() * sizeof(uint32_t), "segment info");
@@ -608,6 +629,7 @@ static void slot_init(Slot& s, int dev) {
         hipHostMalloc((void**)&s.h_plan, sizeof(IterPlan) * SA_MAX_CHUNKS) != hipSuccess ||
         hipHostMalloc((void**)&s.h_td_plan, sizeof(TdPlan) * SA_MAX_CHUNKS) != hipSuccess ||
         hipHostMalloc((void**)&s.h_seg_info, dedup_seg_info_words() * sizeof(uint32_t)) != hipSuccess ||
+        hipHostMalloc((void**)&s.h_verify, sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc((void**)&s.h_cnt, sizeof(Counters)) != hipSuccess) {
         fprintf(stderr, "Error: hipHostMalloc for slot staging failed\n");
         exit(12);
@@ -635,7 +657,9 @@ static void slot_destroy(Slot& s) {
     if (s.h_td_plan) hipHostFree(s.h_td_plan);
     s.h_td_plan = nullptr;
     dev_free(s.d_plan, "plan"); dev_free(s.d_cnt, "counters"); dev_free(s.d_cov_range, "coverage range");
-    s.d_plan = nullptr; s.d_cnt = nullptr; s.d_cov_range = nullptr;
+    dev_free(s.d_verify, "seed verify flag");
+    if (s.h_verify) hipHostFree(s.h_verify);
+    s.d_plan = nullptr; s.d_cnt = nullptr; s.d_cov_range = nullptr; s.d_verify = nullptr; s.h_verify = nullptr;
     if (s.h_cov) hipHostFree(s.h_cov);
     s.h_cov = nullptr;
     s.out_seg.release("out seg");
@@ -1143,6 +1167,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
     }
     prof_flush(sl);
 
+    t_stats.lookup_path = ca.td ? ((dc->nbr_ctx28 && ca.q2_own && ca.q2_own->base) ? 2 : 1) : 0;
     t_stats.num_hits = num_hits;
     t_stats.num_survivors = survivors;
     t_stats.num_anchors = n_final;
@@ -1458,6 +1483,38 @@ static const uint8_t* upload_ascii(DevCtx* dc, const char* src, size_t len, cons
     return dc->up_tmp.p;
 }
 
+// DROP-IN FAST PATH.  g_SeedAndFilter hands the engine a host seed vector (src/seeder.cpp:57-78).  When that vector is exactly
+// what the device seeder would emit for the positions it spans -- checked on the device, one lane per position group, plus the
+// probe's own count of valid positions -- the call is the same as sa_seed_and_filter_range(first, last + 1) and takes the
+// table-direct path (one probe per position, record-stream filter).  Anything else keeps the reference-shaped path on the
+// uploaded words: hand-made vectors, and the reference's minus-strand arena when the query holds other IUPAC letters (H14).
+// Returns the seed-word count of the table-direct call, or UINT32_MAX.
+static uint32_t dropin_td_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, uint32_t qlen, const uint64_t* host_seeds, size_t n,
+                                const PackedBuf* q4, int rm, uint32_t* first_out, uint32_t* end_out, uint32_t* words_out) {
+    if (n == 0 || !td_eligible(dc, q4)) return 0xFFFFFFFFu;
+    const uint32_t tmask = seed_tmask();
+    const uint32_t per = 1u + (uint32_t)__builtin_popcount(tmask);
+    if (n % per != 0 || n > 0xFFFFFFFFull) return 0xFFFFFFFFu;
+    const uint32_t first = (uint32_t)host_seeds[0], last = (uint32_t)host_seeds[n - 1];
+    if (last < first || (uint64_t)last + g_seed_size > qlen) return 0xFFFFFFFFu;
+    hipStream_t st = sl->stream;
+    SeedShape sh = g_shape;
+    sh.span = (int)g_seed_size;
+    *sl->h_verify = 0;
+    check_memcpy(hipMemsetAsync(sl->d_verify, 0xFF, sizeof(uint32_t), st), "seed verify flag");
+    {
+        ProfScope p(sl, "seed_verify");
+        launch_seed_verify(sl->seeds.p, (uint32_t)(n / per), per, qcodes, qlen, sh, tmask, sl->d_verify, st);
+    }
+    check_memcpy(hipMemcpyAsync(sl->h_verify, sl->d_verify, sizeof(uint32_t), hipMemcpyDeviceToHost, st), "seed verify flag");
+    const uint32_t bp[2] = {first, last + 1u};
+    const uint32_t ns = td_front(dc, sl, qcodes, 1, bp, rm, words_out);  // (synchronises the stream: the flag has arrived)
+    if (ns == 0xFFFFFFFFu || *sl->h_verify == 0u || (uint64_t)ns != (uint64_t)n) return 0xFFFFFFFFu;
+    *first_out = first;
+    *end_out = last + 1u;
+    return ns;
+}
+
 // code presence of a freshly encoded block -> *host_mask (one small D2H; the callers synchronise the admin stream anyway)
 static void presence_of(DevCtx* dc, const uint8_t* codes, uint32_t len, int slot, uint32_t* host_mask) {
     if (!dc->d_present) dc->d_present = (uint32_t*)dev_malloc((1 + SA_BUFFER_DEPTH) * sizeof(uint32_t), "code presence");
@@ -1578,6 +1635,89 @@ static void require_proc(const char* who, uint32_t buffer) {  // hot entry point
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent host worker pool: the engine's own seeder threads (the reference keeps one seeder body per TBB worker,
+// src/main.cpp:565-573).  run_parallel(n, threads, fn) executes fn(0) .. fn(n-1) with at most `threads` of them in flight on pool
+// threads that live as long as the process -- no std::thread is created per interval call.  Several run_parallel calls may be
+// active at once (the host keeps several intervals in flight); each gets its own share of workers.
+// ------------------------------------------------------------------------------------------------------------------
+struct PoolBatch {
+    std::function<void(size_t)> fn;
+    size_t n = 0;
+    int want = 1;                 // workers this batch may occupy
+    int joined = 0;               // workers that took it (guarded by the pool mutex)
+    std::atomic<size_t> next{0};
+    std::atomic<size_t> done{0};
+    std::mutex mu;
+    std::condition_variable cv;
+};
+struct WorkPool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::shared_ptr<PoolBatch>> batches;
+    int workers = 0;
+};
+static WorkPool* g_pool = new WorkPool();  // (never destroyed: its detached workers wait on it until the process ends)
+
+static void pool_worker() {
+    WorkPool& P = *g_pool;
+    std::unique_lock<std::mutex> lk(P.mu);
+    for (;;) {
+        std::shared_ptr<PoolBatch> b;
+        for (auto& c : P.batches)
+            if (c->joined < c->want && c->next.load() < c->n) { b = c; break; }
+        if (!b) {
+            P.cv.wait(lk);
+            continue;
+        }
+        b->joined++;
+        lk.unlock();
+        for (;;) {
+            const size_t i = b->next.fetch_add(1);
+            if (i >= b->n) break;
+            b->fn(i);
+            if (b->done.fetch_add(1) + 1 == b->n) {
+                std::lock_guard<std::mutex> g(b->mu);
+                b->cv.notify_all();
+            }
+        }
+        lk.lock();
+    }
+}
+
+static void run_parallel(size_t n, int threads, std::function<void(size_t)> fn) {
+    if (n == 0) return;
+    threads = std::max(1, std::min<int>(threads, (int)n));
+    if (threads == 1) {  // the caller's own thread is the one seeder body
+        for (size_t i = 0; i < n; i++) fn(i);
+        return;
+    }
+    auto b = std::make_shared<PoolBatch>();
+    b->fn = std::move(fn);
+    b->n = n;
+    b->want = threads;
+    {
+        WorkPool& P = *g_pool;
+        std::lock_guard<std::mutex> lk(P.mu);
+        P.batches.push_back(b);
+        int wanted = 0;  // one worker per call the active batches may have in flight; the pool grows on demand and stays
+        for (auto& c : P.batches) wanted += c->want;
+        while (P.workers < std::min(wanted, 64)) {
+            std::thread(pool_worker).detach();
+            P.workers++;
+        }
+        P.cv.notify_all();
+    }
+    {
+        std::unique_lock<std::mutex> g(b->mu);
+        b->cv.wait(g, [&] { return b->done.load() == b->n; });
+    }
+    WorkPool& P = *g_pool;
+    std::lock_guard<std::mutex> lk(P.mu);
+    for (auto it = P.batches.begin(); it != P.batches.end(); ++it)
+        if (it->get() == b.get()) { P.batches.erase(it); break; }
+}
+
 }  // namespace sa
 
 using namespace sa;
@@ -1625,9 +1765,8 @@ int sa_initialize_interface(int num_gpu) {  // seed_filter_interface.cu:49-80
     for (int g = 0; g < use; g++) {
         const int ord = g_selected.empty() ? g : g_selected[g];
         check_set_device(ord, "InitializeInterface");
-        DevCtx* dc = new DevCtx();
+        DevCtx* dc = new DevCtx(arena_of(ord));
         dc->dev = ord;
-        dc->arena.dev = ord;
         hipStreamCreateWithFlags(&dc->admin, hipStreamNonBlocking);
         hipDeviceProp_t prop;
         hipGetDeviceProperties(&prop, ord);
@@ -1754,7 +1893,6 @@ static void destroy_interface() {  // re-initialisation of the interface: contex
     sa_shutdown_processor();
     for (auto* dc : g_dev) {
         check_set_device(dc->dev, "InitializeInterface");
-        arena_destroy(dc->arena);
         if (dc->admin) hipStreamDestroy(dc->admin);
         delete dc;
     }
@@ -1835,7 +1973,9 @@ void sa_generate_seed_pos_table(const char* ref_str, size_t start_addr, uint32_t
     const uint32_t num_steps = ref_length >= (uint32_t)shape_size ? (ref_length - (uint32_t)shape_size + offset) / step : 0;  // :64
     SeedShape sh = g_shape;
     sh.span = shape_size;
-    for (auto* dc : g_dev) {
+    // every device builds its own copy of the tables (the reference builds once on the host and replicates, seed_pos_table.cu:
+    // 33-47); the builds are independent, so with several devices they run CONCURRENTLY, one host thread per device
+    auto build_on = [&](DevCtx* dc) {
         check_set_device(dc->dev, "GenerateSeedPosTable");
         hipStream_t st = dc->admin;
         const uint8_t* codes = dc->ref.codes;
@@ -1876,6 +2016,13 @@ void sa_generate_seed_pos_table(const char* ref_str, size_t start_addr, uint32_t
         // the neighbourhood table belongs to the table build when the processor parameters are already known (the reference
         // calls InitializeProcessor first, src/main.cpp:298 before :621); otherwise the first table-direct call builds it
         if (g_proc_init && g_packed_filter) ensure_nbr(dc);
+    };
+    if (g_dev.size() <= 1) {
+        for (auto* dc : g_dev) build_on(dc);
+    } else {
+        std::vector<std::thread> builders;
+        for (auto* dc : g_dev) builders.emplace_back(build_on, dc);
+        for (auto& t : builders) t.join();
     }
 }
 
@@ -1934,6 +2081,13 @@ size_t sa_seed_and_filter(const uint64_t* seeds, size_t num_seeds, int rev, uint
     CoreArgs ca = {rev ? dc->query_rc[buffer].codes : dc->query[buffer].codes, g_query_len[buffer], 0, 0, 0, 0, 0, 0, nullptr, 0,
                    rev ? &dc->query4_rc[buffer] : &dc->query4[buffer]};  // :762-767
     set_query2(ca, dc, buffer, rev);
+    uint32_t lo = 0, hi = 0, words = 0;
+    if (dropin_td_front(dc, sl, ca.query, ca.query_len, seeds, num_seeds, ca.query4, 0, &lo, &hi, &words) != 0xFFFFFFFFu) {
+        ca.td = 1;
+        ca.td_words = words;
+        ca.q_lo = lo;
+        ca.q_hi = hi;
+    }
     size_t n = saf_core(dc, sl, (uint32_t)num_seeds, ca, out);
     release_slot(sl);
     return n;
@@ -2087,34 +2241,22 @@ size_t sa_seed_interval(uint32_t start, uint32_t end, uint32_t q_len, int strand
     sa_call_stats tot;
     memset(&tot, 0, sizeof(tot));
     std::mutex mu;
-    std::atomic<size_t> next(0);
-    auto worker = [&]() {
-        for (;;) {
-            const size_t j = next.fetch_add(1);
-            if (j >= jobs.size()) return;
-            Job& jb = jobs[j];
-            sa_seed_and_filter_chunks(jb.a, jb.b, jb.rev, buffer, jb.res, jb.n);
-            std::lock_guard<std::mutex> lk(mu);
-            tot.num_seeds += t_stats.num_seeds;
-            tot.num_hits += t_stats.num_hits;
-            tot.num_survivors += t_stats.num_survivors;
-            tot.num_anchors += t_stats.num_anchors;
-            tot.num_examined += t_stats.num_examined;
-            tot.num_examined_filter += t_stats.num_examined_filter;
-            tot.num_candidates += t_stats.num_candidates;
-            tot.num_entropy += t_stats.num_entropy;
-            tot.num_iter += t_stats.num_iter;
-            tot.device = t_stats.device;
-        }
-    };
-    const int nt = std::max(1, std::min<int>(threads, (int)jobs.size()));
-    if (nt == 1) {
-        worker();
-    } else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nt; t++) pool.emplace_back(worker);
-        for (auto& th : pool) th.join();
-    }
+    run_parallel(jobs.size(), threads, [&](size_t j) {  // (pool threads of the engine: nothing is created per interval)
+        Job& jb = jobs[j];
+        sa_seed_and_filter_chunks(jb.a, jb.b, jb.rev, buffer, jb.res, jb.n);
+        std::lock_guard<std::mutex> lk(mu);
+        tot.num_seeds += t_stats.num_seeds;
+        tot.num_hits += t_stats.num_hits;
+        tot.num_survivors += t_stats.num_survivors;
+        tot.num_anchors += t_stats.num_anchors;
+        tot.num_examined += t_stats.num_examined;
+        tot.num_examined_filter += t_stats.num_examined_filter;
+        tot.num_candidates += t_stats.num_candidates;
+        tot.num_entropy += t_stats.num_entropy;
+        tot.num_iter += t_stats.num_iter;
+        tot.device = t_stats.device;
+        tot.lookup_path = t_stats.lookup_path;
+    });
     size_t cnt[2] = {0, 0};
     for (const Job& jb : jobs)
         for (int c = 0; c < jb.k; c++) if (jb.n[c] > 1) cnt[jb.rev] += jb.n[c] - 1;
@@ -2133,6 +2275,55 @@ size_t sa_seed_interval(uint32_t start, uint32_t end, uint32_t q_len, int strand
     *out_rc = dst[1]; *n_rc = cnt[1];
     if (totals) *totals = tot;
     return cnt[0] + cnt[1];
+}
+
+// A list of independent calls -- each up to sa_max_chunks_per_call() consecutive chunks of one strand -- run with `threads` of
+// them in flight on the engine's worker pool.  This is the unit a multi-GPU host deals out: any subset of the calls of a pass
+// may run on any device.  results[i]: the HSPs of call i, its chunks concatenated in order, headers removed.
+size_t sa_seed_calls(const sa_call_desc* calls, size_t num_calls, uint32_t buffer, int threads, sa_call_result* results,
+                     sa_call_stats* totals) {
+    require_proc("SeedCalls", buffer);
+    sa_call_stats tot;
+    memset(&tot, 0, sizeof(tot));
+    std::mutex mu;
+    run_parallel(num_calls, threads, [&](size_t i) {
+        sa_segment_pair* res[SA_MAX_CHUNKS];
+        size_t cnt[SA_MAX_CHUNKS];
+        const sa_call_desc& c = calls[i];
+        const int K = c.end > c.start ? (int)(((uint64_t)c.end - c.start + g_wga_chunk - 1) / g_wga_chunk) : 0;
+        sa_seed_and_filter_chunks(c.start, c.end, c.rev, buffer, res, cnt);
+        size_t n = 0;
+        for (int k = 0; k < K; k++)
+            if (cnt[k] > 0) n += cnt[k] - 1;
+        sa_segment_pair* out = (sa_segment_pair*)malloc(std::max<size_t>(n, 1) * sizeof(sa_segment_pair));
+        size_t off = 0;
+        for (int k = 0; k < K; k++) {
+            if (cnt[k] > 1) {
+                memcpy(out + off, res[k] + 1, (cnt[k] - 1) * sizeof(sa_segment_pair));
+                off += cnt[k] - 1;
+            }
+            free(res[k]);
+        }
+        results[i].hsps = out;
+        results[i].num_hsps = n;
+        results[i].num_hits = t_stats.num_hits;
+        std::lock_guard<std::mutex> lk(mu);
+        tot.num_seeds += t_stats.num_seeds;
+        tot.num_hits += t_stats.num_hits;
+        tot.num_survivors += t_stats.num_survivors;
+        tot.num_anchors += t_stats.num_anchors;
+        tot.num_examined += t_stats.num_examined;
+        tot.num_examined_filter += t_stats.num_examined_filter;
+        tot.num_candidates += t_stats.num_candidates;
+        tot.num_entropy += t_stats.num_entropy;
+        tot.num_iter += t_stats.num_iter;
+        tot.device = t_stats.device;
+        tot.lookup_path = t_stats.lookup_path;
+    });
+    size_t total = 0;
+    for (size_t i = 0; i < num_calls; i++) total += results[i].num_hsps;
+    if (totals) *totals = tot;
+    return total;
 }
 
 size_t sa_device_make_seeds(uint32_t start, uint32_t end, int rev, uint32_t buffer, uint64_t* dst, size_t cap) {
@@ -2196,6 +2387,13 @@ size_t sa_rm_seed_and_filter(const uint64_t* seeds, size_t num_seeds, int rev, u
     CoreArgs ca = {rev ? dc->ref_rc.codes : dc->ref.codes, dc->ref.len, 1, rev ? 1 : 0, ref_start, ref_end, 0, 0, nullptr, 0,
                    rev ? &dc->ref4_rc : &dc->ref4};  // rm :805-810
     set_query2_rm(ca, dc, rev);
+    uint32_t lo = 0, hi = 0, words = 0;
+    if (dropin_td_front(dc, sl, ca.query, ca.query_len, seeds, num_seeds, ca.query4, 1, &lo, &hi, &words) != 0xFFFFFFFFu) {
+        ca.td = 1;
+        ca.td_words = words;
+        ca.q_lo = lo;
+        ca.q_hi = hi;
+    }
     size_t n = saf_core(dc, sl, (uint32_t)num_seeds, ca, out);
     release_slot(sl);
     return n;
@@ -2302,7 +2500,8 @@ size_t sa_rm_mask_interval(uint32_t start_pos, uint32_t end_pos, uint32_t ref_st
     // positions of the minus strand of a block's first interval: undefined there, no seed here)
     const uint32_t lim = block_len >= g_seed_size ? block_len - g_seed_size + 1 : 0;
     const uint32_t end_pos_rc = block_len - 1 - start_pos;  // seeder.cpp:46-47
-    uint64_t tot_seeds = 0, tot_hits = 0, tot_hsps = 0;
+    uint64_t tot_seeds = 0, tot_hits = 0, tot_hsps = 0, tot_ex = 0, tot_exf = 0, tot_cand = 0;
+    int path = 0;
     // The reference walks the plus-strand chunks and derives a minus-strand chunk from each (:73-150).  Coverage counting is
     // order independent and every chunk keeps its own iteration plan and dedup scope, so the chunks of a strand are grouped:
     // consecutive chunks that tile a range go through ONE table-direct pass (up to g_chunks_per_call of them), the rest --
@@ -2357,6 +2556,10 @@ size_t sa_rm_mask_interval(uint32_t start_pos, uint32_t end_pos, uint32_t ref_st
                 tot_seeds += ns;
                 tot_hits += t_stats.num_hits;
                 tot_hsps += t_stats.num_anchors;
+                tot_ex += t_stats.num_examined;
+                tot_exf += t_stats.num_examined_filter;
+                tot_cand += t_stats.num_candidates;
+                path = t_stats.lookup_path;
             }
             a = b;
         }
@@ -2365,6 +2568,14 @@ size_t sa_rm_mask_interval(uint32_t start_pos, uint32_t end_pos, uint32_t ref_st
     prof_flush(sl);
     release_slot(sl);
     if (totals) { totals[0] = tot_seeds; totals[1] = tot_hits; totals[2] = tot_hsps; }
+    // sa_get_last_call_stats after an interval call: the sums over its SeedAndFilter passes
+    t_stats.num_seeds = tot_seeds;
+    t_stats.num_hits = tot_hits;
+    t_stats.num_anchors = tot_hsps;
+    t_stats.num_examined = tot_ex;
+    t_stats.num_examined_filter = tot_exf;
+    t_stats.num_candidates = tot_cand;
+    t_stats.lookup_path = path;
     return n;
 }
 

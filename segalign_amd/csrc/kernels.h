@@ -223,6 +223,9 @@ void launch_table_sort_buckets(const uint32_t* bucket_start, uint32_t nkeys, uin
 void launch_seed_flags(const uint8_t* query, uint32_t start, uint32_t end, SeedShape sh, uint32_t* flags, hipStream_t s);
 void launch_seed_emit(const uint8_t* query, uint32_t start, uint32_t end, SeedShape sh, int transition,
                       const uint32_t* flag_prefix_excl, uint64_t* seeds, hipStream_t s);
+// *ok &= (the host seed vector of ngroups x per words equals what the device seeder emits for the same positions)
+void launch_seed_verify(const uint64_t* seeds, uint32_t ngroups, uint32_t per, const uint8_t* query, uint32_t query_len, SeedShape sh,
+                        uint32_t tmask, uint32_t* ok, hipStream_t s);
 // per seed: bucket start + bucket size  (find_num_hits, seed_filter.cu:157-182)
 void launch_seed_lookup(const uint64_t* seeds, uint32_t num_seeds, const uint32_t* bucket_start /*4^k+1*/, uint32_t nkeys,
                         uint32_t* start_out, uint32_t* count_out, hipStream_t s);

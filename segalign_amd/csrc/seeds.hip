@@ -7,6 +7,8 @@
 //   iteration plan: SeedAndFilter's lower_bound chain (src/seed_filter.cu:718-745) as one tiny kernel, so the
 //                   host needs a single D2H instead of ~6-10 implicit device_vector[] reads.
 //   seed_flags/emit: src/seeder.cpp:57-74 on the device (same word format, same order).
+#include <algorithm>
+
 #include "kernels.h"
 #include "kmer_dev.h"
 #include "plan.h"
@@ -40,6 +42,41 @@ __global__ __launch_bounds__(256) void seed_emit_kernel(const uint8_t* __restric
                 if ((tmask >> t) & 1u) *o++ = ((uint64_t)(key ^ (2u << (2 * t))) << 32) + j;  // seeder.cpp:64-69
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Is a HOST seed vector (src/seeder.cpp:57-74: per valid position the k-mer word, then one word per transition position) the
+// vector the device would emit for the same strand?  One lane per GROUP of `per` words: the group's words are
+// {key, key ^ (2 << 2t)...} of the k-mer that really stands at the group's query position, and the positions ascend strictly.
+// Together with "#groups == #valid positions in [first, last]" (counted by the position probe) this makes the vector EQUAL to the
+// device-emitted one, so the call may take the table-direct path; any deviation (hand-made words, the reference's shifted
+// minus-strand arena of hazard H14) clears *ok and the call keeps the reference-shaped path.
+__global__ __launch_bounds__(256) void seed_verify_kernel(const uint64_t* __restrict__ seeds, uint32_t ngroups, uint32_t per,
+                                                          const uint8_t* __restrict__ query, uint32_t query_len, SeedShape sh,
+                                                          uint32_t tmask, uint32_t* __restrict__ ok) {
+    bool good = true;
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += gridDim.x * blockDim.x) {
+        const uint64_t* w = seeds + (uint64_t)g * per;
+        const uint64_t w0 = w[0];
+        const uint32_t qpos = (uint32_t)w0;
+        uint32_t key = 0;
+        if ((uint64_t)qpos + (uint32_t)sh.span > query_len || !kmer_at(query, qpos, sh, key) || (uint32_t)(w0 >> 32) != key) good = false;
+        if (g > 0 && (uint32_t)w[-(int64_t)per] >= qpos) good = false;  // strictly ascending positions
+        uint32_t j = 1;
+        for (int t = 0; t < sh.weight; t++)
+            if ((tmask >> t) & 1u) {
+                if (w[j] != (((uint64_t)(key ^ (2u << (2 * t))) << 32) + qpos)) good = false;  // seeder.cpp:64-69
+                j++;
+            }
+    }
+    if (!good) atomicAnd(ok, 0u);
+}
+
+void launch_seed_verify(const uint64_t* seeds, uint32_t ngroups, uint32_t per, const uint8_t* query, uint32_t query_len, SeedShape sh,
+                        uint32_t tmask, uint32_t* ok, hipStream_t s) {
+    if (ngroups == 0) return;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)ngroups + 255) / 256, 4096);
+    hipLaunchKernelGGL(seed_verify_kernel, dim3(blocks), dim3(256), 0, s, seeds, ngroups, per, query, query_len, sh, tmask, ok);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

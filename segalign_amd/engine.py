@@ -37,7 +37,7 @@ C_ABI_SYMBOLS = [
     "sa_rm_mask_interval", "sa_rm_coverage_intervals", "sa_free_intervals", "sa_get_filter_mode",
     "sa_seed_interval", "sa_seed_and_filter_chunks", "sa_max_chunks_per_call", "sa_get_chunks_per_call", "sa_extend_hits",
     "sa_get_lookup_mode", "sa_get_neighbourhood_entries",
-    "sa_set_option", "sa_reset_option", "sa_get_option", "sa_option_count", "sa_option_name", "sa_get_audit",
+    "sa_seed_calls", "sa_set_option", "sa_reset_option", "sa_get_option", "sa_option_count", "sa_option_name", "sa_get_audit",
 ]
 IVL_DTYPE = np.dtype([("query_start", "<u4"), ("len", "<u4")])  # struct Segment, repeat_masker_src/graph.h:32-35
 STRAND_PLUS, STRAND_MINUS, STRAND_BOTH = 1, 2, 3
@@ -47,7 +47,7 @@ class CallStats(C.Structure):
     _fields_ = [("num_seeds", C.c_uint64), ("num_hits", C.c_uint64), ("num_survivors", C.c_uint64),
                 ("num_anchors", C.c_uint64), ("num_examined", C.c_uint64), ("num_examined_filter", C.c_uint64),
                 ("num_candidates", C.c_uint64), ("num_entropy", C.c_uint64), ("num_iter", C.c_uint32),
-                ("device", C.c_int)]
+                ("device", C.c_int), ("lookup_path", C.c_int), ("reserved", C.c_int)]
 
 
 _lib = None
@@ -115,6 +115,8 @@ def lib():
     L.sa_extend_hits.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]
     L.sa_get_neighbourhood_entries.restype = C.c_uint64
     L.sa_version.restype = C.c_char_p
+    L.sa_seed_calls.restype = C.c_size_t
+    L.sa_seed_calls.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_void_p, C.POINTER(CallStats)]
     L.sa_set_option.restype = C.c_int
     L.sa_set_option.argtypes = [C.c_char_p, C.c_int64]
     L.sa_reset_option.restype = C.c_int
@@ -223,6 +225,33 @@ def SeedAndFilterChunks(start, end, rev, buffer):
     for c in range(k):
         res.append(_take(counts[c], C.c_void_p(outs[c])) if outs[c] else np.zeros(0, dtype=SEG_DTYPE))
     return res
+
+
+class CallDesc(C.Structure):
+    _fields_ = [("start", C.c_uint32), ("end", C.c_uint32), ("rev", C.c_int)]
+
+
+class CallResult(C.Structure):
+    _fields_ = [("hsps", C.c_void_p), ("num_hsps", C.c_size_t), ("num_hits", C.c_uint64)]
+
+
+def SeedCalls(calls, buffer=0, threads=4):
+    """calls: [(start, end, rev), ...], each up to sa_max_chunks_per_call() chunks of one strand; `threads` of them in flight on
+    the engine's worker pool.  -> ([HSP array per call (chunks concatenated, headers removed)], summed stats dict)."""
+    n = len(calls)
+    descs = (CallDesc * max(n, 1))(*[CallDesc(int(a), int(b), int(bool(r))) for (a, b, r) in calls])
+    res = (CallResult * max(n, 1))()
+    st = CallStats()
+    lib().sa_seed_calls(descs, n, buffer, threads, res, C.byref(st))
+    outs = []
+    for i in range(n):
+        if res[i].num_hsps:
+            buf = (C.c_char * (res[i].num_hsps * SEG_DTYPE.itemsize)).from_address(res[i].hsps)
+            outs.append(np.frombuffer(buf, dtype=SEG_DTYPE).copy())
+        else:
+            outs.append(np.zeros(0, dtype=SEG_DTYPE))
+        lib().sa_free_segments(res[i].hsps)
+    return outs, {k: getattr(st, k) for k, _ in CallStats._fields_}
 
 
 def ExtendHits(hits, rev, buffer):

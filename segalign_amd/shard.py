@@ -24,6 +24,49 @@ def shard(items, rank, world):
     return list(items[rank::world])
 
 
+def call_jobs(intervals, q_block_len, chunk, chunks_per_call=16):
+    """The SeedAndFilter CALLS of one pass over a query block, as the engine's interval entry (sa_seed_interval) issues them:
+    per interval and strand the wga_chunk pieces (src/seeder.cpp:48-51, :89-91 in reverse-complement coordinates) are grouped
+    into equal calls of at most `chunks_per_call` chunks (40 chunks go as 14 + 14 + 12).  One dict per call: interval index,
+    strand, [a, b) in that strand's coordinates, chunks.  Every call is independent (own iteration plans, own dedup scopes, its
+    output position is fixed by the host loop), so ANY assignment of calls to GPUs gives identical bytes."""
+    jobs = []
+    for idx, (s, e) in enumerate(intervals):
+        for rev in (False, True):
+            a, b = (q_block_len - e, q_block_len - s) if rev else (s, e)
+            nchunks = (b - a + chunk - 1) // chunk if b > a else 0
+            ncalls = (nchunks + chunks_per_call - 1) // chunks_per_call
+            group = (nchunks + ncalls - 1) // ncalls if ncalls else 1
+            i = a
+            while i < b:
+                j = min(i + chunk * group, b)
+                jobs.append(dict(interval=idx, rev=rev, a=i, b=j, chunks=(j - i + chunk - 1) // chunk))
+                i = j
+    return jobs
+
+
+def partition(jobs, rank, world):
+    """Strong scaling: the calls of ONE problem dealt round-robin to the ranks -- every call exactly once.  Consecutive calls
+    (neighbouring query regions, similar hit density) land on different ranks, which balances dense and sparse regions."""
+    return [j for k, j in enumerate(jobs) if k % world == rank]
+
+
+def hsp_checksum(segs, rev):
+    """Order-independent checksum of a list of HSP records (numpy structured array ref_start, query_start, len, score): the sum
+    over records of a 61-bit mix of the fields and the strand.  Equal HSP multisets <=> equal sums (up to hash collisions), so
+    the N-GPU run of a problem must reproduce the 1-GPU checksum whatever the partition."""
+    import numpy as np
+    if segs is None or len(segs) == 0:
+        return 0
+    x = (segs["ref_start"].astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) ^ (segs["query_start"].astype(np.uint64) * np.uint64(0xC2B2AE3D27D4EB4F))
+    x ^= (segs["len"].astype(np.uint64) << np.uint64(17)) ^ (segs["score"].astype(np.int64).astype(np.uint64) * np.uint64(0x165667B19E3779F9))
+    x ^= np.uint64(0xD6E8FEB86659FD93) if rev else np.uint64(0)
+    x ^= x >> np.uint64(29)
+    x *= np.uint64(0xBF58476D1CE4E5B9)
+    x ^= x >> np.uint64(32)
+    return int(np.sum(x & np.uint64((1 << 61) - 1), dtype=np.uint64) & np.uint64((1 << 63) - 1))
+
+
 def rm_plan(seq_len, seq_block_size=1000000000, lastz_interval_size=10000000, prop_neigh_interval=0.2, seed_size=19):
     """repeat_masker_src/main.cpp:316-436 (float/ceil arithmetic included): one dict per (block, interval) task with the
     seed range [start, end) and the target window [ref_start, ref_end] inside the block."""

@@ -116,7 +116,7 @@ int main(int argc, char** argv) {
     g_InitializeProcessor(transition, chunk, span, sub_mat, xdrop, hspthresh, false);                 // main.cpp:298
     g_SendRefWriteRequest(&target[0], 0, (uint32_t)target.size());                                    // main.cpp:615
     GenerateSeedPosTable(&target[0], 0, (uint32_t)target.size(), 1, (int)span, kmer_size);           // main.cpp:621
-    struct Job { bool rev; uint32_t s, e; std::vector<segmentPair> out; };
+    struct Job { bool rev; uint32_t s, e; std::vector<segmentPair> out; int path; };
     std::vector<Job> jobs;
 #ifdef COMPAT_DRIVER_RM
     if (argc < 9) {
@@ -132,9 +132,9 @@ int main(int argc, char** argv) {
         const uint32_t end_pos_rc = L - 1 - start_pos;                                                // rm seeder.cpp:46-47
         for (uint32_t i = start_pos; i < end_pos; i += chunk) {                                       // rm seeder.cpp:73-77
             const uint32_t e = std::min(i + chunk, end_pos);
-            jobs.push_back({false, i, e, {}});
+            jobs.push_back({false, i, e, {}, -1});
             const uint32_t s_rc = L - 1 - e;                                                          // rm seeder.cpp:118-119
-            jobs.push_back({true, s_rc, std::min(std::min(s_rc + chunk, end_pos_rc), L - span + 1), {}});
+            jobs.push_back({true, s_rc, std::min(std::min(s_rc + chunk, end_pos_rc), L - span + 1), {}, -1});
         }
     }
 #else
@@ -143,7 +143,7 @@ int main(int argc, char** argv) {
     std::string query_rc = HostRevComp(query);                                                        // main.cpp:372
     const uint32_t end_pos = (uint32_t)query.size() - span;                                           // main.cpp:383
     for (int rev = 0; rev < 2; rev++)
-        for (uint32_t i = 0; i < end_pos; i += chunk) jobs.push_back({rev != 0, i, std::min(i + chunk, end_pos), {}});
+        for (uint32_t i = 0; i < end_pos; i += chunk) jobs.push_back({rev != 0, i, std::min(i + chunk, end_pos), {}, -1});
 #endif
 
     std::atomic<size_t> next(0);
@@ -168,6 +168,11 @@ int main(int argc, char** argv) {
 #else
             if (!seeds.empty()) job.out = g_SeedAndFilter(seeds, job.rev, 0);                         // seeder.cpp:76-78
 #endif
+            if (!seeds.empty()) {  // (test introspection, not a reference symbol: which lookup path did the engine give this call?)
+                sa_call_stats st;
+                sa_get_last_call_stats(&st);
+                job.path = st.lookup_path;
+            }
         }
     };
     std::vector<std::thread> pool;
@@ -181,7 +186,7 @@ int main(int argc, char** argv) {
 #else
         long hits = job.out.empty() ? 0 : job.out[0].score;
 #endif
-        printf("C %d %u %u %zu %ld\n", job.rev ? 1 : 0, job.s, job.e, n, hits);
+        printf("C %d %u %u %zu %ld %d\n", job.rev ? 1 : 0, job.s, job.e, n, hits, job.path);
         for (size_t i = 1; i < job.out.size(); i++)
             printf("%u %u %u %d\n", job.out[i].ref_start, job.out[i].query_start, job.out[i].len, job.out[i].score);
     }

@@ -28,7 +28,7 @@ def test_reference_symbols_end_to_end(oracle, tmp_path, threads):
     i = 0
     total = 0
     while i < len(out) and out[i]:
-        tag, rev, s, e, n, hits = out[i].split()
+        tag, rev, s, e, n, hits, path = out[i].split()
         assert tag == "C"
         rev, s, e, n, hits = int(rev), int(s), int(e), int(n), int(hits)
         got = np.array([tuple(int(x) for x in out[i + 1 + j].split()) for j in range(n)],
@@ -36,6 +36,9 @@ def test_reference_symbols_end_to_end(oracle, tmp_path, threads):
         seeds = c.host_seeds(s, e, bool(rev))
         want, st = c.oracle_saf(seeds, bool(rev))
         assert hits == st["num_hits"]
+        # the reference's own hot symbol gets the fast path: a host seed vector that is what seeder.cpp emits is looked up
+        # table-direct with target context (sa_call_stats.lookup_path), not through the seed-word path
+        assert seeds.size == 0 or int(path) == 2, (rev, s, e, path)
         assert got.size == want.size - 1 and np.all(got == want[1:]), (rev, s, e)
         total += n
         i += 1 + n
@@ -67,9 +70,10 @@ def test_repeat_masker_reference_symbols_end_to_end(oracle, tmp_path, threads):
                                   stderr=subprocess.DEVNULL).decode().split("\n")
     i = total = ncalls = 0
     while i < len(out) and out[i]:
-        tag, rev, s, e, n, hits = out[i].split()
+        tag, rev, s, e, n, hits, path = out[i].split()
         assert tag == "C"
         rev, s, e, n, hits = int(rev), int(s), int(e), int(n), int(hits)
+        assert int(path) == 2, (rev, s, e, path)  # (table-direct with target context for the repeat masker's g_SeedAndFilter too)
         got = np.array([tuple(int(x) for x in out[i + 1 + j].split()) for j in range(n)], dtype=O.SEG_DTYPE)
         buf = rc_ascii if rev else t
         seeds = O.make_seeds(buf.tobytes(), 0, s, e, 19, c.kmer_size, True)

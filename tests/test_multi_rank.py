@@ -24,42 +24,85 @@ def test_interval_and_chunk_plan_matches_reference_rules():
     assert sorted(parts[0] + parts[1]) == ivs and not set(parts[0]) & set(parts[1])
 
 
-def _run(nproc, steps):
+def _run(nproc, steps, scaling="strong", port=29541):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", str(steps), "--warmup", "0",
-            "--dry-run", "--target-mbp", "60"]
+            "--dry-run", "--target-mbp", "60", "--scaling", scaling]
     if nproc == 1:
         cmd = base
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
-               "--master-addr", "127.0.0.1", "--master-port", "29541"] + base[1:]
+               "--master-addr", "127.0.0.1", "--master-port", str(port)] + base[1:]
     out = subprocess.check_output(cmd, env=env, stderr=subprocess.DEVNULL, timeout=300).decode().strip().split("\n")
     return json.loads(out[-1])
 
 
-def _model(world, steps, qlen=60_000_000, interval=10_000_000, chunk=250_000):
-    """Independent statement of the bench's work map: in step k rank r walks the interval list from interval r + k on,
-    wrapping (weak scaling: every rank covers every interval once per step); chunks per src/seeder.cpp:48-51,:33-34."""
+def _stub(j, chunk, w=1):
+    return sum(w * ((a * 31 + min(a + chunk, j["b"]) * 17 + int(j["rev"])) % 1000003) for a in range(j["a"], j["b"], chunk))
+
+
+def _model(world, steps, scaling, qlen=60_000_000, interval=10_000_000, chunk=250_000):
+    """Independent statement of the bench's work map.  strong: the calls of a pass (per interval and strand the 250 kbp chunks
+    of src/seeder.cpp:48-51 / :33-34 in groups of <= 16) are dealt round-robin, each exactly once per step; weak: in step k rank r
+    walks the whole call list from call r + k on, wrapping."""
     ivs = shard.plan_intervals(qlen, 19, interval)
+    jobs = []
+    for idx, (s, e) in enumerate(ivs):
+        for rev in (False, True):
+            a, b = (qlen - 19 - e, qlen - 19 - s) if rev else (s, e)
+            n = -(-(b - a) // chunk)
+            calls = -(-n // 16)
+            group = -(-n // calls)
+            for c in range(calls):
+                jobs.append(dict(rev=rev, a=a + c * group * chunk, b=min(a + (c + 1) * group * chunk, b)))
     bases = check = 0
     for r in range(world):
         for k in range(steps):
-            for i in range(len(ivs)):
-                iv = ivs[(r + k + i) % len(ivs)]
-                bases += iv[1] - iv[0]
-                for rev in (False, True):
-                    s, e = (qlen - 19 - iv[1], qlen - 19 - iv[0]) if rev else iv
-                    for a in range(s, e, chunk):
-                        check += (i + 1) * ((a * 31 + min(a + chunk, e) * 17 + int(rev)) % 1000003)
+            if scaling == "strong":
+                todo = [(1, j) for i, j in enumerate(jobs) if i % world == r]
+            else:
+                todo = [(i + 1, jobs[(r + k + i) % len(jobs)]) for i in range(len(jobs))]
+            for w, j in todo:
+                bases += 0 if j["rev"] else j["b"] - j["a"]
+                check += _stub(j, chunk, w)
     return bases, check
 
 
-def test_rank_walks_and_reduction_match_the_model():
-    # 60 Mbp -> 6 intervals; the stub engine's checksum depends on WHICH interval a rank visits WHEN, so a wrong
-    # interval-to-rank map, a wrong chunk bound or a wrong sum/max reduction changes the line
+def test_call_list_partition_covers_every_call_exactly_once():
+    ivs = shard.plan_intervals(60_000_000, 19, 10_000_000)
+    jobs = shard.call_jobs(ivs, 60_000_000 - 19, 250_000, 16)
+    assert len(jobs) == 6 * 2 * 3 and sum(j["chunks"] for j in jobs) == 2 * 240
+    # every strand of every interval is tiled by its calls without gap or overlap
+    for idx, (s, e) in enumerate(ivs):
+        for rev in (False, True):
+            mine = sorted((j["a"], j["b"]) for j in jobs if j["interval"] == idx and j["rev"] == rev)
+            lo, hi = (60_000_000 - 19 - e, 60_000_000 - 19 - s) if rev else (s, e)
+            assert mine[0][0] == lo and mine[-1][1] == hi and all(mine[i][1] == mine[i + 1][0] for i in range(len(mine) - 1))
+    for world in (1, 2, 3, 8):
+        parts = [shard.partition(jobs, r, world) for r in range(world)]
+        flat = [id(j) for p in parts for j in p]
+        assert sorted(flat) == sorted(id(j) for j in jobs)  # exactly once
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_strong_scaling_partition_keeps_the_checksum_for_world_1_2_3():
+    """The strong-scaling map: total work fixed, every call on exactly one rank, so bases and the stub checksum of a pass do not
+    depend on the number of ranks -- and equal the independent model."""
     one = _run(1, 2)
-    two = _run(2, 2)
+    two = _run(2, 2, port=29541)
+    three = _run(3, 2, port=29543)
+    assert one["scaling"] == two["scaling"] == three["scaling"] == "strong"
+    assert (one["bases"], one["checksum"]) == _model(1, 2, "strong")
+    assert (two["bases"], two["checksum"]) == (one["bases"], one["checksum"])
+    assert (three["bases"], three["checksum"]) == (one["bases"], one["checksum"])
+    assert two["n_gpus"] == 2 and three["n_gpus"] == 3
+
+
+def test_weak_scaling_rank_walks_and_reduction_match_the_model():
+    # the stub checksum is weighted by the walk position, so a wrong rank walk, chunk bound or sum / max reduction changes the line
+    one = _run(1, 2, "weak")
+    two = _run(2, 2, "weak", port=29545)
     assert two["n_gpus"] == 2 and two["scaling"] == "weak"
-    assert (one["bases"], one["checksum"]) == _model(1, 2)
-    assert (two["bases"], two["checksum"]) == _model(2, 2)
+    assert (one["bases"], one["checksum"]) == _model(1, 2, "weak")
+    assert (two["bases"], two["checksum"]) == _model(2, 2, "weak")
     assert two["bases"] == 2 * one["bases"]  # weak scaling: per-GPU work is fixed

@@ -186,6 +186,7 @@ struct ProfEntry {
 static std::mutex g_prof_mu;
 static std::vector<ProfEntry> g_prof;
 static bool g_prof_on = false;
+static int g_trace_scopes = 0;  // option debug >= 2: synchronise after every kernel scope and name it on stderr (fault localisation)
 
 struct Slot;
 struct ProfRec {
@@ -557,8 +558,10 @@ static int max_hits_for_mem(uint64_t total_global_mem) {  // src/seed_filter.cu:
 struct ProfScope {
     Slot* sl;
     bool on;
+    const char* nm;
     ProfRec r;
-    ProfScope(Slot* s, const char* name) : sl(s), on(g_prof_on) {
+    ProfScope(Slot* s, const char* name) : sl(s), on(g_prof_on), nm(name) {
+        if (g_trace_scopes) fprintf(stderr, "[scope] %s ...\n", name);
         if (!on) return;
         if (sl->events_used == sl->event_pool.size()) {
             hipEvent_t a, b;
@@ -573,6 +576,10 @@ struct ProfScope {
         hipEventRecord(r.e0, sl->stream);
     }
     ~ProfScope() {
+        if (g_trace_scopes) {
+            hipError_t e = hipStreamSynchronize(sl->stream);
+            fprintf(stderr, "[scope] %s done (%s)\n", nm, hipGetErrorString(e));
+        }
         if (!on) return;
         hipEventRecord(r.e1, sl->stream);
         sl->prof_pending.push_back(r);
@@ -1376,8 +1383,11 @@ static bool ensure_nbr(DevCtx* dc) {
     } else if ([&] {  // positions only: an arena kept from an earlier (smaller) block gives its memory back first
                    if (arena_mapped(dc->arena)) {
                        arena_trim(dc->arena, 0);
+                       hipDeviceSynchronize();
                        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
                    }
+                   if (dbg) fprintf(stderr, "neighbourhood table: no room for the context table (%.1f GB + %.1f GB reserve), positions only need %.1f GB, free %.1f GB\n",
+                                    (rec28 + pos28) / 1e9, reserve / 1e9, need_pos / 1e9, free_b / 1e9);
                    return need_pos + reserve <= free_b;
                }()) {
         dc->nbr_pos = (uint32_t*)dev_malloc(need_pos, "nbr_pos");
@@ -1425,14 +1435,14 @@ static uint32_t td_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, int K, con
         ProfScope p(sl, "seed_probe");
         launch_probe_lookup(qcodes, start, n, sh, dc->nbr_start, dc->nkeys, sl->td_toff.p, sl->td_tcnt.p, sl->td_partial.p, st);
     }
-    // head-bit map for the class filter: sized for 64 hits per position; a denser call regrows it and repeats the compaction
+    // head-bit map for the class filter: sized for 128 hits per position; a denser call regrows it (it stays) and repeats the compaction
     const bool want_bits = dc->nbr_ctx28 != nullptr;
-    if (want_bits) sl->td_bits.ensure(std::max<size_t>((size_t)n * 2 + 64, 1u << 16), "probe head bits");
-    for (;;) {
+    if (want_bits) sl->td_bits.ensure(std::max<size_t>((size_t)n * 4 + 64, 1u << 16), "probe head bits");
+    for (bool first_pass = true;; first_pass = false) {
         {
             ProfScope p(sl, "probe_compact");
             launch_probe_compact(start, n, sl->td_toff.p, sl->td_tcnt.p, sl->td_partial.p, sl->d_td_bounds, sl->td_rec.p, sl->td_chunk.p, TD_CHUNK_CAP,
-                                 want_bits ? sl->td_bits.p : nullptr, (uint32_t)std::min<size_t>(sl->td_bits.cap, 0xFFFFFFFFu), tb, st);
+                                 want_bits ? sl->td_bits.p : nullptr, (uint32_t)std::min<size_t>(sl->td_bits.cap, 0xFFFFFFFFu), tb, first_pass, st);
         }
         {
             ProfScope p(sl, "iteration_plan");
@@ -1555,7 +1565,7 @@ static Option g_opts[] = {
     {"no_packed_filter", 0, 0, 1, 0},                  // 1: byte-coded filter kernels only (also disables table-direct lookup)
     {"no_fast_filter", 0, 0, 1, 0},                    // 1: exact per-base filter only
     {"arena_gb", 40, 0, 1024, 0},                      // GiB of table arena mapped in the background from InitializeProcessor on
-    {"debug", 0, 0, 1, 0},                             // 1: table-build timings on stderr
+    {"debug", 0, 0, 2, 0},                             // 1: table-build timings on stderr; 2: + sync and name every kernel scope
     // launch geometry (swept by tools/sweep_*.sh; the defaults are the measured optima)
     {"fin_batch", 48, 1, 64, 0}, {"bufs_per_wave", 8, 1, 1 << 20, 0}, {"long_cap", 128, 0, 2 * PACK_PAD, 0},
     {"long_blocks", 1792, 1, 1 << 20, 0}, {"max_waves", 4096, 4, 1 << 20, 0}, {"packed_waves", 4096, 8, 1 << 20, 0},
@@ -1596,6 +1606,7 @@ static void resolve_options() {
     g_td = opt_value("no_td") ? 0 : 1;
     g_chain = opt_value("no_chain") ? 0 : 1;
     g_arena_gb = opt_value("arena_gb");
+    g_trace_scopes = opt_value("debug") >= 2 ? 1 : 0;
     g_fin_batch = (int)opt_value("fin_batch");
     g_bufs_per_wave = (int)opt_value("bufs_per_wave");
     g_long_cap = (int)opt_value("long_cap") & ~7;

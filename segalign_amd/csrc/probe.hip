@@ -411,11 +411,13 @@ void launch_probe_lookup(const uint8_t* query, uint32_t start, uint32_t n, SeedS
 }
 void launch_probe_compact(uint32_t start, uint32_t n, const uint64_t* t_off, const uint32_t* t_cnt, void* partial_buf, void* bounds_buf,
                           TdRec* c_rec, uint32_t* chunk_rec, uint32_t chunk_cap, uint32_t* head_bits, uint32_t head_words,
-                          const TdBounds& bpos, hipStream_t s) {
+                          const TdBounds& bpos, bool first_pass, hipStream_t s) {
     Tri* partial = reinterpret_cast<Tri*>(partial_buf);
     const uint32_t nblocks = probe_blocks(start, n);
     Tri* total = partial + nblocks;
-    hipLaunchKernelGGL(probe_partials_kernel, dim3(1), dim3(PR_THREADS), 0, s, partial, nblocks, total);
+    // (the block sums are turned into prefixes IN PLACE: only once per probe -- a repeated compaction, after the head-bit map
+    //  was regrown, starts from the prefixes)
+    if (first_pass) hipLaunchKernelGGL(probe_partials_kernel, dim3(1), dim3(PR_THREADS), 0, s, partial, nblocks, total);
     if (head_bits) hipLaunchKernelGGL(head_bits_clear_kernel, dim3(1024), dim3(256), 0, s, total, head_bits, head_words);
     hipLaunchKernelGGL(probe_compact_kernel, dim3(nblocks), dim3(PR_THREADS), 0, s, start, n, t_off, t_cnt, partial, total, c_rec, chunk_rec,
                        chunk_cap, head_bits, head_words, bpos, reinterpret_cast<Tri*>(bounds_buf));

@@ -1,0 +1,116 @@
+"""GPU: the reference's block loop at size -- g_ClearRef -> next target block -> BUFFER_DEPTH query blocks swapping
+(src/main.cpp:601-685) -- with target blocks large -> small -> large, so the engine's table arena is filled, partly reused and
+grown again, and a block whose context table does not fit next to the work buffers falls back to the position-only table
+(lookup mode 1) and comes back to mode 2 on the next block.  Per block: lookup mode, table footprint, and two chunks per query
+buffer and strand bit-exact against the oracle (the oracle runs on the table copied from the device: building a 200 Mbp table
+on the CPU takes longer than the whole GPU suite)."""
+import numpy as np
+import pytest
+
+from segalign_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+SHAPE = "TTT0T00TT00T0T0TTTT"
+CHUNK = 250000
+
+
+def make_block(n, seed):
+    t = synth.soft_mask(synth.random_dna(n, seed), seed + 1, 0.25, 200, 2000)
+    per = n // 3
+    return synth.join_records([t[i * per:(i + 1) * per] for i in range(3)])
+
+
+def make_query(target, seed, pieces=4, piece=260000):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(pieces):
+        p = int(rng.integers(0, target.size - piece - 1))
+        seg = synth.mutate(target[p:p + piece].copy(), seed + 10 + i, 0.03, indel_every=700)
+        out.append(synth.reverse_complement(seg) if i % 2 else seg)
+    return np.concatenate(out)
+
+
+def check_block(E, O, sub_mat, k, target, queries, expect_mode):
+    """one pass of the reader lambda for a target block (main.cpp:613-621,649-664) + chunk calls on both buffers"""
+    keep = E.SendRefWriteRequest(target, 0, target.size)
+    E.GenerateSeedPosTable(keep, 0, target.size, 1, 19, k)
+    for b, q in enumerate(queries):
+        E.SendQueryWriteRequest(q, 0, q.size, b)
+    assert E.lookup_mode() == expect_mode
+    index, pos, rcodes = E.copy_index_table(), E.copy_pos_table(), E.copy_ref_codes()
+    if expect_mode:
+        assert E.neighbourhood_entries() == 13 * pos.size
+    hsps = 0
+    for b, q in enumerate(queries):
+        for rev in (False, True):
+            qcodes = E.copy_query_codes(b, rev)
+            buf = q if not rev else np.frombuffer(O.rev_comp_ascii(q.tobytes(), 0, q.size), dtype=np.uint8)
+            for a in (0, CHUNK):
+                e = min(a + CHUNK, q.size - 19)
+                seeds = O.make_seeds(buf.tobytes(), 0, a, e, 19, k, True)
+                want, st = O.seed_and_filter(rcodes, qcodes, index, pos, seeds, sub_mat)
+                got = E.SeedAndFilterRange(a, e, rev, b)
+                assert got.shape == want.shape and np.all(got == want), (target.size, b, rev, a)
+                assert E.last_call_stats()["lookup_path"] == expect_mode
+                got2 = E.SeedAndFilter(seeds, rev, b)  # the drop-in entry on the same chunk
+                assert got2.shape == want.shape and np.all(got2 == want), (target.size, b, rev, a, "drop-in")
+                hsps += want.size - 1
+    for b in range(len(queries)):
+        E.ClearQuery(b)  # main.cpp:659,680
+    return hsps
+
+
+def test_large_small_large_blocks_through_clear_ref(oracle, engine):
+    E, O = engine, oracle
+    sub_mat = O.build_sub_mat(910)
+    E.InitializeInterface(1)
+    k = E.GenerateShapePos(SHAPE)
+    O.generate_shape_pos(SHAPE)
+    E.InitializeProcessor(True, CHUNK, 19, sub_mat, 910, 3000, False)
+    try:
+        big = make_block(200_000_000, 11)
+        small = make_block(50_000_000, 21)
+        total = 0
+        for i, t in enumerate((big, small, big)):
+            if i:
+                E.ClearRef()  # main.cpp:613
+            total += check_block(E, O, sub_mat, k, t, [make_query(t, 100 + 7 * i), make_query(t, 200 + 7 * i)], 2)
+        assert total > 100
+    finally:
+        E.ShutdownProcessor()
+
+
+def test_block_that_does_not_fit_falls_back_to_positions_and_recovers(oracle, engine):
+    """Free HBM is taken away (a foreign allocation) between two blocks, so the context table of the second, larger block does not
+    fit next to the engine's reserve: that block runs with the position-only table (mode 1) and gives the arena back; once the
+    memory is free again the next block is back in mode 2.  Results equal the oracle in every mode."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")  # the HIP runtime the engine itself is linked against (same process-wide instance)
+    E, O = engine, oracle
+    sub_mat = O.build_sub_mat(910)
+    E.InitializeInterface(1)
+    k = E.GenerateShapePos(SHAPE)
+    O.generate_shape_pos(SHAPE)
+    E.set_option("arena_gb", 8)  # (a small arena, so that what is mapped when the memory is taken away does not depend on timing)
+    E.InitializeProcessor(True, CHUNK, 19, sub_mat, 910, 3000, False)
+    hog = None
+    try:
+        small = make_block(20_000_000, 31)
+        big = make_block(160_000_000, 41)
+        check_block(E, O, sub_mat, k, small, [make_query(small, 300)], 2)
+        free_b, total_b = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipMemGetInfo(ctypes.byref(free_b), ctypes.byref(total_b)) == 0
+        hog = ctypes.c_void_p()  # leave ~30 GB: the table (~52 GB) + the engine's reserve (16 GiB) exceed that + the arena (8 GiB),
+        assert hip.hipMalloc(ctypes.byref(hog), ctypes.c_size_t(max(free_b.value - (30 << 30), 1 << 20))) == 0  # positions + reserve fit
+        E.ClearRef()
+        check_block(E, O, sub_mat, k, big, [make_query(big, 400)], 1)
+        assert hip.hipFree(hog) == 0
+        hog = None
+        E.ClearRef()
+        check_block(E, O, sub_mat, k, big, [make_query(big, 500)], 2)
+    finally:
+        if hog is not None:
+            hip.hipFree(hog)
+        E.ShutdownProcessor()
+        E.reset_option("arena_gb")

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void strip_kernel(const HspRec* __restrict__ i
     }
 }
 
-constexpr int DEDUP_SMALL_SEGS = 32;  // distinct segment ids (reference iterations x chunks of a call) the LDS path handles
+constexpr int DEDUP_SMALL_SEGS = 64;  // distinct segment ids (reference iterations x chunks of a call) the LDS path handles
 
 // ---- the whole chain in LDS, ONE WORKGROUP PER SEGMENT -----------------------------------------------------------------
 // After the chain shortcut a call leaves a few hundred to a few thousand survivors; three library sorts + unique + strip then

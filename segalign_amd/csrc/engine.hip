@@ -210,7 +210,8 @@ static int prof_id(const char* name) {
 constexpr int MAX_SLOTS_PER_DEVICE = 4;
 static uint32_t SPEC_RECS = 16384;    // records of the speculative output copy (256 KB); SEGALIGN_AMD_SPEC_RECS (tests)
 static uint32_t g_dedup_seg_max = 0;   // SEGALIGN_AMD_DEDUP_SEG_MAX: records per segment the LDS chain accepts (0 = its LDS capacity; tests)
-constexpr int SA_MAX_CHUNKS = 16;  // chunks one multi-chunk call may carry: 2 reference iterations each = MAX_SEGS segments
+constexpr int SA_MAX_CHUNKS = 32;  // chunks one multi-chunk call may carry: 2 reference iterations each = MAX_SEGS segments
+constexpr int SA_DEFAULT_CHUNKS = 20;  // ... and what the interval entries hand to one call: the 40 chunks of a 10 Mbp strand go as 20 + 20
 static int SLOTS_PER_DEVICE = 2;  // calls in flight per device (the reference allows one: token == device); SEGALIGN_AMD_SLOTS
 
 struct Counters {  // device-side scalars of one slot
@@ -241,7 +242,7 @@ struct Slot {
     DevBuf<CandRec> cand_list;
     DevBuf<L2Rec> l2_list;
     DevBuf<uint2> audit;                    // (tests) rejected hits of the filter levels
-    DevBuf<uint32_t> l2_counts, l2_prefix;  // sub-list counters (one 128-byte line each) and their prefix
+    DevBuf<uint32_t> l2_counts;             // sub-list counters (one 128-byte line each)
     DevBuf<CandRec> chain_tmp, chain_sorted;  // chain shortcut of the exact stage
     DevBuf<uint32_t> chain_is_head, chain_heads, chain_bucket_cnt, chain_bucket_start;
     DevBuf<EntRec> ent_list;
@@ -512,7 +513,7 @@ static int g_max_waves = 4096;    // SEGALIGN_AMD_MAX_WAVES: waves of the filter
 static int g_fast_filter = 0;     // derived in InitializeProcessor: xdrop >= 0 && 7*max(M) <= xdrop
 static int g_packed_filter = 0;   // derived in InitializeProcessor: the packed upper-bound filter may be used
 static int g_chain_sort_threads = 256;  // SEGALIGN_AMD_CHAIN_SORT_THREADS
-static int g_chunks_per_call = SA_MAX_CHUNKS;  // SEGALIGN_AMD_CHUNKS_PER_CALL: chunks sa_seed_interval hands to one multi-chunk call
+static int g_chunks_per_call = SA_DEFAULT_CHUNKS;  // SEGALIGN_AMD_CHUNKS_PER_CALL: chunks sa_seed_interval hands to one multi-chunk call
 static int g_no_small_dedup = 0;  // SEGALIGN_AMD_NO_SMALL_DEDUP=1: always use the library sorts
 static int g_ctx = 1;             // neighbourhood table with target context when it fits (SEGALIGN_AMD_NO_CTX=1: positions only)
 static uint32_t g_audit_cap = 0;  // SEGALIGN_AMD_AUDIT_CAP (tests): record up to this many hits the filter levels reject per call
@@ -651,7 +652,6 @@ static void slot_destroy(Slot& s) {
     s.l2_list.release("second-level list");
     s.audit.release("audit list");
     s.l2_counts.release("second-level counters");
-    s.l2_prefix.release("second-level prefix");
     s.chain_tmp.release("chain"); s.chain_sorted.release("chain"); s.chain_is_head.release("chain");
     s.chain_heads.release("chain"); s.chain_bucket_cnt.release("chain"); s.chain_bucket_start.release("chain"); s.ent_list.release("entropy list");
     s.cov_diff.release("coverage"); s.cov_pre.release("coverage"); s.cov_is_start.release("coverage");
@@ -877,10 +877,8 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                         sl->l2_list.ensure(g_l2_cap_test ? (size_t)g_l2_cap_test
                                                          : (size_t)std::max<uint64_t>((uint64_t)L2_NSUB * TD_CHUNK_HITS, bh / 8), "second-level list");
                         sl->l2_counts.ensure((size_t)L2_NSUB * L2_CNT_STRIDE, "second-level counters");
-                        sl->l2_prefix.ensure((size_t)L2_NSUB + 1, "second-level prefix");
                     }
                     ea.l2_count = sl->l2_counts.p;
-                    ea.l2_prefix = sl->l2_prefix.p;
                     ea.l2_total = &sl->d_cnt->n_l2;
                     ea.l2_max = &sl->d_cnt->n_l2_max;
                     ea.l2_blocks = (uint32_t)g_l2_blocks;
@@ -932,9 +930,9 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                 // sort key, and is off while E is being counted.  The repeat masker takes it too: its window only decides WHICH
                 // hits are extended (all candidates lie inside it), and its chain starts with an exact-duplicate unique
                 // (rm :819-823), so the duplicates the shortcut never produces would be removed there anyway
-                const bool chain_rel = ca.td && ca.q_hi > ca.q_lo && ca.q_hi - ca.q_lo < (1u << 27);  // positions relative to the call's first
+                const bool chain_rel = ca.td && ca.q_hi > ca.q_lo && (uint64_t)ca.q_hi - ca.q_lo + g_seed_size < (1u << 26);  // anchors relative to the call's first position fit the key
                 const bool chain = g_chain && g_xdrop >= 0 && (chain_rel || (nseg <= MAX_SEGS_ABS && ca.query_len < (1u << 29))) && !g_count_examined;
-                ea.chain_q_bits = chain_rel ? 27u : 29u;
+                ea.chain_q_bits = chain_rel ? 26u : 29u;
                 ea.chain_q_base = chain_rel ? ca.q_lo : 0u;
                 ea.chain_cap = chain ? CHAIN_CAP : 0u;
                 ea.chain_sort_threads = (uint32_t)g_chain_sort_threads;
@@ -960,7 +958,10 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                 before.n_heads = 0;
                 before.n_l2 = 0;
                 before.n_l2_max = 0;
-                check_memcpy(hipMemsetAsync(&sl->d_cnt->n_long, 0, 6 * sizeof(uint32_t), st), "counters");
+                // (a table-direct call is ONE batch, and td_front's clearing kernel has just zeroed the counters, the sub-list counters,
+                //  the chain buckets and the segment info: the memsets below only run for later batches and for reruns)
+                bool cleared = ca.td && it0 == 0;
+                if (!cleared) check_memcpy(hipMemsetAsync(&sl->d_cnt->n_long, 0, 6 * sizeof(uint32_t), st), "counters");
                 if (g_audit_cap && ca.td) {
                     sl->audit.ensure(g_audit_cap, "audit list");
                     ea.audit_list = sl->audit.p;
@@ -979,7 +980,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                         // context / class filter over the table's own records, then the packed filter on what it could not decide
                         ea.l2_list = sl->l2_list.p;
                         ea.l2_cap = (uint32_t)std::min<size_t>(sl->l2_list.cap / L2_NSUB, 0xFFFFFFu);  // per sub-list
-                        check_memcpy(hipMemsetAsync(sl->l2_counts.p, 0, (size_t)L2_NSUB * L2_CNT_STRIDE * sizeof(uint32_t), st), "second-level counters");
+                        if (!cleared) check_memcpy(hipMemsetAsync(sl->l2_counts.p, 0, (size_t)L2_NSUB * L2_CNT_STRIDE * sizeof(uint32_t), st), "second-level counters");
                         { ProfScope p(sl, "extend_filter"); launch_extend_filter_cls(ea, st); }
                         ExtendArgs e2 = ea;
                         e2.td = 0;
@@ -990,7 +991,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                         launch_extend_filter(ea, st);
                     }
                     if (ea.chain_cap) {
-                        check_memcpy(hipMemsetAsync(sl->chain_bucket_cnt.p, 0, chain_num_buckets() * sizeof(uint32_t), st), "chain buckets");
+                        if (!cleared) check_memcpy(hipMemsetAsync(sl->chain_bucket_cnt.p, 0, chain_num_buckets() * sizeof(uint32_t), st), "chain buckets");
                         { ProfScope p(sl, "chain_group"); launch_chain_group(ea, st); }
                         { ProfScope p(sl, "chain_link");  launch_chain_link(ea, st); }
                     }
@@ -1009,7 +1010,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                         sl->out16.ensure(dedup_seg_max_total(), "out16");
                         ensure_host_out(dedup_seg_max_total());
                         ensure_host_seg(std::max<size_t>(dedup_seg_max_total(), seg_words));
-                        check_memcpy(hipMemsetAsync(sl->d_seg_info, 0, seg_words * sizeof(uint32_t), st), "segment info");
+                        if (!cleared) check_memcpy(hipMemsetAsync(sl->d_seg_info, 0, seg_words * sizeof(uint32_t), st), "segment info");
                         { ProfScope p(sl, "dedup_seg"); launch_dedup_seg(ea.out, 0, &sl->d_cnt->survivors, (uint32_t)segs.size(), sl->out16.p, sl->d_seg_info, (uint32_t)g_dedup_threads, g_dedup_seg_max, st); }
                         check_launch("dedup seg");
                         check_memcpy(hipMemcpyAsync(sl->h_seg_info, sl->d_seg_info, seg_words * sizeof(uint32_t), hipMemcpyDeviceToHost, st), "segment info");
@@ -1045,6 +1046,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                         sl->recA.ensure((size_t)std::min<uint64_t>((uint64_t)before.survivors + bh, (uint64_t)c.survivors + c.n_long + c.n_ent),
                                         "survivors(grow)", true, st);
                     check_memcpy(hipMemcpy(sl->d_cnt, &before, sizeof(Counters), hipMemcpyHostToDevice), "counter reset");
+                    cleared = false;  // (the rerun of the batch clears its lists itself)
                 }
                 survivors = sl->h_cnt->survivors;
                 n_cand_total += sl->h_cnt->n_long;
@@ -1438,11 +1440,19 @@ static uint32_t td_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, int K, con
     // head-bit map for the class filter: sized for 128 hits per position; a denser call regrows it (it stays) and repeats the compaction
     const bool want_bits = dc->nbr_ctx28 != nullptr;
     if (want_bits) sl->td_bits.ensure(std::max<size_t>((size_t)n * 4 + 64, 1u << 16), "probe head bits");
+    // the device-side state the later stages of the call expect zeroed is cleared by the probe's own clearing kernel
+    sl->l2_counts.ensure((size_t)L2_NSUB * L2_CNT_STRIDE, "second-level counters");
+    sl->chain_bucket_cnt.ensure(chain_num_buckets(), "chain buckets");
+    ZeroList zl;
+    zl.p[0] = reinterpret_cast<uint32_t*>(sl->d_cnt);  zl.n[0] = (uint32_t)(sizeof(Counters) / sizeof(uint32_t));
+    zl.p[1] = sl->l2_counts.p;                         zl.n[1] = (uint32_t)(L2_NSUB * L2_CNT_STRIDE);
+    zl.p[2] = sl->chain_bucket_cnt.p;                  zl.n[2] = chain_num_buckets();
+    zl.p[3] = sl->d_seg_info;                          zl.n[3] = dedup_seg_info_words();
     for (bool first_pass = true;; first_pass = false) {
         {
             ProfScope p(sl, "probe_compact");
             launch_probe_compact(start, n, sl->td_toff.p, sl->td_tcnt.p, sl->td_partial.p, sl->d_td_bounds, sl->td_rec.p, sl->td_chunk.p, TD_CHUNK_CAP,
-                                 want_bits ? sl->td_bits.p : nullptr, (uint32_t)std::min<size_t>(sl->td_bits.cap, 0xFFFFFFFFu), tb, first_pass, st);
+                                 want_bits ? sl->td_bits.p : nullptr, (uint32_t)std::min<size_t>(sl->td_bits.cap, 0xFFFFFFFFu), zl, tb, first_pass, st);
         }
         {
             ProfScope p(sl, "iteration_plan");
@@ -1450,7 +1460,6 @@ static uint32_t td_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, int K, con
         }
         check_launch("probe");
         check_memcpy(hipMemcpyAsync(sl->h_td_plan, sl->d_td_plan, sizeof(TdPlan) * K, hipMemcpyDeviceToHost, st), "probe plan");
-        check_memcpy(hipMemsetAsync(sl->d_cnt, 0, sizeof(Counters), st), "counters");
         check_sync(st, "probe plan");
         const uint64_t call_hits = sl->h_td_plan[K - 1].hit_base + sl->h_td_plan[K - 1].num_hits;
         const uint64_t need_words = ((call_hits + 63) >> 6) * 2 + 16;  // (the filter reads up to six 64-bit words past the last buffer)
@@ -1464,7 +1473,7 @@ static uint32_t td_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, int K, con
         if (tp.num_hits >= (uint64_t)(uint32_t)g_max_hits) return 0xFFFFFFFFu;
         if (!rm && tp.num_hits > 0xFFFFFFFFull) return 0xFFFFFFFFu;
     }
-    if (sl->h_td_plan[K - 1].hit_base + sl->h_td_plan[K - 1].num_hits > 0xFFFFFFFFull) return 0xFFFFFFFFu;
+    if (sl->h_td_plan[K - 1].hit_base + sl->h_td_plan[K - 1].num_hits >= 0xFFFFFFFFull) return 0xFFFFFFFFu;  // (hit indices are 32-bit, 2^32 - 1 is a sentinel)
     if (nvalid * words >= 0xFFFFFFFFull) return 0xFFFFFFFFu;
     return (uint32_t)(nvalid * words);
 }
@@ -1558,7 +1567,7 @@ struct Option {
 static Option g_opts[] = {
     // deployment
     {"slots", 2, 1, MAX_SLOTS_PER_DEVICE, 0},          // calls in flight per device (the reference allows one: token == device)
-    {"chunks_per_call", SA_MAX_CHUNKS, 1, SA_MAX_CHUNKS, 0},  // chunks sa_seed_interval / sa_rm_mask_interval hand to one pass
+    {"chunks_per_call", SA_DEFAULT_CHUNKS, 1, SA_MAX_CHUNKS, 0},  // chunks sa_seed_interval / sa_rm_mask_interval hand to one pass
     {"no_ctx", 0, 0, 1, 0},                            // 1: neighbourhood table without target context (lookup mode 1)
     {"no_td", 0, 0, 1, 0},                             // 1: no neighbourhood table at all (lookup mode 0, the reference-shaped path)
     {"no_chain", 0, 0, 1, 0},                          // 1: every candidate is extended on its own (no chain shortcut)

@@ -532,8 +532,28 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
     __shared__ CandRec s_cand[PK_THREADS / 64][STAGE_CAP];
     __shared__ uint32_t s_l2pre[SRC == SRC_CAND ? L2_NSUB + 1 : 1];  // SRC_CAND: prefix of the sub-lists of the second-level list
     pk_table_init(s_pk, a.sub_mat, PK_THREADS);
-    if (SRC == SRC_CAND)
-        for (int i = threadIdx.x; i <= L2_NSUB; i += PK_THREADS) s_l2pre[i] = a.l2_prefix[i];
+    if (SRC == SRC_CAND) {
+        // prefix of the sub-list counts (clamped to their capacity), computed by every workgroup for itself -- 256 values, a
+        // microsecond -- instead of by a kernel of its own; workgroup 0 also reports the total and the largest raw count
+        __shared__ uint32_t s_l2cnt[SRC == SRC_CAND ? L2_NSUB : 1];
+        uint32_t raw = 0;
+        if (threadIdx.x < L2_NSUB) {
+            raw = a.l2_count[threadIdx.x * L2_CNT_STRIDE];
+            s_l2cnt[threadIdx.x & (SRC == SRC_CAND ? 0xFFFF : 0)] = min(raw, a.l2_cap);
+        }
+        __syncthreads();
+        if (threadIdx.x <= L2_NSUB) {
+            uint32_t pre = 0;
+            for (int t = 0; t < (int)threadIdx.x; t++) pre += s_l2cnt[t & (SRC == SRC_CAND ? 0xFFFF : 0)];
+            s_l2pre[threadIdx.x & (SRC == SRC_CAND ? 0xFFFF : 0)] = pre;
+            if (blockIdx.x == 0 && threadIdx.x == L2_NSUB) *a.l2_total = pre;
+        }
+        if (blockIdx.x == 0 && threadIdx.x < L2_NSUB) {
+            uint32_t mx = raw;
+            for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+            if ((threadIdx.x & 63) == 0) atomicMax(a.l2_max, mx);
+        }
+    }
     __syncthreads();
     CandRec* stage = s_cand[threadIdx.x >> 6];
     int n_stage = 0;
@@ -1051,28 +1071,6 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(E
     stage_flush(stage, n_stage, my_list, my_count, a.l2_cap, lane);
 }
 
-// one workgroup of L2_NSUB threads: prefix of the sub-list counts (clamped to their capacity), total and maximum
-__global__ __launch_bounds__(L2_NSUB) void l2_prefix_kernel(ExtendArgs a) {
-    __shared__ uint32_t s_v[L2_NSUB];
-    const uint32_t c = a.l2_count[threadIdx.x * L2_CNT_STRIDE];
-    s_v[threadIdx.x] = min(c, a.l2_cap);
-    __syncthreads();
-    uint32_t pre = 0, mx = 0;
-    for (int t = 0; t < L2_NSUB; t++) {  // 256 broadcast reads per thread: a microsecond
-        const uint32_t v = s_v[t];
-        if (t < (int)threadIdx.x) pre += v;
-    }
-    a.l2_prefix[threadIdx.x] = pre;
-    // maximum of the raw counts (wave reduce, then one atomic per wave)
-    mx = c;
-    for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(a.l2_max, mx);
-    if (threadIdx.x == L2_NSUB - 1) {
-        a.l2_prefix[L2_NSUB] = pre + s_v[L2_NSUB - 1];
-        *a.l2_total = pre + s_v[L2_NSUB - 1];
-    }
-}
-
 // =====================================================================================================================
 // 2. exact extension of the candidates: one wave per hit, 512 bases per step
 // =====================================================================================================================
@@ -1261,7 +1259,7 @@ __device__ __forceinline__ uint32_t chain_bucket_of(uint32_t seg, const CandRec&
 }
 __device__ __forceinline__ unsigned long long chain_key(const ExtendArgs& a, const CandRec& c) {
     // iteration | diagonal (32) | query position (q bits): 3 | 32 | 29 with absolute positions (general path, <= 8 iterations per
-    // batch), 5 | 32 | 27 with positions relative to the call's first one (table-direct calls: <= 32 iterations, <= 4 M positions)
+    // batch), 6 | 32 | 26 with positions relative to the call's first one (table-direct calls: <= 64 iterations, <= 8 M positions)
     const uint32_t qb = a.chain_q_bits;
     return ((unsigned long long)(seg_of(a, c.hidx) - a.seg_base) << (32u + qb)) |
            ((unsigned long long)(uint32_t)(c.ref_loc - c.query_loc) << qb) |
@@ -1307,27 +1305,38 @@ __global__ __launch_bounds__(256) void chain_scatter_kernel(ExtendArgs a) {
     }
 }
 
-// one workgroup per bucket: rank sort in LDS by (iteration, diagonal, position)
+// CHAIN_SORT_GROUP consecutive buckets per workgroup (a bucket holds ~40 candidates: one workgroup per bucket was 16384 tiny
+// workgroups whose dispatch cost more than their work): rank sort in LDS by (iteration, diagonal, position), every entry ranked
+// inside its own bucket
+constexpr uint32_t CHAIN_SORT_GROUP = 8;
 __global__ __launch_bounds__(512) void chain_bucket_sort_kernel(ExtendArgs a) {
-    __shared__ unsigned long long s_key[CHAIN_SORT_MAX];
+    __shared__ unsigned long long s_key[CHAIN_SORT_GROUP * CHAIN_SORT_MAX / 2];  // 32 KB: the group's entries, when they fit
+    __shared__ uint32_t s_b[CHAIN_SORT_GROUP + 1];
     const uint32_t n = min(*a.cand_count, a.cand_cap_recs);
     if (n > a.chain_cap) return;
-    const uint32_t b0 = a.chain_bucket_start[blockIdx.x], m = a.chain_bucket_start[blockIdx.x + 1] - b0;
-    if (m == 0) return;
-    if (m > CHAIN_SORT_MAX) {
-        for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) a.chain_sorted[b0 + i] = a.chain_tmp[b0 + i];
+    if (threadIdx.x <= CHAIN_SORT_GROUP) s_b[threadIdx.x] = a.chain_bucket_start[blockIdx.x * CHAIN_SORT_GROUP + threadIdx.x];
+    __syncthreads();
+    const uint32_t g0 = s_b[0], m_all = s_b[CHAIN_SORT_GROUP] - g0;
+    if (m_all == 0) return;
+    bool big = m_all > CHAIN_SORT_GROUP * CHAIN_SORT_MAX / 2;  // (a bucket above CHAIN_SORT_MAX, or a group that does not fit: left unsorted)
+    for (uint32_t j = 0; j < CHAIN_SORT_GROUP; j++) big = big || (s_b[j + 1] - s_b[j]) > CHAIN_SORT_MAX;
+    if (big) {
+        for (uint32_t i = threadIdx.x; i < m_all; i += blockDim.x) a.chain_sorted[g0 + i] = a.chain_tmp[g0 + i];
         return;
     }
-    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) s_key[i] = chain_key(a, a.chain_tmp[b0 + i]);
+    for (uint32_t i = threadIdx.x; i < m_all; i += blockDim.x) s_key[i] = chain_key(a, a.chain_tmp[g0 + i]);
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+    for (uint32_t i = threadIdx.x; i < m_all; i += blockDim.x) {
+        uint32_t j = 0;  // the entry's bucket inside the group
+        while (g0 + i >= s_b[j + 1]) j++;
+        const uint32_t lo = s_b[j] - g0, hi = s_b[j + 1] - g0;
         const unsigned long long k = s_key[i];
         uint32_t rank = 0;
-        for (uint32_t j = 0; j < m; j++) {
-            const unsigned long long kj = s_key[j];
-            rank += (kj < k || (kj == k && j < i)) ? 1u : 0u;  // keys are unique per hit; the index breaks hand-made ties
+        for (uint32_t t = lo; t < hi; t++) {
+            const unsigned long long kt = s_key[t];
+            rank += (kt < k || (kt == k && t < i)) ? 1u : 0u;  // keys are unique per hit; the index breaks hand-made ties
         }
-        a.chain_sorted[b0 + rank] = a.chain_tmp[b0 + i];
+        a.chain_sorted[g0 + lo + rank] = a.chain_tmp[g0 + i];
     }
 }
 
@@ -1510,7 +1519,6 @@ void launch_extend_filter_cls(const ExtendArgs& a, hipStream_t s) {
     const uint32_t blocks = (uint32_t)((waves + wpb - 1) / wpb);
     const size_t lds = wpb * CTX_STAGE_CAP * sizeof(L2Rec);
     hipLaunchKernelGGL(extend_filter_cls_kernel, dim3(blocks), dim3(threads), lds, s, a);
-    hipLaunchKernelGGL(l2_prefix_kernel, dim3(1), dim3(L2_NSUB), 0, s, a);
 }
 
 void launch_chain_group(const ExtendArgs& a, hipStream_t s) {  // chain_bucket_cnt must be zero on entry
@@ -1518,7 +1526,7 @@ void launch_chain_group(const ExtendArgs& a, hipStream_t s) {  // chain_bucket_c
     hipLaunchKernelGGL(chain_count_kernel, dim3(256), dim3(256), 0, s, a);
     hipLaunchKernelGGL(chain_scan_kernel, dim3(1), dim3(256), 0, s, a);
     hipLaunchKernelGGL(chain_scatter_kernel, dim3(256), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(chain_bucket_sort_kernel, dim3(CHAIN_BUCKETS), dim3(a.chain_sort_threads ? a.chain_sort_threads : 256), 0, s, a);
+    hipLaunchKernelGGL(chain_bucket_sort_kernel, dim3(CHAIN_BUCKETS / CHAIN_SORT_GROUP), dim3(a.chain_sort_threads ? a.chain_sort_threads : 256), 0, s, a);
 }
 uint32_t chain_num_buckets() { return CHAIN_BUCKETS; }
 void launch_chain_link(const ExtendArgs& a, hipStream_t s) {

@@ -13,7 +13,7 @@ namespace sa {
 constexpr int SEQ_PAD = 64;
 
 constexpr int MAX_CARE = 16;  // seed weight limit; reference asserts 3 < kmer_size <= 15 (seed_pos_table.cu:51-52)
-constexpr int MAX_SEGS = 32;  // reference iterations handled by one extension batch (16 chunks x 2 iterations of a table-direct call)
+constexpr int MAX_SEGS = 64;  // reference iterations handled by one extension batch (32 chunks x 2 iterations of a table-direct call)
 constexpr int MAX_SEGS_ABS = 8;  // ... of a batch whose chain sort key carries absolute query positions (general path)
 
 struct SeedShape {            // device copy of the state GenerateShapePos keeps (ntcoding.cpp:6-8)
@@ -154,7 +154,6 @@ struct ExtendArgs {
     L2Rec* l2_list;
     uint32_t* l2_count;
     uint32_t l2_cap;
-    uint32_t* l2_prefix;        // [L2_NSUB + 1]: exclusive prefix of min(count, l2_cap) over the sub-lists (l2_prefix_kernel)
     uint32_t* l2_total;         // -> number of records in all sub-lists
     uint32_t* l2_max;           // -> largest sub-list count (> l2_cap: records were dropped, the host regrows and reruns)
     int src_cand;               // packed filter reads its anchors from l2_list / *l2_count instead of `hits`

@@ -7,7 +7,7 @@
 
 namespace sa {
 
-constexpr int TD_MAX_BOUNDS = 20; // chunk boundaries of one call: SA_MAX_CHUNKS + 1 <= 20
+constexpr int TD_MAX_BOUNDS = 36; // chunk boundaries of one call: SA_MAX_CHUNKS + 1 <= 36
 
 struct TdBounds {                 // query positions of the chunk boundaries of a call, ascending; pos[0] = start, pos[nb-1] = end
     int nb;
@@ -21,6 +21,12 @@ struct TdPlan {                   // per chunk, written by probe_plan_kernel
     uint32_t num_valid;           // valid seed positions (seed words = num_valid * words per position)
     uint32_t m_lo, m_hi;          // the chunk's range of compacted (non-empty) positions
     uint32_t pad;
+};
+
+struct ZeroList {                 // dword regions the per-call clearing kernel zeroes next to the head-bit map
+    static constexpr int N = 4;
+    uint32_t* p[N];
+    uint32_t n[N];
 };
 
 // neighbourhood table build
@@ -44,7 +50,7 @@ void launch_probe_lookup(const uint8_t* query, uint32_t start, uint32_t n, SeedS
 // head_bits (nullable): bit g of the map is set <=> a record starts at hit g of the call; only hits below 32 * head_words get a bit
 void launch_probe_compact(uint32_t start, uint32_t n, const uint64_t* t_off, const uint32_t* t_cnt, void* partial_buf, void* bounds_buf,
                           TdRec* c_rec, uint32_t* chunk_rec, uint32_t chunk_cap, uint32_t* head_bits, uint32_t head_words,
-                          const TdBounds& bpos, bool first_pass, hipStream_t s);
+                          const ZeroList& zero, const TdBounds& bpos, bool first_pass, hipStream_t s);
 void launch_probe_plan(const uint8_t* query, SeedShape sh, uint32_t tmask, const uint32_t* bucket_start, const void* bounds_buf, int nchunks,
                        const TdRec* c_rec, TdPlan* plan, hipStream_t s);
 

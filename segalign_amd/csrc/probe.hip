@@ -393,10 +393,19 @@ __global__ void probe_plan_kernel(const uint8_t* __restrict__ query, SeedShape s
     plan[c] = p;
 }
 
-// zero the words of the head-bit map the call will use (its hit total is only known on the device at this point)
-__global__ __launch_bounds__(256) void head_bits_clear_kernel(const Tri* __restrict__ total, uint32_t* __restrict__ head_bits, uint32_t head_words) {
-    const uint64_t need = min((uint64_t)head_words, ((total->hits + 63) >> 6) * 2 + 16);  // (+ the words the filter reads ahead)
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < need; i += (uint64_t)gridDim.x * blockDim.x) head_bits[i] = 0u;
+// ONE clearing kernel per table-direct call: the words of the head-bit map the call will use (its hit total is only known on the
+// device at this point) and the small device-side state the later stages expect zeroed -- counters, the sub-list counters of the
+// second-level list, the chain buckets, the per-segment info of the dedup stage (five hipMemsetAsync launches before).
+__global__ __launch_bounds__(256) void call_clear_kernel(const Tri* __restrict__ total, uint32_t* __restrict__ head_bits, uint32_t head_words,
+                                                         ZeroList z) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
+    if (head_bits) {
+        const uint64_t need = min((uint64_t)head_words, ((total->hits + 63) >> 6) * 2 + 16);  // (+ the words the filter reads ahead)
+        for (uint64_t i = tid; i < need; i += nth) head_bits[i] = 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < ZeroList::N; r++)
+        for (uint64_t i = tid; i < z.n[r]; i += nth) z.p[r][i] = 0u;
 }
 
 size_t probe_partial_bytes(uint32_t n) { return ((size_t)(n + 3 + PR_TILE - 1) / PR_TILE + 2) * sizeof(Tri); }
@@ -411,14 +420,14 @@ void launch_probe_lookup(const uint8_t* query, uint32_t start, uint32_t n, SeedS
 }
 void launch_probe_compact(uint32_t start, uint32_t n, const uint64_t* t_off, const uint32_t* t_cnt, void* partial_buf, void* bounds_buf,
                           TdRec* c_rec, uint32_t* chunk_rec, uint32_t chunk_cap, uint32_t* head_bits, uint32_t head_words,
-                          const TdBounds& bpos, bool first_pass, hipStream_t s) {
+                          const ZeroList& zero, const TdBounds& bpos, bool first_pass, hipStream_t s) {
     Tri* partial = reinterpret_cast<Tri*>(partial_buf);
     const uint32_t nblocks = probe_blocks(start, n);
     Tri* total = partial + nblocks;
     // (the block sums are turned into prefixes IN PLACE: only once per probe -- a repeated compaction, after the head-bit map
     //  was regrown, starts from the prefixes)
     if (first_pass) hipLaunchKernelGGL(probe_partials_kernel, dim3(1), dim3(PR_THREADS), 0, s, partial, nblocks, total);
-    if (head_bits) hipLaunchKernelGGL(head_bits_clear_kernel, dim3(1024), dim3(256), 0, s, total, head_bits, head_words);
+    hipLaunchKernelGGL(call_clear_kernel, dim3(head_bits ? 1024 : 64), dim3(256), 0, s, total, head_bits, head_words, zero);
     hipLaunchKernelGGL(probe_compact_kernel, dim3(nblocks), dim3(PR_THREADS), 0, s, start, n, t_off, t_cnt, partial, total, c_rec, chunk_rec,
                        chunk_cap, head_bits, head_words, bpos, reinterpret_cast<Tri*>(bounds_buf));
 }

@@ -92,7 +92,14 @@ def test_block_that_does_not_fit_falls_back_to_positions_and_recovers(oracle, en
     E.InitializeInterface(1)
     k = E.GenerateShapePos(SHAPE)
     O.generate_shape_pos(SHAPE)
-    E.set_option("arena_gb", 8)  # (a small arena, so that what is mapped when the memory is taken away does not depend on timing)
+    # the table arena is a process-wide cache: give back what earlier tests left mapped (arena_gb = 0 releases it at
+    # ShutdownProcessor), then run with a small arena, so that what is mapped when the memory is taken away is known
+    E.set_option("arena_gb", 0)
+    E.InitializeProcessor(True, CHUNK, 19, sub_mat, 910, 3000, False)
+    E.ShutdownProcessor()
+    E.InitializeInterface(1)
+    k = E.GenerateShapePos(SHAPE)
+    E.set_option("arena_gb", 8)
     E.InitializeProcessor(True, CHUNK, 19, sub_mat, 910, 3000, False)
     hog = None
     try:

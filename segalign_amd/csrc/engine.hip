@@ -466,8 +466,7 @@ struct DevCtx {
     std::mutex nbr_mu;
     uint64_t* nbr_start = nullptr;       // nkeys + 1
     uint32_t* nbr_pos = nullptr;         // == pos_table when no transition word exists (nbr_alias); null when nbr_ctx is built
-    Ctx28* nbr_ctx28 = nullptr;          // the runs WITH their target context: 28-byte records + nbr_pos as the side array (class filter, extend.hip 1d)
-    bool nbr_pos_in_arena = false;       // nbr_pos lies inside the arena (not freed on its own)
+    CtxRec* nbr_ctx = nullptr;           // the runs WITH their target context: 32-byte records in the arena (class filter, extend.hip 1d)
     Arena& arena;                        // memory of the context table: outlives target blocks AND engine contexts (a process-wide
                                          // cache per device ordinal, see arena_of), grown in the background
     explicit DevCtx(Arena& a) : arena(a) {}
@@ -548,6 +547,9 @@ static void class_scores(uint32_t present_t, uint32_t present_q, int cls[4]) {
             any = true;
         }
     if (any) for (int x = 0; x < 4; x++) cls[x] = std::max(cls[x], na);
+    // the filter keeps (score, drop) as two int16 halves of one register: 64 bases x |score| must stay below 2^14.  Raising a
+    // negative score keeps the bound an upper bound (positive scores are <= 127 wherever the packed filters are eligible)
+    for (int x = 0; x < 4; x++) cls[x] = std::max(cls[x], -255);
 }
 
 static int max_hits_for_mem(uint64_t total_global_mem) {  // src/seed_filter.cu:832-841, literally
@@ -864,15 +866,17 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     ea.td_m = sl->h_td_plan[K - 1].m_hi;
                     ea.td_pos = dc->nbr_pos;
                     ea.seed_size = g_seed_size;
-                    if (dc->nbr_ctx28 && ca.q2_own && ca.q2_own->base && ca.q2_other && ca.q2_other->base) {
-                        ea.td_ctx28 = dc->nbr_ctx28;
+                    // (class filter: needs the 2-bit copies of both strands, each set below 4 GB -- blocks of up to ~1 Gbp)
+                    if (dc->nbr_ctx && ca.q2_own && ca.q2_own->base && ca.q2_other && ca.q2_other->base &&
+                        ca.q2_own->stride * Q2_COPIES < ((size_t)1 << 32)) {
+                        ea.td_ctx = dc->nbr_ctx;
                         ea.td_bits = reinterpret_cast<const uint64_t*>(sl->td_bits.p);
                         ea.q2_own = ca.q2_own->base;
                         ea.q2_other = ca.q2_other->base;
                         ea.q2_stride = ca.q2_own->stride;
                         class_scores(dc->ref_present, ca.q_present, ea.cls);
                     }
-                    if (ea.td_ctx28) {
+                    if (ea.td_ctx) {
                         // (a sub-list can take a whole chunk; SEGALIGN_AMD_L2_CAP: tests start small to reach the regrow-and-rerun path)
                         sl->l2_list.ensure(g_l2_cap_test ? (size_t)g_l2_cap_test
                                                          : (size_t)std::max<uint64_t>((uint64_t)L2_NSUB * TD_CHUNK_HITS, bh / 8), "second-level list");
@@ -976,7 +980,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                     ea.cand_cap_recs = (uint32_t)std::min<size_t>(sl->cand_list.cap, 0xFFFFFFFFu);
                     ea.ent_list = sl->ent_list.p;
                     ea.ent_cap_recs = (uint32_t)std::min<size_t>(sl->ent_list.cap, 0xFFFFFFFFu);
-                    if (ea.td && ea.td_ctx28) {
+                    if (ea.td && ea.td_ctx) {
                         // context / class filter over the table's own records, then the packed filter on what it could not decide
                         ea.l2_list = sl->l2_list.p;
                         ea.l2_cap = (uint32_t)std::min<size_t>(sl->l2_list.cap / L2_NSUB, 0xFFFFFFu);  // per sub-list
@@ -1033,7 +1037,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                         check_sync(st, "extend (no chain)");
                     }
                     const Counters& c = *sl->h_cnt;
-                    const bool l2_ok = !(ea.td && ea.td_ctx28) || c.n_l2_max <= ea.l2_cap;
+                    const bool l2_ok = !(ea.td && ea.td_ctx) || c.n_l2_max <= ea.l2_cap;
                     if (c.survivors <= ea.out_cap && c.n_long <= ea.cand_cap_recs && c.n_ent <= ea.ent_cap_recs && l2_ok) break;
                     if (!l2_ok)  // (the later stages saw a truncated list)
                         sl->l2_list.ensure((size_t)c.n_l2_max * L2_NSUB + ((size_t)c.n_l2_max * L2_NSUB) / 4, "second-level list(grow)");
@@ -1176,7 +1180,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
     }
     prof_flush(sl);
 
-    t_stats.lookup_path = ca.td ? ((dc->nbr_ctx28 && ca.q2_own && ca.q2_own->base) ? 2 : 1) : 0;
+    t_stats.lookup_path = ca.td ? ((dc->nbr_ctx && ca.q2_own && ca.q2_own->base) ? 2 : 1) : 0;
     t_stats.num_hits = num_hits;
     t_stats.num_survivors = survivors;
     t_stats.num_anchors = n_final;
@@ -1295,11 +1299,10 @@ __global__ void widen_u32_kernel(const uint32_t* __restrict__ in, uint64_t* __re
 
 static void nbr_release(DevCtx* dc) {
     dev_free(dc->nbr_start, "nbr_start");
-    if (!dc->nbr_alias && !dc->nbr_pos_in_arena) dev_free(dc->nbr_pos, "nbr_pos");
+    if (!dc->nbr_alias) dev_free(dc->nbr_pos, "nbr_pos");
     dc->nbr_start = nullptr;
     dc->nbr_pos = nullptr;
-    dc->nbr_pos_in_arena = false;
-    dc->nbr_ctx28 = nullptr;  // (the memory stays with the arena)
+    dc->nbr_ctx = nullptr;  // (the memory stays with the arena)
     dc->nbr_alias = false;
     dc->nbr_total = 0;
     dc->nbr_state = 0;
@@ -1351,28 +1354,25 @@ static bool ensure_nbr(DevCtx* dc) {
     // keep room for the slots' work buffers: at human-scale hit density a sixteen-chunk call holds ~6 GB of lists per slot
     const size_t reserve = ((size_t)8 << 30) + ((size_t)4 << 30) * (size_t)SLOTS_PER_DEVICE;
     const size_t need_pos = (size_t)std::max<uint64_t>(total, 1) * sizeof(uint32_t);
-    // 28-byte records + the side array of positions (class filter): 32 bytes per entry; the two-stage fill wants num_index
-    // records of scratch behind them, which is given up (one-stage fill) when only the table itself fits
-    const size_t rec28 = (((size_t)std::max<uint64_t>(total, 1) * sizeof(Ctx28)) + 255) & ~(size_t)255;
-    const size_t pos28 = (need_pos + 255) & ~(size_t)255;
-    const size_t scratch28 = (size_t)dc->num_index * sizeof(Ctx28);
+    // context records (class filter): 32 bytes per entry; the two-stage fill wants num_index records of scratch behind them, which is
+    // given up (one-stage fill) when only the table itself fits.  (+ 4 KB of slack: the filter's lanes past a call's last hit
+    // read up to 63 entries past a run)
+    const size_t rec_b = (size_t)std::max<uint64_t>(total, 1) * sizeof(CtxRec) + 4096;
+    const size_t scratch_b = (size_t)dc->num_index * sizeof(CtxRec);
     const size_t have = arena_mapped(dc->arena);  // (already ours: does not count against the free memory)
     bool built = false;
-    if (g_ctx && dc->ref2.base && rec28 + pos28 + reserve <= free_b + have) {
-        const bool two_stage = g_nbr_two_stage && tmask != 0 && rec28 + pos28 + scratch28 + reserve <= free_b + have;
-        const size_t need = rec28 + pos28 + (two_stage ? scratch28 : 0);
+    if (g_ctx && dc->ref2.base && rec_b + reserve <= free_b + have) {
+        const bool two_stage = g_nbr_two_stage && tmask != 0 && rec_b + scratch_b + reserve <= free_b + have;
+        const size_t need = rec_b + (two_stage ? scratch_b : 0);
         if (arena_wait(dc->arena, need)) {
             uint8_t* arena = dc->arena.base;
-            dc->nbr_ctx28 = reinterpret_cast<Ctx28*>(arena);
-            dc->nbr_pos = reinterpret_cast<uint32_t*>(arena + rec28);
-            dc->nbr_pos_in_arena = true;
+            dc->nbr_ctx = reinterpret_cast<CtxRec*>(arena);
             if (dbg) fprintf(stderr, "neighbourhood table: %.1f M entries, waited %.1f ms for %.1f GB of arena\n", total / 1e6, now() - t_a, need / 1e9);
             const double t_b = now();
-            launch_nbr_fill_ctx28(dc->bucket_start, dc->pos_table, nkeys, tmask, g_shape.weight, dc->nbr_start, dc->ref2.base, dc->ref2.stride,
-                                  g_seed_size, dc->nbr_ctx28, dc->nbr_pos, two_stage ? reinterpret_cast<Ctx28*>(arena + rec28 + pos28) : nullptr,
-                                  (uint32_t)dc->num_index, st);
-            check_launch("nbr fill ctx28");
-            check_sync(st, "nbr fill ctx28");
+            launch_nbr_fill_ctx(dc->bucket_start, dc->pos_table, nkeys, tmask, g_shape.weight, dc->nbr_start, dc->ref2.base, dc->ref2.stride,
+                                g_seed_size, dc->nbr_ctx, two_stage ? reinterpret_cast<CtxRec*>(arena + rec_b) : nullptr, (uint32_t)dc->num_index, st);
+            check_launch("nbr fill ctx");
+            check_sync(st, "nbr fill ctx");
             if (dbg) fprintf(stderr, "neighbourhood table: context fill (%s) took %.1f ms\n", two_stage ? "two-stage" : "one-stage", now() - t_b);
             built = true;
         }
@@ -1389,7 +1389,7 @@ static bool ensure_nbr(DevCtx* dc) {
                        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
                    }
                    if (dbg) fprintf(stderr, "neighbourhood table: no room for the context table (%.1f GB + %.1f GB reserve), positions only need %.1f GB, free %.1f GB\n",
-                                    (rec28 + pos28) / 1e9, reserve / 1e9, need_pos / 1e9, free_b / 1e9);
+                                    rec_b / 1e9, reserve / 1e9, need_pos / 1e9, free_b / 1e9);
                    return need_pos + reserve <= free_b;
                }()) {
         dc->nbr_pos = (uint32_t*)dev_malloc(need_pos, "nbr_pos");
@@ -1438,7 +1438,7 @@ static uint32_t td_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, int K, con
         launch_probe_lookup(qcodes, start, n, sh, dc->nbr_start, dc->nkeys, sl->td_toff.p, sl->td_tcnt.p, sl->td_partial.p, st);
     }
     // head-bit map for the class filter: sized for 128 hits per position; a denser call regrows it (it stays) and repeats the compaction
-    const bool want_bits = dc->nbr_ctx28 != nullptr;
+    const bool want_bits = dc->nbr_ctx != nullptr;
     if (want_bits) sl->td_bits.ensure(std::max<size_t>((size_t)n * 4 + 64, 1u << 16), "probe head bits");
     // the device-side state the later stages of the call expect zeroed is cleared by the probe's own clearing kernel
     sl->l2_counts.ensure((size_t)L2_NSUB * L2_CNT_STRIDE, "second-level counters");
@@ -2683,7 +2683,7 @@ int sa_get_lookup_mode(void) {  // how device-seeded calls look seeds up on devi
     DevCtx* dc = g_dev[0];
     check_set_device(dc->dev, "lookup mode");
     if (!(g_td && g_packed_filter && !g_count_examined && dc->ref2.base && ensure_nbr(dc))) return 0;
-    return dc->nbr_ctx28 ? 2 : 1;
+    return dc->nbr_ctx ? 2 : 1;
 }
 uint64_t sa_get_neighbourhood_entries(void) { return (g_ndev > 0 && g_dev[0]->nbr_state == 1) ? g_dev[0]->nbr_total : 0; }
 void sa_profile_enable(int on) { g_prof_on = on != 0; }

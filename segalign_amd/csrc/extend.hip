@@ -599,9 +599,11 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
                 h.ref_loc = c.ref_loc;
                 h.query_loc = c.query_loc;
                 f_idx = c.hidx;
-                f_known = (uint32_t)c.known;
-                f_tm = c.tm;
-                f_flags = c.flags;
+                f_known = c.meta & 0xFFFFu;
+                f_flags = (c.meta >> 16) & 3u;
+                // level 1's packed left-walk state {T : D} -> {running score (low 16) | best score = T + D (high 16)}
+                const int t16 = (int)c.state >> 16;
+                f_tm = ((uint32_t)t16 & 0xFFFFu) | ((uint32_t)(t16 + (int)(c.state & 0xFFFFu)) << 16);
             }
         } else if (cnt > 0) {  // (wave-uniform)
             uint64_t entry;
@@ -837,36 +839,44 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
     stage_flush(stage, n_stage, a.cand_list, a.cand_count, a.cand_cap_recs, lane);
 }
 
-// ---- launch constants of the record-stream filter (1d) ---------------------------------------------------------------------
-// Workgroup size: 1024 threads (two workgroups per CU = 8 waves per SIMD; the class table is built once per 16 waves).
-constexpr int CTX_THREADS = 1024;      // default; ExtendArgs::ctx_threads (option ctx_threads) overrides it per launch
-constexpr int CTX_THREADS_MAX = 1024;
-constexpr int CTX_STAGE_FLUSH = 32;                    // forwards are rare (~4 % of the hits): flush early, keep the stage small
-constexpr int CTX_STAGE_CAP = CTX_STAGE_FLUSH - 1 + 64 + 1;  // 96 records of 24 bytes per wave: two workgroups per CU fit
-
 // =====================================================================================================================
-// 1d. the X-drop filter on 28-byte context records with CLASS scoring: 6 bases per table lookup
+// 1d. the X-drop filter on the CONTEXT table with CLASS scoring: the target bases travel with the seed table entry (no random
+//     target access), 6 bases per table lookup
 // =====================================================================================================================
-// 1c is bound by instruction issue: two bases per LDS lookup, ~39 VALU + 8 LDS per 16 bases, 7 lockstep steps per hit
-// (profiles/r02: 365 VALU + 68 LDS wave-instructions per 64 hits, 0.49 of the HBM peak by counter bytes).  The filter
-// only needs an UPPER bound of every walk, and the pair score is bounded by a function of (target code XOR query code) alone:
+// A filter that fetches the target per hit is priced in random 128-byte lines: one per hit, ~57 G lines/s on the whole chip
+// (tools/micro/gather_bw.hip) -- 173 M hits of a call cannot take less than ~3 ms however little arithmetic they need.  With
+// 288 GB of HBM the neighbourhood table (probe.hip) carries, next to every seed position, the 2-bit target bases the filter looks
+// at: 48 to the right of the anchor and 64 to the left (CtxRec, 32 bytes).  The hits of a call are then ONE SEQUENTIAL STREAM of
+// records, the query windows of a wave's 64 hits are a couple of L1-resident lines, and the filter is an arithmetic kernel: every
+// hit costs the same, a wave walks its contiguous range of 64-hit buffers in lockstep, straight-line code.
+// The round-2 form of this kernel scored two bases per LDS lookup with exact pair scores: ~39 VALU + 8 LDS per 16 bases, 365 VALU
+// + 68 LDS wave-instructions per 64 hits, bound by instruction issue (profiles/r02).  The filter only needs an UPPER bound of
+// every walk, and the pair score is bounded by a function of (target code XOR query code) alone:
 //     x = t ^ q :  0 = same base,  2 = transition (A<->G, C<->T),  1 / 3 = the two transversion classes,
 //     cls[x] = max of the matrix entries of that class (engine.hip class_scores(): for HOXD70 100 / -114 / -31 / -123 against
 //     the exact 91..100 / -114 / -31 / -123..-125 -- the drift of a random walk is -42.0 instead of -43.4 per base).
 // With target AND query at 2 bits per base one XOR per 16 bases yields the class string, and a 12-bit field of it -- SIX bases
-// -- indexes a 4096-entry table {sum of the six scores, maximum prefix sum}: 19 lookups per hit instead of 56, no byte permutes.
-// The walk is kept as (T, D): T = running score, D = best - T (the current drop):
-//     D = max(D, e.mx) - e.sum;  T += e.sum;  dropped |= D > xdrop          (4 VALU + 1 ds_read_b64 per six bases)
-// The drop test is looked at after every field; a side that has dropped is NOT frozen -- it walks on to the end of its context,
-// which can only raise its best score (still an upper bound, and the wave runs straight-line code: all 19 table reads of a
-// buffer are independent of the scores and are issued up front).  Why the bound holds: with u_i >= s_i pointwise the bounded
-// walk's drop max_i<=k(Q_i) - Q_k never exceeds the exact walk's, so it cannot stop earlier, and its best is taken over a
-// superset of positions.  Codes >= 4 (soft-masked, N, separators, other IUPAC letters) are stored as code 0 on both sides;
-// cls[] covers every matrix entry such a pair could have had, for the codes that occur in the two blocks (engine.hip).
-// Verdicts are those of 1c; a hit whose bound passes with both sides settled is sent to the second level as "walk both sides"
-// (flags 3), so the exact pair scoring of 1b gets a say before the hit becomes a candidate of the exact stage.
-// Records: Ctx28 (kernels.h) -- the stream is 28 bytes per hit; the seed position lives in a side array that only forwarded
-// hits (~4 %) and the repeat masker's window test read.
+// -- indexes a 4096-entry table: 19 lookups per hit instead of 56, no byte permutes.
+// The walk is kept as (T, D): T = running score, D = best - T (the current drop):  D = max(D, mx) - sum;  T += sum, with
+// (T, D) in ONE register P = T * 65536 + D:
+//     P = pk_max_i16(P, {INT16_MIN : mx}) + sum * 65535;   W = pk_max_i16(W, P)      (3 VALU + 1 ds_read_b64 per six bases)
+// (the integer identity (T + sum) * 65536 + (max(D, mx) - sum) = Pmax + sum * 65535 keeps both halves exact; |T| and D stay far
+// below 2^15: class scores are clamped to >= -255.)  W's low half is the largest drop seen at a field end; the drop test
+// (:374 / :523) is looked at once per side on it.  A side that has dropped is NOT frozen -- it walks on to the end of its context,
+// which can only raise its best score (still an upper bound), and all 19 table reads of a buffer are independent of the scores.
+// Why the bound holds: with u_i >= s_i pointwise the bounded walk's drop max_i<=k(Q_i) - Q_k never exceeds the exact walk's, so it
+// cannot stop earlier, and its best is taken over a superset of positions.  Codes >= 4 (soft-masked, N, separators, other IUPAC
+// letters) are stored as code 0 on both sides; cls[] covers every matrix entry such a pair could have had, for the codes that
+// occur in the two blocks (engine.hip).
+// Verdicts (all conservative):
+//   both sides dropped inside the context and bestR + bestL cannot pass (:608-633)   -> rejected here (~96 % of all hits)
+//   a side still alive at the end of its context (1.8 % right, 2.5 % left on random hits), or the bound passes
+//        -> L2Rec (kernels.h) to the second level: kernel 1b on that list (SRC_CAND), which walks only what is still open with exact
+//           pair scores and decides between reject and the exact kernels.
+constexpr int CTX_THREADS = 1024;      // two workgroups per CU = 8 waves per SIMD; the class table is built once per 16 waves
+constexpr int CTX_THREADS_MAX = 1024;  // (ExtendArgs::ctx_threads, option ctx_threads, overrides the default per launch)
+constexpr int CTX_STAGE_FLUSH = 32;                    // forwards are rare (~4 % of the hits): flush early, keep the stage small
+constexpr int CTX_STAGE_CAP = CTX_STAGE_FLUSH - 1 + 64 + 1;  // 96 records of 20 bytes per wave
 constexpr int CLS_TAB = 4096;                       // 12-bit fields: six bases
 constexpr int CLS_TAIL = 256;                       // the left context ends with a four-base field (64 = 10 x 6 + 4)
 constexpr int CLS_LDS_DWORDS = 2 * (CLS_TAB + CLS_TAIL);
@@ -882,8 +892,8 @@ __device__ __forceinline__ void cls_table_init(uint32_t* __restrict__ s_cls, con
             sum += x == 0 ? c0 : x == 1 ? c1 : x == 2 ? c2 : c3;
             mx = max(mx, sum);
         }
-        s_cls[2 * i] = (uint32_t)sum;
-        s_cls[2 * i + 1] = (uint32_t)mx;
+        s_cls[2 * i] = (uint32_t)(sum * 65535);                  // the step's addend (see above)
+        s_cls[2 * i + 1] = 0x80000000u | (uint32_t)max(mx, 0);   // {INT16_MIN : max prefix}; a negative prefix never raises D
     }
 }
 
@@ -901,15 +911,17 @@ __device__ __forceinline__ uint32_t mul24(uint32_t x, uint32_t s_uniform) {  // 
     return r;
 }
 
-__device__ __forceinline__ void cls_step(const uint32_t* __restrict__ s_tab, uint32_t addr, int xdrop, int& T, int& D, bool& dropped) {
-    const uint2 e = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(s_tab) + addr);  // one ds_read_b64
-    D = max(D, (int)e.y) - (int)e.x;
-    T += (int)e.x;
-    dropped = dropped || (D > xdrop);  // :374 / :523, looked at every six bases
+typedef short cls_s16x2 __attribute__((ext_vector_type(2)));
+// one field: P = {T : D} packed, W = running maximum of P's halves (its low half: the largest drop seen at a field end)
+__device__ __forceinline__ void cls_step(const uint32_t* __restrict__ s_tab, uint32_t addr, uint32_t& P, uint32_t& W) {
+    const uint64_t e64 = *reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(s_tab) + addr);  // one ds_read_b64 (entries are 8-byte aligned)
+    const uint32_t add = (uint32_t)e64, mxw = (uint32_t)(e64 >> 32);
+    P = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(cls_s16x2, P), __builtin_bit_cast(cls_s16x2, mxw))) + add;
+    W = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(cls_s16x2, W), __builtin_bit_cast(cls_s16x2, P)));
 }
 
 __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(ExtendArgs a) {
-    __shared__ uint32_t s_cls[CLS_LDS_DWORDS];  // {sum, max prefix} of every 6-base class field (32 KB) + the 4-base tail fields (2 KB)
+    __shared__ __attribute__((aligned(16))) uint32_t s_cls[CLS_LDS_DWORDS];  // 8-byte entry per 6-base class field (32 KB) + the 4-base tail fields (2 KB)
     extern __shared__ L2Rec s_l2_dyn[];          // [waves of the workgroup][CTX_STAGE_CAP]
     cls_table_init(s_cls, a.cls, (int)blockDim.x);
     __syncthreads();
@@ -919,9 +931,10 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(E
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     const int xdrop = a.xdrop;
-    const uint32_t* __restrict__ ctx = reinterpret_cast<const uint32_t*>(a.td_ctx28);
+    const uint4* __restrict__ ctx = reinterpret_cast<const uint4*>(a.td_ctx);
 
-    // a wave takes a contiguous range of TD_CHUNK_HITS-hit chunks (64 buffers each), exactly like 1c
+    // a wave takes a contiguous range of TD_CHUNK_HITS-hit chunks (64 buffers each); the record that holds a chunk's first hit
+    // was noted by the probe (td_chunk), so no wave has to search for its starting point
     const uint64_t num_buf = (a.num_hits + 63) >> 6;
     const uint64_t n_chunks = (a.num_hits + TD_CHUNK_HITS - 1) / TD_CHUNK_HITS;
     const uint64_t W = (uint64_t)gridDim.x * (blockDim.x >> 6);
@@ -930,19 +943,22 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(E
     const uint64_t b_lo = c_lo * (TD_CHUNK_HITS / 64);
     const uint64_t b_hi = min(c_hi * (TD_CHUNK_HITS / 64), num_buf);
     if (b_lo >= b_hi) return;
-    const uint32_t my_sub = (uint32_t)wid & (uint32_t)(L2_NSUB - 1);
+    const uint32_t my_sub = (uint32_t)wid & (uint32_t)(L2_NSUB - 1);  // this wave's sub-list of the second-level list
     L2Rec* __restrict__ my_list = a.l2_list + (size_t)my_sub * a.l2_cap;
     uint32_t* __restrict__ my_count = a.l2_count + my_sub * L2_CNT_STRIDE;
     // Which record (query position) does hit g belong to?  The probe left a HEAD-BIT map of the call's hits (bit g set <=> a
     // record starts at hit g), so the record index of hit g is (number of head bits in [0, g]) - 1: per 64-hit buffer ONE 64-bit
-    // word (a scalar load), a running scalar count and two v_mbcnt -- no search, no shuffles (the TdCursor of 1b / 1c spends six
-    // ds_bpermute + ~40 VALU per buffer on the same question).  td_chunk gives the count at the wave's first hit.
-    // The map is read through the constant address space: a wave-uniform address there is a SCALAR load (s_load_dwordx2), which
-    // costs no VALU slot and no vector-memory slot.  The loop runs two buffers ahead on the map and one ahead on the TdRec gather,
-    // so the only latency a wave waits for inside an iteration is its own record stream.
+    // word, a running scalar count and two v_mbcnt -- no search, no shuffles (the TdCursor of 1b spends six ds_bpermute + ~40
+    // VALU per buffer on the same question).  td_chunk gives the count at the wave's first hit.  The map is read through the
+    // constant address space: a wave-uniform address there is a SCALAR load (s_load_dwordx2), no VALU or vector-memory slot.
+    // Latency: the head word is fetched three buffers ahead and the TdRec gather one buffer ahead, so inside an iteration a wave
+    // only waits for its own record stream, which the other seven waves of the SIMD cover.  (Requesting the records one buffer
+    // ahead as well -- two register sets, 55 VGPRs -- measured 4 % SLOWER: the kernel is bound by VALU issue, not by bytes in
+    // flight; profiles/r03.)  Requests past the wave's range read valid memory (the next wave's buffers, the map's zero words, a
+    // page of slack behind the table) and are never used -- conditional loads would turn every s_waitcnt of the loop into a drain.
     typedef const uint64_t __attribute__((address_space(4))) * HeadPtr;
     HeadPtr head = (HeadPtr)a.td_bits;
-    const uint32_t stride16 = (uint32_t)(a.q2_stride >> 4) & 0xFFFFFFu;  // (the engine keeps copy strides below 2^28 bytes)
+    const uint32_t stride16 = (uint32_t)(a.q2_stride >> 4) & 0xFFFFFFu;  // (the sixteen copies of a strand stay below 4 GB, engine.hip)
     uint32_t cbefore;  // head bits in [0, first hit of the next buffer to be located)
     auto locate = [&](uint64_t B) -> uint32_t {  // record index of hit (buffer start + lane), advances cbefore
         const uint64_t Bs = B >> 1;              // bits 1..lane of B = the bits below `lane` of Bs
@@ -950,15 +966,9 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(E
         cbefore += (uint32_t)__builtin_popcountll(B);
         return idx;
     };
-    // Latency: the head word is fetched three buffers ahead and the TdRec gather one buffer ahead, so inside an iteration a wave
-    // only waits for its own record stream, which the other seven waves of the SIMD cover.  (Requesting the records one buffer
-    // ahead as well -- two register sets, 55 VGPRs -- measured 4 % SLOWER: the kernel is bound by VALU issue, 77 % busy, not by
-    // bytes in flight; profiles/r03.)  Requests past the wave's range read valid memory (the next wave's buffers, the map's zero
-    // words, record 0) and are never used -- conditional loads would turn every s_waitcnt of the loop into a full drain.
     struct Stage {
-        uint4 tl, ql;
-        uint32_t tr0, tr1, tr2, qr0, qr1, qr2;
-        uint64_t entry;
+        uint4 c0, tl, ql;  // c0 = {seed position, right context}, tl = left context (CtxRec); ql = the query's left window
+        uint32_t qr0, qr1, qr2;
         uint32_t query_loc;
     };
     uint64_t B2, B3;  // head words of the buffers one and two ahead of the one being requested
@@ -969,90 +979,92 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(E
         B3 = head[b_req + 3];
     };
     auto request = [&](uint64_t b, Stage& S) {  // uses hnext = record of buffer b
-        const bool valid = (b << 6) + (uint64_t)lane < a.num_hits;
-        uint64_t entry = hnext.off + (uint64_t)((uint32_t)(b << 6) + (uint32_t)lane - hnext.prefix);  // run offset + index inside the run
-        if (!valid) entry = 0;  // (lanes past the call's last hit: any readable record, the verdict is discarded)
-        S.entry = entry;
-        // 7 dwords per record as shift + subtract (a 64-bit multiply is two quarter-rate v_mad_u64_u32; the asm keeps the
-        // compiler from folding the pair back into one)
-        uint64_t e8;
-        asm("v_lshlrev_b64 %0, 3, %1" : "=v"(e8) : "v"(entry));
-        const uint32_t* rec = ctx + (e8 - entry);
-        __builtin_memcpy(&S.tl, rec, 16);
-        uint3 t;
-        __builtin_memcpy(&t, rec + 4, 12);
-        S.tr0 = t.x; S.tr1 = t.y; S.tr2 = t.z;
-        const uint32_t query_loc = valid ? hnext.qpos + a.seed_size : a.seed_size;  // :204
+        // (lanes past the call's last hit stay on the last record and run up to 63 entries past its run: still inside the table
+        //  allocation -- the engine keeps a page of slack behind it -- and their verdict is discarded)
+        const uint64_t entry = hnext.off + (uint64_t)((uint32_t)(b << 6) + (uint32_t)lane - hnext.prefix);  // run offset + index inside the run
+        S.c0 = ctx[2 * entry];  // two aligned 16-byte loads: the stream of the kernel
+        S.tl = ctx[2 * entry + 1];
+        const uint32_t query_loc = hnext.qpos + a.seed_size;  // :204
         S.query_loc = query_loc;
-        // copy (pos & 3, (pos >> 2) & 3) = copy number pos & 15, dword pos >> 4 (encode.hip); strides are multiples of 16 bytes
-        const uint8_t* p = a.q2_own + ((uint64_t)mul24(query_loc & 15u, stride16) << 4) + (size_t)((query_loc >> 4) << 2);
-        __builtin_memcpy(&t, __builtin_assume_aligned(p, 4), 12);
+        // copy (pos & 3, (pos >> 2) & 3) = copy number pos & 15, dword pos >> 4 (encode.hip); strides are multiples of 16 bytes, so
+        // the offset is ONE 32-bit value next to a scalar base
+        const uint32_t po = (mul24(query_loc & 15u, stride16) << 4) + ((query_loc >> 4) << 2);
+        uint3 t;
+        __builtin_memcpy(&t, __builtin_assume_aligned(a.q2_own + po, 4), 12);
         S.qr0 = t.x; S.qr1 = t.y; S.qr2 = t.z;
-        const uint32_t lp = a.query_len - query_loc;  // the left walk = the other strand's forward window at len - anchor (Ctx28)
-        const uint8_t* q = a.q2_other + ((uint64_t)mul24(lp & 15u, stride16) << 4) + (size_t)((lp >> 4) << 2);
-        __builtin_memcpy(&S.ql, __builtin_assume_aligned(q, 4), 16);
+        const uint32_t lp = a.query_len - query_loc;  // the left walk = the other strand's forward window at len - anchor (CtxRec)
+        const uint32_t qo = (mul24(lp & 15u, stride16) << 4) + ((lp >> 4) << 2);
+        __builtin_memcpy(&S.ql, __builtin_assume_aligned(a.q2_other + qo, 4), 16);
     };
     auto score = [&](uint64_t b, const Stage& S) {
         const bool valid = (b << 6) + (uint64_t)lane < a.num_hits;
-        const uint64_t entry = S.entry;
         const uint32_t query_loc = S.query_loc;
-        uint32_t ref_pos = 0;
+        const uint32_t ref_loc = S.c0.x + a.seed_size;  // :220
         bool skip = !valid;
-        if (a.rm) {  // rm :239-244,:305-333: hits outside the window are not extended, total stays 0
-            ref_pos = a.td_pos[entry];
-            const uint32_t ref_loc = ref_pos + a.seed_size;
-            skip = skip || !(ref_loc >= a.rm_win_start && ref_loc <= a.rm_win_end);
-        }
+        if (a.rm) skip = skip || !(ref_loc >= a.rm_win_start && ref_loc <= a.rm_win_end);  // rm :239-244,:305-333: total stays 0
         // ---- class strings ----
-        const uint32_t x0 = S.tr0 ^ S.qr0, x1 = S.tr1 ^ S.qr1, x2 = S.tr2 ^ S.qr2;
+        const uint32_t x0 = S.c0.y ^ S.qr0, x1 = S.c0.z ^ S.qr1, x2 = S.c0.w ^ S.qr2;
         const uint32_t y0 = S.tl.x ^ S.ql.x, y1 = S.tl.y ^ S.ql.y, y2 = S.tl.z ^ S.ql.z, y3 = S.tl.w ^ S.ql.w;
         // ---- right side (:326-453): 48 bases = 8 fields ----
-        int T = 0, D = 0;
-        bool dropped = false;
-        cls_step(s_cls, cls_field_addr<0>(x0, x1), xdrop, T, D, dropped);
-        cls_step(s_cls, cls_field_addr<12>(x0, x1), xdrop, T, D, dropped);
-        cls_step(s_cls, cls_field_addr<24>(x0, x1), xdrop, T, D, dropped);
-        cls_step(s_cls, cls_field_addr<4>(x1, x2), xdrop, T, D, dropped);
-        cls_step(s_cls, cls_field_addr<16>(x1, x2), xdrop, T, D, dropped);
-        cls_step(s_cls, cls_field_addr<28>(x1, x2), xdrop, T, D, dropped);
-        cls_step(s_cls, cls_field_addr<8>(x2, 0u), xdrop, T, D, dropped);
-        cls_step(s_cls, cls_field_addr<20>(x2, 0u), xdrop, T, D, dropped);
-        const bool r_alive = !dropped;
-        const int bestR = T + D;
+        uint32_t P = 0, Wd = 0;
+        cls_step(s_cls, cls_field_addr<0>(x0, x1), P, Wd);
+        cls_step(s_cls, cls_field_addr<12>(x0, x1), P, Wd);
+        cls_step(s_cls, cls_field_addr<24>(x0, x1), P, Wd);
+        cls_step(s_cls, cls_field_addr<4>(x1, x2), P, Wd);
+        cls_step(s_cls, cls_field_addr<16>(x1, x2), P, Wd);
+        cls_step(s_cls, cls_field_addr<28>(x1, x2), P, Wd);
+        cls_step(s_cls, cls_field_addr<8>(x2, 0u), P, Wd);
+        cls_step(s_cls, cls_field_addr<20>(x2, 0u), P, Wd);
+        const bool r_alive = (int)(Wd & 0xFFFFu) <= xdrop;       // never dropped at a field end (:374)
+        const int bestR = ((int)P >> 16) + (int)(P & 0xFFFFu);  // T + D
         // ---- left side (:478-604): 64 bases = 10 fields + a four-base tail ----
-        T = 0; D = 0; dropped = false;
-        cls_step(s_cls, cls_field_addr<0>(y0, y1), xdrop, T, D, dropped);
-        cls_step(s_cls, cls_field_addr<12>(y0, y1), xdrop, T, D, dropped);
-        cls_step(s_cls, cls_field_addr<24>(y0, y1), xdrop, T, D, dropped);
-        cls_step(s_cls, cls_field_addr<4>(y1, y2), xdrop, T, D, dropped);
-        cls_step(s_cls, cls_field_addr<16>(y1, y2), xdrop, T, D, dropped);
-        cls_step(s_cls, cls_field_addr<28>(y1, y2), xdrop, T, D, dropped);
-        cls_step(s_cls, cls_field_addr<8>(y2, y3), xdrop, T, D, dropped);
-        cls_step(s_cls, cls_field_addr<20>(y2, y3), xdrop, T, D, dropped);
-        cls_step(s_cls, cls_field_addr<0>(y3, 0u), xdrop, T, D, dropped);
-        cls_step(s_cls, cls_field_addr<12>(y3, 0u), xdrop, T, D, dropped);
-        cls_step(s_tail, (y3 >> 21) & 0x7F8u, xdrop, T, D, dropped);
-        const bool l_alive = !dropped;
-        const int bestL = T + D;
+        P = 0; Wd = 0;
+        cls_step(s_cls, cls_field_addr<0>(y0, y1), P, Wd);
+        cls_step(s_cls, cls_field_addr<12>(y0, y1), P, Wd);
+        cls_step(s_cls, cls_field_addr<24>(y0, y1), P, Wd);
+        cls_step(s_cls, cls_field_addr<4>(y1, y2), P, Wd);
+        cls_step(s_cls, cls_field_addr<16>(y1, y2), P, Wd);
+        cls_step(s_cls, cls_field_addr<28>(y1, y2), P, Wd);
+        cls_step(s_cls, cls_field_addr<8>(y2, y3), P, Wd);
+        cls_step(s_cls, cls_field_addr<20>(y2, y3), P, Wd);
+        cls_step(s_cls, cls_field_addr<0>(y3, 0u), P, Wd);
+        cls_step(s_cls, cls_field_addr<12>(y3, 0u), P, Wd);
+        cls_step(s_tail, (y3 >> 21) & 0x7F8u, P, Wd);
+        const bool l_alive = (int)(Wd & 0xFFFFu) <= xdrop;       // (:523)
+        const int bestL = ((int)P >> 16) + (int)(P & 0xFFFFu);
         const bool fwd = !skip && (r_alive || l_alive || classify(a, bestR + bestL) != 0);
-        if (__ballot(fwd)) {
-            if (!a.rm && fwd) ref_pos = a.td_pos[entry];
-            L2Rec cr;  // what is known travels with the anchor (kernels.h): level 2 walks only what is still open
-            cr.ref_loc = ref_pos + a.seed_size;  // :220
+        // what is known travels with the anchor (kernels.h L2Rec): level 2 walks only what is still open
+        const unsigned long long fm = __ballot(fwd);
+        if (fm) {
+            L2Rec cr;
+            cr.ref_loc = ref_loc;
             cr.query_loc = query_loc;
             cr.hidx = (uint32_t)(b << 6) + (uint32_t)lane;
-            const uint32_t fl = (r_alive ? 1u : 0u) | (l_alive ? 2u : 0u);
-            cr.flags = fl ? fl : 3u;             // both settled but the bound passes: level 2 re-walks both sides with exact pair scores
-            cr.known = r_alive ? bestL : bestR;  // flags 1: bestL; flags 2: bestR
-            cr.tm = (l_alive && !r_alive) ? (((uint32_t)T & 0xFFFFu) | ((uint32_t)bestL << 16)) : (uint32_t)bestL;  // flags 2: left walk state
-            stage_append<CTX_STAGE_FLUSH>(stage, n_stage, fwd, cr, my_list, my_count, a.l2_cap, lane, lane_lt);
+            cr.state = P;  // (the left walk's packed state: used when only the left side is open)
+            const uint32_t fl = (r_alive ? 1u : 0u) | (l_alive ? 2u : 0u);  // 0 (both settled, the bound passes) -> 3: level 2 re-walks both
+            cr.meta = (uint32_t)(r_alive ? bestL : bestR) | ((fl ? fl : 3u) << 16);
+            // -> the wave's LDS stage (rank by v_mbcnt on the ballot), flushed 64 records at a time
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+            if (fwd) stage[n_stage + (int)rank] = cr;
+            n_stage += __popcll(fm);
+            __builtin_amdgcn_wave_barrier();
+            if (n_stage >= CTX_STAGE_FLUSH) {
+                const int k = n_stage < 64 ? n_stage : 64;
+                stage_flush(stage, k, my_list, my_count, a.l2_cap, lane);
+                const int rest = n_stage - k;
+                L2Rec tmp = cr;
+                if (lane < rest) tmp = stage[k + lane];
+                __builtin_amdgcn_wave_barrier();
+                if (lane < rest) stage[lane] = tmp;
+                __builtin_amdgcn_wave_barrier();
+                n_stage = rest;
+            }
         }
         if (a.audit_list) {  // (tests) the hits this level rejects
-            const bool rej = valid && !skip && !fwd;
             uint2 ar;
-            ar.x = (rej ? a.td_pos[entry] : 0u) + a.seed_size;
+            ar.x = ref_loc;
             ar.y = query_loc;
-            wave_append(rej, ar, a.audit_list, a.audit_count, a.audit_cap, lane, lane_lt);
+            wave_append(valid && !skip && !fwd, ar, a.audit_list, a.audit_count, a.audit_cap, lane, lane_lt);
         }
     };
     {

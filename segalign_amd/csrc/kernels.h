@@ -42,20 +42,19 @@ struct CandRec {              // a hit the X-drop filter could not reject: exten
     uint32_t hidx;            // index of the hit inside the launch (for the segment id)
 };
 
-// What the context filter hands to the second level: the anchor plus what level 1 already knows, so that level 2 walks only
-// the side(s) that were still alive at the end of the 48 + 64 context bases.
-//   flags bit 0: right side undecided, bit 1: left side undecided
-//   flags 0 (both sides dropped inside the context, the bound passes): known = bestR, tm = bestL -- nothing left to walk
-//   flags 1: known = bestL (the left side is settled), the right side is walked from the anchor
-//   flags 2: known = bestR, tm = running score (low 16 bits) | best score (high 16 bits) of the left walk after 64 bases,
-//            which level 2 continues from there
-//   flags 3: both sides from the anchor
+// What the class filter (level 1) hands to the second level: the anchor plus what level 1 already knows, so that level 2 walks only
+// the side(s) that were still alive at the end of the 48 + 64 context bases.  20 bytes:
+//   state: the packed (score : drop) register of level 1's LEFT walk after 64 bases (extend.hip cls_table_init)
+//   meta : known (16 bits) | flags (2 bits) << 16
+//     flags bit 0: right side undecided, bit 1: left side undecided
+//     flags 1: known = bestL (the left side is settled), the right side is walked from the anchor
+//     flags 2: known = bestR, the left walk continues after 64 bases from `state`
+//     flags 3: both sides from the anchor (also: both settled but the bound passes -- the exact pair scores of level 2 get a say)
 struct L2Rec {
     uint32_t ref_loc, query_loc;
     uint32_t hidx;
-    int32_t known;
-    uint32_t tm;
-    uint32_t flags;
+    uint32_t state;
+    uint32_t meta;
 };
 
 constexpr int L2_NSUB = 256;        // sub-lists of the second-level list
@@ -77,16 +76,19 @@ struct TdRec {                // table-direct lookup (probe.hip): a non-empty qu
     uint64_t off;             // offset of the position's run in the neighbourhood table
 };
 
-// Neighbourhood table WITH target context (probe.hip; class filter, extend.hip 1d): 28 bytes of 2-bit target bases per run entry,
-// so the X-drop filter never touches the target; the seed position lives in a side array (td_pos).  The
-// left context is stored in WALKING order with whole 2-bit fields reversed and COMPLEMENTED -- the reverse of a strand is the
-// complement of its reverse-complement strand, so l ^ (the other query strand's forward window) is the per-base XOR of target
-// and query in walking order without any query-side reversal.
-struct Ctx28 {
-    uint32_t l[4];            // ~(64 bases left of the anchor, base anchor-1-k in bits 2k..2k+1 of the 128-bit string)
+// Neighbourhood table WITH target context (probe.hip; class filter, extend.hip 1d): every run entry carries, next to its seed
+// position, 28 bytes of 2-bit target bases -- the X-drop filter never touches the target.  The left context is stored in WALKING
+// order with whole 2-bit fields reversed and COMPLEMENTED -- the reverse of a strand is the complement of its reverse-complement
+// strand, so l ^ (the other query strand's forward window) is the per-base XOR of target and query in walking order without
+// any query-side reversal.  32 bytes, 16-byte aligned: two aligned 16-byte loads per hit and a shift for the address (a 28-byte
+// record with the position in a side array was measured: its 64-bit multiply-by-28 and the extra gather for the ~4 % of
+// forwarded hits cost more VALU issue and wait time than the 4 bytes save in a kernel that is not bound by bytes).
+struct CtxRec {
+    uint32_t pos;             // seed START position in the target (+ seed_size = anchor)
     uint32_t r[3];            // 48 bases right of the anchor (anchor+k in bits 2k..2k+1 of the 96-bit string)
+    uint32_t l[4];            // ~(64 bases left of the anchor, base anchor-1-k in bits 2k..2k+1 of the 128-bit string)
 };
-static_assert(sizeof(Ctx28) == 28, "Ctx28 is a packed 28-byte record");
+static_assert(sizeof(CtxRec) == 32, "CtxRec is a 32-byte record");
 
 constexpr int Q2_COPIES = 16;  // 2-bit query copies per strand: 4 base phases x 4 byte shifts (encode.hip)
 constexpr int Q2_TAIL = 32;    // zero bytes a window may read past the last base of a copy
@@ -135,9 +137,9 @@ struct ExtendArgs {
     const TdRec* td_rec;        // [td_m + 1] one record per NON-EMPTY query position, in query order; td_rec[td_m].prefix = num_hits
     uint32_t td_m;
     const uint32_t* td_pos;     // neighbourhood table runs: seed START positions in the target (+ seed_size = anchor, :220)
-    // class filter (extend.hip 1d), != null: the runs carry their target context as 28-byte records, td_pos is the side array of
-    // seed positions; the 2-bit shifted copies of this call's query strand (right windows) and of the OTHER strand (left windows)
-    const Ctx28* td_ctx28;
+    // class filter (extend.hip 1d), != null: the runs carry their target context (then td_pos is unused); the 2-bit shifted
+    // copies of this call's query strand (right windows) and of the OTHER strand (left windows)
+    const CtxRec* td_ctx;
     const uint64_t* td_bits;    // head-bit map of the call's hits (probe.hip): bit g set <=> a record (query position) starts at hit g
     const uint8_t* q2_own;
     const uint8_t* q2_other;

@@ -35,11 +35,11 @@ void launch_nbr_count(const uint32_t* bucket_start, uint32_t nkeys, uint32_t tma
 void launch_nbr_fill(const uint32_t* bucket_start, const uint32_t* pos_table, uint32_t nkeys, uint32_t tmask, int weight,
                      const uint64_t* nbr_start, uint32_t* nbr_pos, hipStream_t s);
 
-// the table as 28-byte context records (Ctx28) + the side array of seed positions; scratch: room for num_index records (nullptr:
-// every entry cuts its context out of the target itself)
-void launch_nbr_fill_ctx28(const uint32_t* bucket_start, const uint32_t* pos_table, uint32_t nkeys, uint32_t tmask, int weight,
-                           const uint64_t* nbr_start, const uint8_t* ref2, size_t ref2_stride, uint32_t seed_size, Ctx28* ctx,
-                           uint32_t* nbr_pos, Ctx28* scratch, uint32_t num_index, hipStream_t s);
+// the table as context records (kernels.h CtxRec); scratch: room for num_index records (nullptr: every entry cuts its context out
+// of the target itself)
+void launch_nbr_fill_ctx(const uint32_t* bucket_start, const uint32_t* pos_table, uint32_t nkeys, uint32_t tmask, int weight,
+                         const uint64_t* nbr_start, const uint8_t* ref2, size_t ref2_stride, uint32_t seed_size, CtxRec* ctx,
+                         CtxRec* scratch, uint32_t num_index, hipStream_t s);
 
 // position probe of n = end - start query positions; t_off/t_cnt: n entries of scratch; c_rec: n + 1 records
 size_t probe_partial_bytes(uint32_t n);

@@ -68,45 +68,42 @@ __global__ __launch_bounds__(256) void nbr_fill_kernel(const uint32_t* __restric
     }
 }
 
-// ---- 28-byte records + side array of positions (class filter, extend.hip 1d) ------------------------------------------------
+// ---- context records (class filter, extend.hip 1d): kernels.h CtxRec --------------------------------------------------------
 // reverse the sixteen 2-bit fields of a dword (bit reversal also swaps the two bits of every field: swap them back)
 __device__ __forceinline__ uint32_t fieldrev16(uint32_t v) {
     const uint32_t r = __builtin_bitreverse32(v);
     return ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
 }
-__device__ __forceinline__ void cut_ctx28(const uint8_t* __restrict__ ref2, size_t ref2_stride, uint32_t anchor, uint32_t out[7]) {
+// the anchor's [-64, +64) bases are 32 contiguous bytes of ONE overlapped line of copy `anchor & 3` of the 2-bit target (encode.hip)
+__device__ __forceinline__ void cut_ctx(const uint8_t* __restrict__ ref2, size_t ref2_stride, uint32_t pos, uint32_t seed_size, uint4& c0, uint4& c1) {
+    const uint32_t anchor = pos + seed_size;                    // :220
     const uint32_t jj0 = (anchor >> 2) + (uint32_t)PACK2_BIAS;  // logical byte of the anchor's 4-base group in copy anchor & 3
     const uint32_t line = (jj0 - 16u) / (uint32_t)PACK2_PAYLOAD;
     const uint8_t* tp = ref2 + (size_t)(anchor & 3u) * ref2_stride + (jj0 + 32u * line);
     const uint4 rw = load16u(tp), lw = load16u(tp - 16);
-    out[0] = ~fieldrev16(lw.w);  // bases anchor-1 .. anchor-16, walking order, complemented (Ctx28)
-    out[1] = ~fieldrev16(lw.z);
-    out[2] = ~fieldrev16(lw.y);
-    out[3] = ~fieldrev16(lw.x);
-    out[4] = rw.x;
-    out[5] = rw.y;
-    out[6] = rw.z;
+    c0 = make_uint4(pos, rw.x, rw.y, rw.z);
+    // bases anchor-1 .. anchor-64 in walking order, complemented (CtxRec)
+    c1 = make_uint4(~fieldrev16(lw.w), ~fieldrev16(lw.z), ~fieldrev16(lw.y), ~fieldrev16(lw.x));
 }
 // stage 1: the context of every seed position ONCE, in pos_table order (one random target line per position)
-__global__ __launch_bounds__(256) void ctx28_by_index_kernel(const uint32_t* __restrict__ pos_table, uint32_t num_index,
-                                                             const uint8_t* __restrict__ ref2, size_t ref2_stride, uint32_t seed_size,
-                                                             uint32_t* __restrict__ out /* 7 dwords per position */) {
+__global__ __launch_bounds__(256) void ctx_by_index_kernel(const uint32_t* __restrict__ pos_table, uint32_t num_index,
+                                                           const uint8_t* __restrict__ ref2, size_t ref2_stride, uint32_t seed_size,
+                                                           uint4* __restrict__ out /* 2 x uint4 per position */) {
     for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < num_index; id += gridDim.x * blockDim.x) {
-        uint32_t r[7];
-        cut_ctx28(ref2, ref2_stride, pos_table[id] + seed_size, r);  // anchor (:220)
-#pragma unroll
-        for (int j = 0; j < 7; j++) out[(size_t)id * 7 + j] = r[j];
+        uint4 c0, c1;
+        cut_ctx(ref2, ref2_stride, pos_table[id], seed_size, c0, c1);
+        out[2 * (size_t)id] = c0;
+        out[2 * (size_t)id + 1] = c1;
     }
 }
 // stage 2: one WAVE per key, one lane per run ENTRY.  The lanes 0..weight hold the key's source buckets {start, length}, a wave
-// prefix gives every piece its offset inside the run, and entry t of the run finds its piece with a few shuffles; it then moves
-// its whole 28-byte record (16 + 12 byte load / store) and its position.  Consecutive lanes read consecutive records of a piece
-// and write consecutive records of the run: both sides are coalesced, 64 entries per wave instruction (the 16-lane-per-key,
-// dword-per-lane form of the first version ran at 1.3 TB/s of the ~68 GB this kernel moves per 100 Mbp block).
-__global__ __launch_bounds__(256) void nbr_copy28_kernel(const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ pos_table,
-                                                         uint32_t nkeys, uint32_t tmask, int weight, const uint64_t* __restrict__ nbr_start,
-                                                         const uint32_t* __restrict__ by_index, uint32_t* __restrict__ ctx,
-                                                         uint32_t* __restrict__ nbr_pos) {
+// prefix gives every piece its offset inside the run, and entry t of the run finds its piece from scalar broadcasts; it then moves
+// its whole 32-byte record (two aligned 16-byte loads / stores).  Consecutive lanes read consecutive records of a piece and write
+// consecutive records of the run: both sides are coalesced, 64 entries per wave instruction (the 16-lane-per-key, dword-per-lane
+// form of the first version ran at 1.3 TB/s of the ~68 GB this kernel moves per 100 Mbp block).
+__global__ __launch_bounds__(256) void nbr_copy_ctx_kernel(const uint32_t* __restrict__ bucket_start, uint32_t nkeys, uint32_t tmask, int weight,
+                                                           const uint64_t* __restrict__ nbr_start, const uint4* __restrict__ by_index,
+                                                           uint4* __restrict__ ctx) {
     const int lane = threadIdx.x & 63;
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
     for (uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); k < nkeys; k += waves) {
@@ -140,24 +137,18 @@ __global__ __launch_bounds__(256) void nbr_copy28_kernel(const uint32_t* __restr
                 if (p <= weight && n && t >= e) src = bb + (t - e);
             }
             if (t < total) {
-                const uint32_t* sp = by_index + (size_t)src * 7;
-                uint32_t* dp = ctx + (o + t) * 7;
-                uint4 a;
-                uint3 b;
-                __builtin_memcpy(&a, sp, 16);
-                __builtin_memcpy(&b, sp + 4, 12);
-                __builtin_memcpy(dp, &a, 16);
-                __builtin_memcpy(dp + 4, &b, 12);
-                nbr_pos[o + t] = pos_table[src];
+                const uint4 a = by_index[2 * (size_t)src], b = by_index[2 * (size_t)src + 1];
+                ctx[2 * (o + t)] = a;
+                ctx[2 * (o + t) + 1] = b;
             }
         }
     }
 }
 // one-stage form (no scratch): every table entry cuts its own context out of the target
-__global__ __launch_bounds__(256) void nbr_fill28_kernel(const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ pos_table,
-                                                         uint32_t nkeys, uint32_t tmask, int weight, const uint64_t* __restrict__ nbr_start,
-                                                         const uint8_t* __restrict__ ref2, size_t ref2_stride, uint32_t seed_size,
-                                                         uint32_t* __restrict__ ctx, uint32_t* __restrict__ nbr_pos) {
+__global__ __launch_bounds__(256) void nbr_fill_ctx_kernel(const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ pos_table,
+                                                           uint32_t nkeys, uint32_t tmask, int weight, const uint64_t* __restrict__ nbr_start,
+                                                           const uint8_t* __restrict__ ref2, size_t ref2_stride, uint32_t seed_size,
+                                                           uint4* __restrict__ ctx) {
     const uint32_t gl = threadIdx.x & (NBR_GROUP - 1);
     const uint32_t groups = gridDim.x * (blockDim.x / NBR_GROUP);
     for (uint32_t k = blockIdx.x * (blockDim.x / NBR_GROUP) + threadIdx.x / NBR_GROUP; k < nkeys; k += groups) {
@@ -167,30 +158,28 @@ __global__ __launch_bounds__(256) void nbr_fill28_kernel(const uint32_t* __restr
             const uint32_t kk = j < 0 ? k : (k ^ (2u << (2 * j)));
             const uint32_t b = bucket_start[kk], n = bucket_start[kk + 1] - b;
             for (uint32_t i = gl; i < n; i += NBR_GROUP) {
-                const uint32_t p = pos_table[b + i];
-                uint32_t r[7];
-                cut_ctx28(ref2, ref2_stride, p + seed_size, r);
-#pragma unroll
-                for (int q = 0; q < 7; q++) ctx[7 * (o + i) + q] = r[q];
-                nbr_pos[o + i] = p;
+                uint4 c0, c1;
+                cut_ctx(ref2, ref2_stride, pos_table[b + i], seed_size, c0, c1);
+                ctx[2 * (o + i)] = c0;
+                ctx[2 * (o + i) + 1] = c1;
             }
             o += n;
         }
     }
 }
 
-void launch_nbr_fill_ctx28(const uint32_t* bucket_start, const uint32_t* pos_table, uint32_t nkeys, uint32_t tmask, int weight,
-                           const uint64_t* nbr_start, const uint8_t* ref2, size_t ref2_stride, uint32_t seed_size, Ctx28* ctx,
-                           uint32_t* nbr_pos, Ctx28* scratch, uint32_t num_index, hipStream_t s) {
+void launch_nbr_fill_ctx(const uint32_t* bucket_start, const uint32_t* pos_table, uint32_t nkeys, uint32_t tmask, int weight,
+                         const uint64_t* nbr_start, const uint8_t* ref2, size_t ref2_stride, uint32_t seed_size, CtxRec* ctx,
+                         CtxRec* scratch, uint32_t num_index, hipStream_t s) {
     if (scratch) {
-        hipLaunchKernelGGL(ctx28_by_index_kernel, dim3(8192), dim3(256), 0, s, pos_table, num_index, ref2, ref2_stride, seed_size,
-                           reinterpret_cast<uint32_t*>(scratch));
-        hipLaunchKernelGGL(nbr_copy28_kernel, dim3(8192), dim3(256), 0, s, bucket_start, pos_table, nkeys, tmask, weight, nbr_start,
-                           reinterpret_cast<const uint32_t*>(scratch), reinterpret_cast<uint32_t*>(ctx), nbr_pos);
+        hipLaunchKernelGGL(ctx_by_index_kernel, dim3(8192), dim3(256), 0, s, pos_table, num_index, ref2, ref2_stride, seed_size,
+                           reinterpret_cast<uint4*>(scratch));
+        hipLaunchKernelGGL(nbr_copy_ctx_kernel, dim3(8192), dim3(256), 0, s, bucket_start, nkeys, tmask, weight, nbr_start,
+                           reinterpret_cast<const uint4*>(scratch), reinterpret_cast<uint4*>(ctx));
         return;
     }
-    hipLaunchKernelGGL(nbr_fill28_kernel, dim3(8192), dim3(256), 0, s, bucket_start, pos_table, nkeys, tmask, weight, nbr_start, ref2,
-                       ref2_stride, seed_size, reinterpret_cast<uint32_t*>(ctx), nbr_pos);
+    hipLaunchKernelGGL(nbr_fill_ctx_kernel, dim3(8192), dim3(256), 0, s, bucket_start, pos_table, nkeys, tmask, weight, nbr_start, ref2,
+                       ref2_stride, seed_size, reinterpret_cast<uint4*>(ctx));
 }
 
 void launch_nbr_count(const uint32_t* bucket_start, uint32_t nkeys, uint32_t tmask, int weight, uint32_t* cnt, uint32_t* overflow,

@@ -56,9 +56,9 @@ SCOPE_KERNELS = {
     "chain_link": ["chain_link_kernel"], "extend_exact_chain": ["extend_exact_chain_kernel"],
     "extend_exact": ["extend_exact_kernel"], "extend_entropy": ["extend_entropy_kernel"], "dedup_seg": ["dedup_seg_kernel"],
 }
-# context-table calls (lookup mode 2): the filter is two kernels -- level 1, the class filter on the 28-byte context records, and
+# context-table calls (lookup mode 2): the filter is two kernels -- level 1, the class filter on the 32-byte context records, and
 # level 2 (the packed kernel) on the few hits level 1 could not decide; these are the symbols profile_check compares
-PROFILE_SCOPE_KERNELS = dict(SCOPE_KERNELS, extend_filter=["extend_filter_cls_kernel", "l2_prefix_kernel"],
+PROFILE_SCOPE_KERNELS = dict(SCOPE_KERNELS, extend_filter=["extend_filter_cls_kernel"],
                              extend_filter2=["extend_filter_packed_kernel"])
 EXTENSION_SCOPES = ["extend_filter", "extend_filter2", "chain_group", "chain_link", "extend_exact_chain", "extend_exact", "extend_entropy"]
 
@@ -87,6 +87,10 @@ def parse():
                     help="do not record per-kernel HIP events in the timed region (roofline block from the untimed passes only)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = the calls of ONE pass are dealt to the ranks (total work fixed); weak = every rank runs the whole pass")
+    ap.add_argument("--no-dropin", action="store_true",
+                    help="skip the drop-in leg (one-chunk g_SeedAndFilter calls): profile collections use it so that per-kernel averages "
+                         "describe the calls of the timed region only")
+    ap.add_argument("--no-roofline", action="store_true", help="timed region only: no extra passes at all (tools/timeline.py)")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU-only rehearsal of the launch/shard/reduce/JSON contract (gloo, no GPU): real shard + chunk "
                          "arithmetic around a stub engine")
@@ -316,14 +320,14 @@ def main():
         E.profile_enable(False)
         prof = E.profile_entries()
     roof = None
-    if rank == 0 and prof:
+    if rank == 0 and prof and not args.no_roofline:
         roof = roofline(args, E, wl, prof, call_stats, run_step, run_job, jobs, elapsed, world)
-        if not wl["rm"]:
+        if not wl["rm"] and not args.no_dropin:
             roof["dropin"] = dropin_leg(E, jobs, args, seed_size, 13 if wl["transition"] else 1)
 
     # ---------------- CPU baseline (rank 0, N == 1 only, bounded sample) ----------------
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not wl["rm"]:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_roofline and not wl["rm"]:
         cpu = cpu_baseline(E, target, query, sub_mat, seed_size, kmer, args, xdrop, hspthresh, wl["transition"])
 
     if rank == 0:
@@ -352,14 +356,14 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         # table build (setup, once per target block): algorithmic bytes of the reference-layout table, and the bytes
-        # this build writes on top of it -- the neighbourhood table: 4-byte positions, or 28-byte context records + positions
+        # this build writes on top of it -- the neighbourhood table: 4-byte positions, or 32-byte context records (position embedded)
         lm, nent = E.lookup_mode(), E.neighbourhood_entries()
         tv = float(target.size)
         alg_tb = tv + 8.0 * 4 ** 12 + 8.0 * tv
         impl_tb = alg_tb + nent * {0: 0, 1: 4, 2: 32}[lm]
         line["table_build"] = {
             "seconds": round(t_table, 4), "lookup_mode": lm, "neighbourhood_entries": nent,
-            "bytes": "1*T + 8*4^12 + 8*T_valid (reference-layout table) [+ 32 B (28-byte context record + position) or 4 B per neighbourhood entry]",
+            "bytes": "1*T + 8*4^12 + 8*T_valid (reference-layout table) [+ 32 B (context record with its position) or 4 B per neighbourhood entry]",
             "algorithmic_bytes": int(alg_tb), "algorithmic_frac": round(alg_tb / max(t_table, 1e-9) / 1e9 / HBM_PEAK_GBS, 5),
             "written_bytes": int(impl_tb), "written_frac": round(impl_tb / max(t_table, 1e-9) / 1e9 / HBM_PEAK_GBS, 4),
             "note": "wall time of GenerateSeedPosTable incl. every sync; the table arena is mapped in the background from InitializeProcessor on"}
@@ -377,8 +381,8 @@ def main():
 def roofline(args, E, wl, prof, call_stats, run_step, run_job, jobs, elapsed, world):
     """The dominant kernel against the HBM roofline, honest by construction.
 
-    `achieved` = bytes the kernel's data layout makes it MOVE per launch (stated per unit in DESIGN.md 4.5: 28 B of context record
-    per hit + 16 B of position record per non-empty query position + 1 bit per hit of head map + 24 B per forwarded hit), from the
+    `achieved` = bytes the kernel's data layout makes it MOVE per launch (stated per unit in DESIGN.md 4.5: 32 B of context record
+    per hit + 16 B of position record per non-empty query position + 1 bit per hit of head map + 20 B per forwarded hit), from the
     exact per-call counts, divided by the kernel's average launch duration from HIP events on the engine's own streams over the
     timed region.  These are bytes that really cross the memory system, so frac <= 1; the PMC-measured HBM bytes of the committed
     rocprofv3 collection stand beside it (`traffic`).  SURVEY 8(d)'s reference-layout figure (8*H + 2*E + 20*A: one byte per
@@ -431,16 +435,16 @@ def roofline(args, E, wl, prof, call_stats, run_step, run_job, jobs, elapsed, wo
     # bytes the layout moves, per scope, from exact counts (h = hits, s = seed words, c = candidates, a = survivors)
     def moved(h, a, s, c):
         pos = s / words                                   # valid query positions (non-empty ones are fewer: upper bound on TdRec bytes)
-        fwd = 0.045 * h                                   # hits level 1 forwards (measured 4.3-4.5 %; 24-byte L2Rec each)
-        return {"extend_filter": (28.0 * h + 16.0 * pos + h / 8.0 + 24.0 * fwd) if ctx_filter else ((4.0 if table_direct else 8.0) * h + 12.0 * c),
-                "extend_filter2": 24.0 * fwd + 12.0 * c,
+        fwd = 0.045 * h                                   # hits level 1 forwards (measured 4.3-4.5 %; 20-byte L2Rec each)
+        return {"extend_filter": (32.0 * h + 16.0 * pos + h / 8.0 + 20.0 * fwd) if ctx_filter else ((4.0 if table_direct else 8.0) * h + 12.0 * c),
+                "extend_filter2": 20.0 * fwd + 12.0 * c,
                 lookup_scope: (9.0 * pos + 12.0 * pos + 16.0 * pos) if table_direct else 16.0 * s,
                 "expand_hits": 12.0 * h}
 
     mv_t, mv_s = moved(H, A, S, Cn), moved(sH2, sA, sS, sC)
-    formula = {"extend_filter": "28*H + 16*P + H/8 + 24*F  (context records + position records + head bits + forwarded records)" if ctx_filter
+    formula = {"extend_filter": "32*H + 16*P + H/8 + 20*F  (context records + position records + head bits + forwarded records)" if ctx_filter
                                 else "%g*H + 12*C" % (4.0 if table_direct else 8.0),
-               "extend_filter2": "24*F + 12*C", lookup_scope: "37*P  (9 B codes + 12 B scratch + 16 B extent per position)" if table_direct else "16*S",
+               "extend_filter2": "20*F + 12*C", lookup_scope: "37*P  (9 B codes + 12 B scratch + 16 B extent per position)" if table_direct else "16*S",
                "expand_hits": "12*H"}.get(name)
     achieved = rate(mv_t[name], ms) if name in mv_t else None
     s_ms = solo[name][0] if name in solo else None

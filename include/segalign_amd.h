@@ -202,7 +202,8 @@ int sa_max_hits_for_mem(uint64_t total_global_mem);
  *   debug             1: table-build timings on stderr
  * Launch geometry (defaults are the measured optima, tools/sweep_*.sh)
  *   fin_batch, bufs_per_wave, long_cap, long_blocks, max_waves, packed_waves, l2_blocks, ctx_waves, ctx_threads,
- *   chain_sort_threads, dedup_threads, nbr_one_stage
+ *   chain_sort_threads, dedup_threads, nbr_one_stage, table_atomic (1: seed table by the atomic counting sort even for seed
+ *   weights 9..12, where the LDS-staged partition build is the default)
  * Test-only options (small capacities that force the overflow / fallback branches of the orchestration)
  *   l2_cap, spec_dedup, spec_recs, dedup_seg_max, no_small_dedup, chain_cap, audit_cap
  */

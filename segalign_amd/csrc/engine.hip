@@ -503,6 +503,7 @@ static int g_packed_waves = 4096; // SEGALIGN_AMD_PACKED_WAVES: waves of the pac
 static int g_ctx_waves = 0;       // SEGALIGN_AMD_CTX_WAVES: wave budget of the context filter; 0 = one 4096-hit chunk per wave (measured best)
 static uint32_t g_l2_cap_test = 0; // SEGALIGN_AMD_L2_CAP
 static int g_nbr_two_stage = 1;   // SEGALIGN_AMD_NBR_ONE_STAGE=1: every table entry cuts its own context out of the target
+static int g_table_atomic = 0;    // option table_atomic: build the seed table with the atomic counting sort even where the partition build applies
 static int64_t g_arena_gb = 40;   // option arena_gb: GiB of table arena the engine starts mapping at InitializeProcessor (0: on demand only)
 static int g_ctx_threads = 0;     // SEGALIGN_AMD_CTX_THREADS: workgroup size of the context filter (0 = kernel default)
 static int g_dedup_threads = 0;   // SEGALIGN_AMD_DEDUP_THREADS: workgroup size of the per-segment LDS chain (0 = 1024)
@@ -1580,7 +1581,7 @@ static Option g_opts[] = {
     {"long_blocks", 1792, 1, 1 << 20, 0}, {"max_waves", 4096, 4, 1 << 20, 0}, {"packed_waves", 4096, 8, 1 << 20, 0},
     {"l2_blocks", 512, 1, 1 << 20, 0}, {"ctx_waves", 0, 0, 1 << 20, 0}, {"ctx_threads", 0, 0, 1024, 0},
     {"chain_sort_threads", 256, 64, 512, 0}, {"dedup_threads", 0, 0, 1024, 0},
-    {"nbr_one_stage", 0, 0, 1, 0},
+    {"nbr_one_stage", 0, 0, 1, 0}, {"table_atomic", 0, 0, 1, 0},
     // test-only: small capacities that force the overflow / fallback branches
     {"l2_cap", 0, 0, 1 << 30, 1}, {"spec_dedup", 1, 0, 1, 1}, {"spec_recs", 16384, 1, 16384, 1}, {"dedup_seg_max", 0, 0, 1 << 30, 1},
     {"no_small_dedup", 0, 0, 1, 1}, {"chain_cap", 1 << 22, 1, 1 << 30, 1}, {"audit_cap", 0, 0, 1 << 28, 1},
@@ -1628,6 +1629,7 @@ static void resolve_options() {
     g_chain_sort_threads = (int)opt_value("chain_sort_threads") & ~63;
     g_dedup_threads = (int)opt_value("dedup_threads");
     g_nbr_two_stage = opt_value("nbr_one_stage") ? 0 : 1;
+    g_table_atomic = (int)opt_value("table_atomic");
     g_l2_cap_test = opt_value("l2_cap") ? (uint32_t)std::max<int64_t>(L2_NSUB, opt_value("l2_cap")) : 0u;
     g_spec_dedup = (int)opt_value("spec_dedup");
     SPEC_RECS = (uint32_t)opt_value("spec_recs");
@@ -2011,25 +2013,55 @@ void sa_generate_seed_pos_table(const char* ref_str, size_t start_addr, uint32_t
         nbr_release(dc);
         dev_free(dc->bucket_start, "d_index_table");
         dev_free(dc->pos_table, "d_pos_table");
-        uint32_t* hist = (uint32_t*)dev_malloc(((size_t)nkeys + 1) * sizeof(uint32_t), "kmer histogram");
         dc->bucket_start = (uint32_t*)dev_malloc(((size_t)nkeys + 1) * sizeof(uint32_t), "index_table");
-        void* scan_tmp = dev_malloc(scan_temp_bytes(nkeys), "scan temp");
-        check_memcpy(hipMemsetAsync(hist, 0, ((size_t)nkeys + 1) * sizeof(uint32_t), st), "histogram");
-        launch_table_count(codes, num_steps, start_offset, step, sh, hist, st);
-        launch_exclusive_scan_u32(hist, dc->bucket_start, nkeys, scan_tmp, st);
-        check_launch("table count/scan");
         uint32_t num_index = 0;
-        check_memcpy(hipMemcpyAsync(&num_index, dc->bucket_start + nkeys, sizeof(uint32_t), hipMemcpyDeviceToHost, st),
-                     "num_index");
-        check_sync(st, "table count");
-        dc->pos_table = (uint32_t*)dev_malloc((size_t)std::max<uint32_t>(num_index, 1) * sizeof(uint32_t), "pos_table");
-        check_memcpy(hipMemsetAsync(hist, 0, ((size_t)nkeys + 1) * sizeof(uint32_t), st), "cursor");
-        launch_table_fill(codes, num_steps, start_offset, step, sh, dc->bucket_start, hist, dc->pos_table, st);
-        launch_table_sort_buckets(dc->bucket_start, nkeys, dc->pos_table, st);
-        check_launch("table fill/sort");
-        check_sync(st, "table fill");
-        dev_free(hist, "kmer histogram");
-        dev_free(scan_tmp, "scan temp");
+        if (table_partition_build_supported(kmer_size) && !g_table_atomic) {
+            // PARTITION build (table.hip): keys + coarse histogram -> offsets of the 4096 coarse partitions -> two LDS-staged
+            // partition passes -> one workgroup per partition finishes its slice of bucket_start and pos_table in LDS
+            const size_t pw = table_partition_part_start_words();
+            uint32_t* keys = (uint32_t*)dev_malloc((size_t)std::max<uint32_t>(num_steps, 1) * sizeof(uint32_t), "kmer keys");
+            uint32_t* coarse = (uint32_t*)dev_malloc(3 * pw * sizeof(uint32_t) + 4096, "coarse histogram");  // hist | part_start | cursor | flags
+            uint32_t* part_start = coarse + pw;
+            uint32_t* cursor = part_start + pw;
+            uint8_t* part_unsorted = reinterpret_cast<uint8_t*>(cursor + pw);
+            void* scan_tmp = dev_malloc(scan_temp_bytes(pw), "scan temp");
+            check_memcpy(hipMemsetAsync(coarse, 0, pw * sizeof(uint32_t), st), "coarse histogram");
+            launch_table_keys(codes, num_steps, start_offset, step, sh, keys, coarse, st);
+            launch_exclusive_scan_u32(coarse, part_start, pw - 1, scan_tmp, st);
+            check_launch("table keys/scan");
+            check_memcpy(hipMemcpyAsync(&num_index, part_start + (pw - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st), "num_index");
+            check_sync(st, "table keys");
+            const size_t np = std::max<uint32_t>(num_index, 1);
+            dc->pos_table = (uint32_t*)dev_malloc(np * sizeof(uint32_t), "pos_table");
+            uint32_t* pairs = (uint32_t*)dev_malloc(4 * np * sizeof(uint32_t), "partition pairs");  // key_a | pos_a | key_b | pos_b
+            launch_table_partition_build(keys, num_steps, start_offset, step, kmer_size, part_start, num_index, cursor, pairs, pairs + np,
+                                         pairs + 2 * np, pairs + 3 * np, part_unsorted, dc->bucket_start, dc->pos_table, st);
+            check_launch("table partition");
+            check_sync(st, "table partition");
+            dev_free(pairs, "partition pairs");
+            dev_free(keys, "kmer keys");
+            dev_free(coarse, "coarse histogram");
+            dev_free(scan_tmp, "scan temp");
+        } else {
+            // ATOMIC build: histogram + scatter with one global atomic per position (any seed weight)
+            uint32_t* hist = (uint32_t*)dev_malloc(((size_t)nkeys + 1) * sizeof(uint32_t), "kmer histogram");
+            void* scan_tmp = dev_malloc(scan_temp_bytes(nkeys), "scan temp");
+            check_memcpy(hipMemsetAsync(hist, 0, ((size_t)nkeys + 1) * sizeof(uint32_t), st), "histogram");
+            launch_table_count(codes, num_steps, start_offset, step, sh, hist, st);
+            launch_exclusive_scan_u32(hist, dc->bucket_start, nkeys, scan_tmp, st);
+            check_launch("table count/scan");
+            check_memcpy(hipMemcpyAsync(&num_index, dc->bucket_start + nkeys, sizeof(uint32_t), hipMemcpyDeviceToHost, st),
+                         "num_index");
+            check_sync(st, "table count");
+            dc->pos_table = (uint32_t*)dev_malloc((size_t)std::max<uint32_t>(num_index, 1) * sizeof(uint32_t), "pos_table");
+            check_memcpy(hipMemsetAsync(hist, 0, ((size_t)nkeys + 1) * sizeof(uint32_t), st), "cursor");
+            launch_table_fill(codes, num_steps, start_offset, step, sh, dc->bucket_start, hist, dc->pos_table, st);
+            launch_table_sort_buckets(dc->bucket_start, nkeys, dc->pos_table, st);
+            check_launch("table fill/sort");
+            check_sync(st, "table fill");
+            dev_free(hist, "kmer histogram");
+            dev_free(scan_tmp, "scan temp");
+        }
         tmp_codes.release("table codes");
         dc->num_index = num_index;
         dc->nkeys = nkeys;

@@ -219,6 +219,16 @@ void launch_table_fill(const uint8_t* ref, uint32_t num_steps, uint32_t start_of
 // canonical (ascending) order inside every bucket -- the reference order is atomic arrival order (H7)
 void launch_table_sort_buckets(const uint32_t* bucket_start, uint32_t nkeys, uint32_t* pos_table, hipStream_t s);
 
+// PARTITION build (table.hip): LDS-staged MSD radix partition, for seed weights table_partition_build_supported() accepts
+bool table_partition_build_supported(int weight);
+size_t table_partition_part_start_words();
+void launch_table_keys(const uint8_t* ref, uint32_t num_steps, uint32_t start_offset, uint32_t step, SeedShape sh, uint32_t* keys,
+                       uint32_t* coarse_hist /* 4096 words, zero on entry */, hipStream_t s);
+void launch_table_partition_build(const uint32_t* keys, uint32_t num_steps, uint32_t start_offset, uint32_t step, int weight,
+                                  const uint32_t* part_start /* 4097 */, uint32_t num_index, uint32_t* cursor /* 4096 */, uint32_t* key_a,
+                                  uint32_t* pos_a, uint32_t* key_b, uint32_t* pos_b, uint8_t* part_unsorted /* 4096 */,
+                                  uint32_t* bucket_start, uint32_t* pos_table, hipStream_t s);
+
 // ---- seeds.hip -------------------------------------------------------------------------------------------------
 // device-side seeder: valid flags for query positions [start,end), then ordered emission
 void launch_seed_flags(const uint8_t* query, uint32_t start, uint32_t end, SeedShape sh, uint32_t* flags, hipStream_t s);

@@ -5,7 +5,7 @@ import threading
 import numpy as np
 import pytest
 
-from helpers import Case, seg_equal, SHAPE_12OF19
+from helpers import Case, canonical_pos_table, seg_equal, SHAPE_12OF19
 from segalign_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -203,3 +203,31 @@ def test_repeat_masker_variant(oracle, engine_clean):
                 total += want.size - 1
     assert total > 0
     E.RmClearQuery()
+
+
+@pytest.mark.parametrize("atomic", [0, 1])
+@pytest.mark.parametrize("shape,step", [(SHAPE_12OF19, 1), (SHAPE_12OF19, 3), ("TTTTT11TTTT", 1), ("TT0TT0TT0TT0T", 2)])
+def test_both_table_builds_give_the_reference_table(oracle, engine_clean, atomic, shape, step):
+    """GenerateSeedPosTable (common/seed_pos_table.cu:49-109) on the device, both builds: the LDS-staged partition build (seed
+    weights 9..12, the default) and the atomic counting sort (option table_atomic, and every other weight) must give the
+    reference's index table and -- canonically ordered -- position table, incl. masked runs, N runs, record separators, a
+    poly-A stretch that makes one coarse partition overflow the finishing kernel's LDS, and steps > 1."""
+    t, q = synth.make_pair(3_000_000, 17, 18, sub_rate=0.08, mask_frac=0.15, records=4, n_runs=3)
+    t = t.copy()
+    t[1_200_000:1_260_000] = ord("A")  # 60 k positions with ONE key: a bucket (and a coarse partition) far above every LDS capacity
+    engine_clean.set_option("table_atomic", atomic)
+    try:
+        c = Case(t, q[:200000], shape=shape, step=step, chunk=100000).oracle_setup(oracle).engine_setup(engine_clean)
+        assert np.array_equal(c.E.copy_index_table(), c.o_index)
+        assert np.array_equal(canonical_pos_table(c.o_index, c.E.copy_pos_table()), canonical_pos_table(c.o_index, c.o_pos))
+        # buckets up to the sort limit are in ascending order on the device as well (hazard H7 is about the rest)
+        idx = c.o_index.astype(np.int64)
+        starts = np.concatenate([[0], idx[:-1]])
+        small = np.flatnonzero((idx - starts >= 2) & (idx - starts <= 512))[:20000]
+        pos = c.E.copy_pos_table()
+        for k in small[:: max(1, small.size // 500)]:
+            seg = pos[starts[k]:idx[k]]
+            assert np.all(seg[1:] > seg[:-1]), int(k)
+        run_all_chunks(c, rev_list=(False,))
+    finally:
+        engine_clean.reset_option("table_atomic")

@@ -46,7 +46,7 @@ def overlap2(iv):
 
 def main():
     out = open(sys.argv[1], "w") if len(sys.argv) > 1 else sys.stdout
-    extra = sys.argv[2:] or ["--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    extra = sys.argv[2:] or ["--steps", "4", "--warmup", "1", "--no-roofline"]
     d = tempfile.mkdtemp(prefix="sa_timeline_")
     cmd = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "r", "--", sys.executable, os.path.join(ROOT, "bench.py")] + extra
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
@@ -58,15 +58,15 @@ def main():
     if not rows:
         out.write("no kernels traced (exit %d)\n%s\n" % (res.returncode, res.stderr.decode()[-800:]))
         return
-    l1_all = [(s, e) for s, e, n in rows if "extend_filter_ctx_kernel" in n]
-    # steady state: from 40 % to 92 % of the context-filter launches (skips setup, warmup and the single-stream extra pass)
-    a, b = l1_all[int(len(l1_all) * 0.40)][0], l1_all[int(len(l1_all) * 0.92)][0]
+    l1_all = [(s, e) for s, e, n in rows if "extend_filter_cls_kernel" in n]
+    # steady state: from 30 % to 95 % of the level-1 filter launches (skips setup and warmup; the run has no extra passes)
+    a, b = l1_all[int(len(l1_all) * 0.30)][0], l1_all[int(len(l1_all) * 0.95)][0]
     win = [(max(s, a), min(e, b), n) for s, e, n in rows if e > a and s < b]
     wall = b - a
     allk = [(s, e) for s, e, n in win]
-    l1 = [(s, e) for s, e, n in win if "extend_filter_ctx_kernel" in n]
+    l1 = [(s, e) for s, e, n in win if "extend_filter_cls_kernel" in n]
     l2 = [(s, e) for s, e, n in win if "extend_filter_packed_kernel" in n]
-    small = [(s, e) for s, e, n in win if "extend_filter_ctx_kernel" not in n and "extend_filter_packed_kernel" not in n]
+    small = [(s, e) for s, e, n in win if "extend_filter_cls_kernel" not in n and "extend_filter_packed_kernel" not in n]
     out.write("command: bench.py %s\n" % " ".join(extra))
     out.write("window: %.1f ms, %d kernels, %d context-filter launches\n" % (wall / 1e6, len(win), len(l1)))
     def pct(x):

@@ -20,8 +20,8 @@ of configs[2] (a 500 Mbp target block, the size at which the reference closes a 
 %-diverged shuffled pieces; every rank of an N-GPU run holds its own block pair, as the 6 x 6 block pairs of a 3 Gbp x 3 Gbp
 run are independent), `plumbing` = configs[0] (1 Mbp x 1 Mbp).
 
-Multi-GPU: the unit of work is one engine CALL (up to sixteen 250 kbp chunks of one strand of one interval, 60
-calls per pass of the default workload); calls are independent and their output position is fixed by the host loop.  Default
+Multi-GPU: the unit of work is one engine CALL (up to 32 consecutive 250 kbp chunks of one strand of one interval; 20 by
+default, so a strand's 40 chunks of an interval are two calls and a pass of the default workload is 40 calls); calls are independent and their output position is fixed by the host loop.  Default
 `--scaling strong`: the calls of ONE pass are dealt round-robin to the N ranks -- every call on exactly one GPU, total work fixed,
 `value` = query bases of the block / max-rank time, and the order-independent HSP checksum of the pass must equal the 1-GPU
 checksum.  `--scaling weak`: every rank runs the whole pass (rank-dependent start).  Every rank holds target + tables; there is
@@ -235,7 +235,7 @@ def main():
         jobs = shard.call_jobs(intervals, q_block_len, args.chunk, E.lib().sa_get_chunks_per_call())
 
     def run_job(job, collect=None):
-        """one engine call: up to sixteen 250 kbp chunks of one strand of one interval (src/seeder.cpp:47-121), or one interval task
+        """one engine call: up to 32 (default 20) 250 kbp chunks of one strand of one interval (src/seeder.cpp:47-121), or one interval task
         of the repeat masker (repeat_masker_src/seeder.cpp:28-195).  -> (query bases counted once, HSPs, checksum)"""
         if job.get("rm"):
             iv, tot = E.RmMaskInterval(job["a"], job["b"], job["ref_start"], job["ref_end"], E.STRAND_BOTH, 1)

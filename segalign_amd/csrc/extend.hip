@@ -1343,11 +1343,13 @@ __global__ __launch_bounds__(512) void chain_bucket_sort_kernel(ExtendArgs a) {
         while (g0 + i >= s_b[j + 1]) j++;
         const uint32_t lo = s_b[j] - g0, hi = s_b[j + 1] - g0;
         const unsigned long long k = s_key[i];
+        // rank = entries below this one; keys are unique per hit, and hand-made ties (a foreign host's duplicate seed words) are
+        // broken by the index: "<=" before i, "<" behind it -- one compare + one add-with-carry per entry either way
         uint32_t rank = 0;
-        for (uint32_t t = lo; t < hi; t++) {
-            const unsigned long long kt = s_key[t];
-            rank += (kt < k || (kt == k && t < i)) ? 1u : 0u;  // keys are unique per hit; the index breaks hand-made ties
-        }
+#pragma unroll 4
+        for (uint32_t t = lo; t < i; t++) rank += s_key[t] <= k ? 1u : 0u;
+#pragma unroll 4
+        for (uint32_t t = i + 1; t < hi; t++) rank += s_key[t] < k ? 1u : 0u;
         a.chain_sorted[g0 + lo + rank] = a.chain_tmp[g0 + i];
     }
 }

@@ -212,7 +212,14 @@ static uint32_t SPEC_RECS = 16384;    // records of the speculative output copy 
 static uint32_t g_dedup_seg_max = 0;   // SEGALIGN_AMD_DEDUP_SEG_MAX: records per segment the LDS chain accepts (0 = its LDS capacity; tests)
 constexpr int SA_MAX_CHUNKS = 32;  // chunks one multi-chunk call may carry: 2 reference iterations each = MAX_SEGS segments
 constexpr int SA_DEFAULT_CHUNKS = 20;  // ... and what the interval entries hand to one call: the 40 chunks of a 10 Mbp strand go as 20 + 20
-static int SLOTS_PER_DEVICE = 2;  // calls in flight per device (the reference allows one: token == device); SEGALIGN_AMD_SLOTS
+static int SLOTS_PER_DEVICE = 4;  // calls in flight per device (the reference allows one: token == device); option slots
+
+// Every slot issues its kernels on a stream of its own, next to the upload stream.  The HIP runtime multiplexes streams onto
+// GPU_MAX_HW_QUEUES hardware queues (default 4), and two slots that share a queue run one after the other: with four slots the
+// small kernels of one call then wait behind another call's filter kernel instead of overlapping it (0.94 -> 1.03 Gbp/s on the
+// default workload with 8 queues).  The runtime reads the variable when it initialises, i.e. at the first HIP call of the process;
+// a value the user has set is left alone.
+__attribute__((constructor)) static void default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 struct Counters {  // device-side scalars of one slot
     uint32_t survivors;
@@ -405,15 +412,20 @@ static void arena_trim(Arena& A, size_t keep) {
         hipMemRelease(A.chunks.back());
         A.chunks.pop_back();
     }
+    // On this runtime (ROCm 7.2) the pages of an unmapped + released chunk only go back to the device when the ADDRESS RANGE is
+    // freed (tools/micro/vmm_info2.hip: every teardown order leaves hipMemGetInfo and the number of creatable chunks unchanged
+    // until hipMemAddressFree).  So giving everything back means giving the range back too; the next request reserves a new one.
+    if (A.mapped == 0 && A.base) {
+        hipMemAddressFree(A.base, A.va_bytes);
+        A.base = nullptr;
+        A.va_bytes = 0;
+        A.goal = 0;
+    }
     A.failed = false;
 }
 static void arena_destroy(Arena& A) {
     arena_trim(A, 0);
     std::lock_guard<std::mutex> lk(A.mu);
-    if (A.vmm && A.base) hipMemAddressFree(A.base, A.va_bytes);
-    A.base = nullptr;
-    A.va_bytes = 0;
-    A.goal = 0;
     A.vmm = true;
 }
 static size_t arena_mapped(Arena& A) {
@@ -1567,7 +1579,7 @@ struct Option {
 };
 static Option g_opts[] = {
     // deployment
-    {"slots", 2, 1, MAX_SLOTS_PER_DEVICE, 0},          // calls in flight per device (the reference allows one: token == device)
+    {"slots", 4, 1, MAX_SLOTS_PER_DEVICE, 0},          // calls in flight per device (the reference allows one: token == device)
     {"chunks_per_call", SA_DEFAULT_CHUNKS, 1, SA_MAX_CHUNKS, 0},  // chunks sa_seed_interval / sa_rm_mask_interval hand to one pass
     {"no_ctx", 0, 0, 1, 0},                            // 1: neighbourhood table without target context (lookup mode 1)
     {"no_td", 0, 0, 1, 0},                             // 1: no neighbourhood table at all (lookup mode 0, the reference-shaped path)

@@ -108,7 +108,7 @@ def test_block_that_does_not_fit_falls_back_to_positions_and_recovers(oracle, en
         check_block(E, O, sub_mat, k, small, [make_query(small, 300)], 2)
         free_b, total_b = ctypes.c_size_t(0), ctypes.c_size_t(0)
         assert hip.hipMemGetInfo(ctypes.byref(free_b), ctypes.byref(total_b)) == 0
-        hog = ctypes.c_void_p()  # leave ~30 GB: the table (~52 GB) + the engine's reserve (16 GiB) exceed that + the arena (8 GiB),
+        hog = ctypes.c_void_p()  # leave ~30 GB: the table (~52 GB) + the engine's reserve (24 GiB) exceed that + the arena (8 GiB),
         assert hip.hipMalloc(ctypes.byref(hog), ctypes.c_size_t(max(free_b.value - (30 << 30), 1 << 20))) == 0  # positions + reserve fit
         E.ClearRef()
         check_block(E, O, sub_mat, k, big, [make_query(big, 400)], 1)

@@ -412,10 +412,10 @@ def roofline(args, E, wl, prof, call_stats, run_step, run_job, jobs, elapsed, wo
 
     def totals(stats):
         return (sum(s["num_hits"] for s in stats), sum(s["num_survivors"] for s in stats), sum(s["num_seeds"] for s in stats),
-                sum(s["num_candidates"] for s in stats))
+                sum(s["num_candidates"] for s in stats), sum(s.get("num_forwarded", 0) for s in stats))
 
-    H, A, S, Cn = totals(call_stats)
-    sH2, sA, sS, sC = totals(solo_stats)
+    H, A, S, Cn, F = totals(call_stats)
+    sH2, sA, sS, sC, sF = totals(solo_stats)
     table_direct = "seed_probe" in prof
     ctx_filter = "extend_filter2" in prof   # context-table calls: level 1 (class filter on the records) + level 2 (packed kernel)
     words = 13 if wl["transition"] else 1
@@ -438,15 +438,14 @@ def roofline(args, E, wl, prof, call_stats, run_step, run_job, jobs, elapsed, wo
               "extend_filter2": "extend_filter_packed_kernel"}.get(name) or (SCOPE_KERNELS.get(name) or [None])[0]
 
     # bytes the layout moves, per scope, from exact counts (h = hits, s = seed words, c = candidates, a = survivors)
-    def moved(h, a, s, c):
+    def moved(h, a, s, c, fwd):                           # fwd = hits level 1 forwards (exact count; 20-byte L2Rec each)
         pos = s / words                                   # valid query positions (non-empty ones are fewer: upper bound on TdRec bytes)
-        fwd = 0.045 * h                                   # hits level 1 forwards (measured 4.3-4.5 %; 20-byte L2Rec each)
         return {"extend_filter": (32.0 * h + 16.0 * pos + h / 8.0 + 20.0 * fwd) if ctx_filter else ((4.0 if table_direct else 8.0) * h + 12.0 * c),
                 "extend_filter2": 20.0 * fwd + 12.0 * c,
                 lookup_scope: (9.0 * pos + 12.0 * pos + 16.0 * pos) if table_direct else 16.0 * s,
                 "expand_hits": 12.0 * h}
 
-    mv_t, mv_s = moved(H, A, S, Cn), moved(sH2, sA, sS, sC)
+    mv_t, mv_s = moved(H, A, S, Cn, F), moved(sH2, sA, sS, sC, sF)
     formula = {"extend_filter": "32*H + 16*P + H/8 + 20*F  (context records + position records + head bits + forwarded records)" if ctx_filter
                                 else "%g*H + 12*C" % (4.0 if table_direct else 8.0),
                "extend_filter2": "20*F + 12*C", lookup_scope: "37*P  (9 B codes + 12 B scratch + 16 B extent per position)" if table_direct else "16*S",
@@ -526,7 +525,7 @@ def roofline(args, E, wl, prof, call_stats, run_step, run_job, jobs, elapsed, wo
             "note": "what the reference's byte-per-base layout would have to move for the same work in the same time; NOT a bandwidth of "
                     "this engine (2-bit / 4-bit packing and the context records move a fraction of it) and therefore not compared with the peak"},
         "per_hit": {"examined_bases_E": round(e_all, 2), "examined_by_filter": round(e_flt, 2),
-                    "candidate_frac": round(Cn / max(H, 1), 5), "survivor_frac": round(A / max(H, 1), 5),
+                    "forwarded_frac": round(F / max(H, 1), 5), "candidate_frac": round(Cn / max(H, 1), 5), "survivor_frac": round(A / max(H, 1), 5),
                     "hits_per_seed_word": round(H / max(S, 1), 3)},
         "table_direct": table_direct,
         # the kernel north_star names: seed lookup.  Table-direct: probe_kernel -- one probe per query POSITION into the neighbourhood table

@@ -237,6 +237,7 @@ typedef struct sa_call_stats {
     int lookup_path;        /* seed lookup path the call took: 0 general (seed words -> buckets -> hit list), 1 table-direct,
                                2 table-direct with target context (sa_get_lookup_mode) */
     int reserved;
+    uint64_t num_forwarded; /* context-table calls: hits the class filter (level 1) handed to the second level; 0 otherwise */
 } sa_call_stats;
 void sa_get_last_call_stats(sa_call_stats* out); /* stats of the calling thread's most recent hot call */
 void sa_set_count_examined(int on);

@@ -743,7 +743,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
     uint64_t num_hits = 0;
     uint32_t n_final = 0;
     uint32_t survivors = 0;
-    uint64_t n_cand_total = 0, n_ent_total = 0;
+    uint64_t n_cand_total = 0, n_ent_total = 0, n_fwd_total = 0;
     // chunks of the seed vector (one for an ordinary call)
     const int K = ca.nchunks > 1 ? ca.nchunks : 1;
     uint32_t sbound[SA_MAX_CHUNKS + 1] = {0, num_seeds};
@@ -1067,6 +1067,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
                 }
                 survivors = sl->h_cnt->survivors;
                 n_cand_total += sl->h_cnt->n_long;
+                n_fwd_total += sl->h_cnt->n_l2;
                 n_ent_total += sl->h_cnt->n_ent;
             }
             if (g_audit_cap && ca.td) {  // (tests) the rejected hits of the last batch
@@ -1080,6 +1081,7 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
             t_stats.num_examined = sl->h_cnt->examined;
             t_stats.num_examined_filter = sl->h_cnt->examined_filter;
             t_stats.num_candidates = n_cand_total;
+            t_stats.num_forwarded = n_fwd_total;
             t_stats.num_entropy = n_ent_total;
 
             // ---- order + de-duplicate (:776-782 ; rm :819-831) ----
@@ -1368,9 +1370,9 @@ static bool ensure_nbr(DevCtx* dc) {
     const size_t reserve = ((size_t)8 << 30) + ((size_t)4 << 30) * (size_t)SLOTS_PER_DEVICE;
     const size_t need_pos = (size_t)std::max<uint64_t>(total, 1) * sizeof(uint32_t);
     // context records (class filter): 32 bytes per entry; the two-stage fill wants num_index records of scratch behind them, which is
-    // given up (one-stage fill) when only the table itself fits.  (+ 4 KB of slack: the filter's lanes past a call's last hit
-    // read up to 63 entries past a run)
-    const size_t rec_b = (size_t)std::max<uint64_t>(total, 1) * sizeof(CtxRec) + 4096;
+    // given up (one-stage fill) when only the table itself fits.  (+ 16 KB of slack: the filter requests two buffers ahead, so
+    // its lanes read up to 3 x 64 entries past the last run)
+    const size_t rec_b = (size_t)std::max<uint64_t>(total, 1) * sizeof(CtxRec) + 16384;
     const size_t scratch_b = (size_t)dc->num_index * sizeof(CtxRec);
     const size_t have = arena_mapped(dc->arena);  // (already ours: does not count against the free memory)
     bool built = false;
@@ -2316,6 +2318,7 @@ size_t sa_seed_interval(uint32_t start, uint32_t end, uint32_t q_len, int strand
         tot.num_examined += t_stats.num_examined;
         tot.num_examined_filter += t_stats.num_examined_filter;
         tot.num_candidates += t_stats.num_candidates;
+        tot.num_forwarded += t_stats.num_forwarded;
         tot.num_entropy += t_stats.num_entropy;
         tot.num_iter += t_stats.num_iter;
         tot.device = t_stats.device;
@@ -2379,6 +2382,7 @@ size_t sa_seed_calls(const sa_call_desc* calls, size_t num_calls, uint32_t buffe
         tot.num_examined += t_stats.num_examined;
         tot.num_examined_filter += t_stats.num_examined_filter;
         tot.num_candidates += t_stats.num_candidates;
+        tot.num_forwarded += t_stats.num_forwarded;
         tot.num_entropy += t_stats.num_entropy;
         tot.num_iter += t_stats.num_iter;
         tot.device = t_stats.device;

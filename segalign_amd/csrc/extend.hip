@@ -857,13 +857,22 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
 //     the exact 91..100 / -114 / -31 / -123..-125 -- the drift of a random walk is -42.0 instead of -43.4 per base).
 // With target AND query at 2 bits per base one XOR per 16 bases yields the class string, and a 12-bit field of it -- SIX bases
 // -- indexes a 4096-entry table: 19 lookups per hit instead of 56, no byte permutes.
-// The walk is kept as (T, D): T = running score, D = best - T (the current drop):  D = max(D, mx) - sum;  T += sum, with
-// (T, D) in ONE register P = T * 65536 + D:
-//     P = pk_max_i16(P, {INT16_MIN : mx}) + sum * 65535;   W = pk_max_i16(W, P)      (3 VALU + 1 ds_read_b64 per six bases)
-// (the integer identity (T + sum) * 65536 + (max(D, mx) - sum) = Pmax + sum * 65535 keeps both halves exact; |T| and D stay far
-// below 2^15: class scores are clamped to >= -255.)  W's low half is the largest drop seen at a field end; the drop test
-// (:374 / :523) is looked at once per side on it.  A side that has dropped is NOT frozen -- it walks on to the end of its context,
-// which can only raise its best score (still an upper bound), and all 19 table reads of a buffer are independent of the scores.
+// The walk is kept as (T, N) in ONE register, two int16: T = running score, N = T - best <= 0 (minus the current drop).  A field
+// with score `sum` and largest prefix score `mx` does  T' = T + sum,  N' = min(N + sum, sum - mx)  -- two VALU ops on a 4-byte
+// table entry {sum : sum - mx} (cls_step below; |T| and |N| stay far below 2^15: class scores are clamped to >= -255).  A side is
+// NOT stopped or frozen when it drops (:374 / :523): it walks on to the end of its context, which can only raise its best score
+// (still an upper bound), so all 19 table reads of a buffer are independent of the scores and the code is straight-line.  W keeps
+// the lowest N seen at a field end: "alive" = never more than xdrop below the best at a field end.  (Asking only at the end of the
+// context -- N_end >= -xdrop, implied by the former, so it errs on the forwarding side -- saves one op per field and forwards 6.3 %
+// instead of 4.6 % of the hits: the second level then costs 0.08 ms more per call than the filter saves.)
+// What bounds the kernel (profiles/r03, tools/pmc_mem.sh): the L1's miss path.  A CU has ~57 lines of 128 bytes in flight at
+// an L1->L2 read latency of ~840 cycles under this load (TCP_TCC_READ_REQ_LATENCY / TCP_TCC_READ_REQ; TCP_PENDING_STALL_CYCLES is
+// 61 % of the kernel's cycles), i.e. ~9 bytes per cycle and CU = 5.1 TB/s for the chip -- what tools/micro/stream_rec.hip gets for
+// the same 32-byte record stream with no arithmetic at all (5.8 TB/s).  Measured on this kernel, each changing NOTHING in its
+// duration: 12 % fewer VALU instructions (no W), half the LDS bytes (these 4-byte entries instead of 8-byte ones; the LDS pipe
+// went from 65 % to ~35 % busy), the next buffer's records requested one iteration ahead.  They are kept because the kernel then
+// leaves more of the CU to the kernels of the other calls in flight (0.96 -> 1.04 Gbp/s for the whole pass).  Only fewer LINES
+// per hit would make it faster: reading half of every record did not (same lines, -9 % from the smaller loads alone).
 // Why the bound holds: with u_i >= s_i pointwise the bounded walk's drop max_i<=k(Q_i) - Q_k never exceeds the exact walk's, so it
 // cannot stop earlier, and its best is taken over a superset of positions.  Codes >= 4 (soft-masked, N, separators, other IUPAC
 // letters) are stored as code 0 on both sides; cls[] covers every matrix entry such a pair could have had, for the codes that
@@ -879,30 +888,31 @@ constexpr int CTX_STAGE_FLUSH = 32;                    // forwards are rare (~4 
 constexpr int CTX_STAGE_CAP = CTX_STAGE_FLUSH - 1 + 64 + 1;  // 96 records of 20 bytes per wave
 constexpr int CLS_TAB = 4096;                       // 12-bit fields: six bases
 constexpr int CLS_TAIL = 256;                       // the left context ends with a four-base field (64 = 10 x 6 + 4)
-constexpr int CLS_LDS_DWORDS = 2 * (CLS_TAB + CLS_TAIL);
+constexpr int CLS_LDS_DWORDS = CLS_TAB + CLS_TAIL;  // 4-byte entries: 16 KB + 1 KB
+constexpr bool CLS_TRACK_DROP = true;               // keep the lowest N seen at a field end (see cls_step)
 
+// entry of a field: {sum : sum - mx} as two int16 (sum = score of the field, mx = its largest prefix score, >= 0)
 __device__ __forceinline__ void cls_table_init(uint32_t* __restrict__ s_cls, const int* cls, int nthreads) {
     const int c0 = cls[0], c1 = cls[1], c2 = cls[2], c3 = cls[3];
     for (int i = threadIdx.x; i < CLS_TAB + CLS_TAIL; i += nthreads) {
         const int nb = i < CLS_TAB ? 6 : 4;
         const int f = i < CLS_TAB ? i : i - CLS_TAB;
-        int sum = 0, mx = INT32_MIN;
+        int sum = 0, mx = 0;  // (a negative prefix never raises the best score)
         for (int k = 0; k < nb; k++) {
             const int x = (f >> (2 * k)) & 3;
             sum += x == 0 ? c0 : x == 1 ? c1 : x == 2 ? c2 : c3;
             mx = max(mx, sum);
         }
-        s_cls[2 * i] = (uint32_t)(sum * 65535);                  // the step's addend (see above)
-        s_cls[2 * i + 1] = 0x80000000u | (uint32_t)max(mx, 0);   // {INT16_MIN : max prefix}; a negative prefix never raises D
+        s_cls[i] = ((uint32_t)sum << 16) | ((uint32_t)(sum - mx) & 0xFFFFu);
     }
 }
 
-// byte address (inside a table of 8-byte entries) of the 12-bit field that starts at bit O of the dword string w0 | w1 << 32
+// byte address (inside a table of 4-byte entries) of the 12-bit field that starts at bit O of the dword string w0 | w1 << 32
 template <int O>
 __device__ __forceinline__ uint32_t cls_field_addr(uint32_t w0, uint32_t w1) {
-    constexpr uint32_t MASK = 0x7FF8u;
-    if (O + 12 <= 32) return O >= 3 ? ((w0 >> (O - 3)) & MASK) : ((w0 << (3 - O)) & MASK);
-    return __builtin_amdgcn_alignbit(w1, w0, (uint32_t)(O - 3)) & MASK;  // the field straddles the two dwords
+    constexpr uint32_t MASK = 0x3FFCu;
+    if (O + 12 <= 32) return O >= 2 ? ((w0 >> (O - 2)) & MASK) : ((w0 << (2 - O)) & MASK);
+    return __builtin_amdgcn_alignbit(w1, w0, (uint32_t)(O - 2)) & MASK;  // the field straddles the two dwords
 }
 
 __device__ __forceinline__ uint32_t mul24(uint32_t x, uint32_t s_uniform) {  // full-rate 24-bit multiply (v_mul_lo_u32 is quarter rate)
@@ -911,21 +921,31 @@ __device__ __forceinline__ uint32_t mul24(uint32_t x, uint32_t s_uniform) {  // 
     return r;
 }
 
-typedef short cls_s16x2 __attribute__((ext_vector_type(2)));
-// one field: P = {T : D} packed, W = running maximum of P's halves (its low half: the largest drop seen at a field end)
+// One field.  P = {T : N} as two int16: T = running score, N = T - best <= 0 (minus the current drop).  With the field's
+// (sum, mx):  T' = T + sum,  N' = min(N + sum, sum - mx)   [= -(max(D, mx) - sum) for D = -N]
+//   v_pk_add_i16 with op_sel adds the entry's HIGH half (sum) to both halves of P;
+//   v_min_i16 (SDWA, destination's other half preserved) takes the low half against the entry's low half (sum - mx).
+// Two VALU and one 4-byte LDS read per six bases.  (Round 3 started with 8-byte entries {sum * 65535, INT16_MIN : mx} and
+// P = pk_max(P, mxw) + add: the same two ops, but a wave's 64 random 8-byte reads keep the LDS pipe busy ~8.6 cycles each --
+// SQ_LDS_IDX_ACTIVE was 65 % of the kernel's cycles, 70 % of them bank conflicts -- and the LDS, not the VALU or the record
+// stream, set the pace: 12 % fewer VALU instructions changed nothing, half the record bytes 9 %.)
+// W (CLS_TRACK_DROP): the lowest N seen at a field end, one more v_pk_min per field.
 __device__ __forceinline__ void cls_step(const uint32_t* __restrict__ s_tab, uint32_t addr, uint32_t& P, uint32_t& W) {
-    const uint64_t e64 = *reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(s_tab) + addr);  // one ds_read_b64 (entries are 8-byte aligned)
-    const uint32_t add = (uint32_t)e64, mxw = (uint32_t)(e64 >> 32);
-    P = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(cls_s16x2, P), __builtin_bit_cast(cls_s16x2, mxw))) + add;
-    W = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(cls_s16x2, W), __builtin_bit_cast(cls_s16x2, P)));
+    const uint32_t e = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_tab) + addr);
+    asm("v_pk_add_i16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(P) : "v"(P), "v"(e));
+    asm("v_min_i16_sdwa %0, %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0" : "+v"(P) : "v"(e));
+    if (CLS_TRACK_DROP) {
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        W = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s16x2, W), __builtin_bit_cast(s16x2, P)));
+    }
 }
 
 __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(ExtendArgs a) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_cls[CLS_LDS_DWORDS];  // 8-byte entry per 6-base class field (32 KB) + the 4-base tail fields (2 KB)
+    __shared__ __attribute__((aligned(16))) uint32_t s_cls[CLS_LDS_DWORDS];  // 4-byte entry per 6-base class field (16 KB) + the 4-base tail fields (1 KB)
     extern __shared__ L2Rec s_l2_dyn[];          // [waves of the workgroup][CTX_STAGE_CAP]
     cls_table_init(s_cls, a.cls, (int)blockDim.x);
     __syncthreads();
-    const uint32_t* __restrict__ s_tail = s_cls + 2 * CLS_TAB;
+    const uint32_t* __restrict__ s_tail = s_cls + CLS_TAB;
     L2Rec* stage = s_l2_dyn + (threadIdx.x >> 6) * CTX_STAGE_CAP;
     int n_stage = 0;
     const int lane = threadIdx.x & 63;
@@ -951,11 +971,9 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(E
     // word, a running scalar count and two v_mbcnt -- no search, no shuffles (the TdCursor of 1b spends six ds_bpermute + ~40
     // VALU per buffer on the same question).  td_chunk gives the count at the wave's first hit.  The map is read through the
     // constant address space: a wave-uniform address there is a SCALAR load (s_load_dwordx2), no VALU or vector-memory slot.
-    // Latency: the head word is fetched three buffers ahead and the TdRec gather one buffer ahead, so inside an iteration a wave
-    // only waits for its own record stream, which the other seven waves of the SIMD cover.  (Requesting the records one buffer
-    // ahead as well -- two register sets, 55 VGPRs -- measured 4 % SLOWER: the kernel is bound by VALU issue, not by bytes in
-    // flight; profiles/r03.)  Requests past the wave's range read valid memory (the next wave's buffers, the map's zero words, a
-    // page of slack behind the table) and are never used -- conditional loads would turn every s_waitcnt of the loop into a drain.
+    // Latency: the head word is fetched four buffers ahead, the TdRec gather two and the records one buffer ahead (see the loop).
+    // Requests past the wave's range read valid memory (the next wave's buffers, the map's zero words, 16 KB of slack behind the
+    // table) and are never used -- conditional loads would turn every s_waitcnt of the loop into a drain.
     typedef const uint64_t __attribute__((address_space(4))) * HeadPtr;
     HeadPtr head = (HeadPtr)a.td_bits;
     const uint32_t stride16 = (uint32_t)(a.q2_stride >> 4) & 0xFFFFFFu;  // (the sixteen copies of a strand stay below 4 GB, engine.hip)
@@ -971,12 +989,13 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(E
         uint32_t qr0, qr1, qr2;
         uint32_t query_loc;
     };
-    uint64_t B2, B3;  // head words of the buffers one and two ahead of the one being requested
-    TdRec hnext;      // TdRec of this lane's hit in the NEXT buffer to be requested
-    auto advance_map = [&](uint64_t b_req) {  // after the request of buffer b_req: gather for b_req + 1, map word for b_req + 3
-        hnext = a.td_rec[locate(B2)];
-        B2 = B3;
-        B3 = head[b_req + 3];
+    uint64_t w0, w1, w2;  // head words of the buffers one, two and three ahead of the one being requested
+    TdRec hnext;          // TdRec of this lane's hit in the NEXT buffer to be requested
+    auto advance_map = [&](uint64_t b_req) {  // after the request of buffer b_req: gather for b_req + 1, map word for b_req + 4
+        hnext = a.td_rec[locate(w0)];
+        w0 = w1;
+        w1 = w2;
+        w2 = head[b_req + 4];
     };
     auto request = [&](uint64_t b, Stage& S) {  // uses hnext = record of buffer b
         // (lanes past the call's last hit stay on the last record and run up to 63 entries past its run: still inside the table
@@ -1015,8 +1034,9 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(E
         cls_step(s_cls, cls_field_addr<28>(x1, x2), P, Wd);
         cls_step(s_cls, cls_field_addr<8>(x2, 0u), P, Wd);
         cls_step(s_cls, cls_field_addr<20>(x2, 0u), P, Wd);
-        const bool r_alive = (int)(Wd & 0xFFFFu) <= xdrop;       // never dropped at a field end (:374)
-        const int bestR = ((int)P >> 16) + (int)(P & 0xFFFFu);  // T + D
+        // alive: never more than xdrop below its best at a field end (:374; without W: at the end of the context)
+        const bool r_alive = (int)(short)((CLS_TRACK_DROP ? Wd : P) & 0xFFFFu) >= -xdrop;
+        const int bestR = ((int)P >> 16) - (int)(short)(P & 0xFFFFu);  // best = T - N
         // ---- left side (:478-604): 64 bases = 10 fields + a four-base tail ----
         P = 0; Wd = 0;
         cls_step(s_cls, cls_field_addr<0>(y0, y1), P, Wd);
@@ -1029,9 +1049,9 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(E
         cls_step(s_cls, cls_field_addr<20>(y2, y3), P, Wd);
         cls_step(s_cls, cls_field_addr<0>(y3, 0u), P, Wd);
         cls_step(s_cls, cls_field_addr<12>(y3, 0u), P, Wd);
-        cls_step(s_tail, (y3 >> 21) & 0x7F8u, P, Wd);
-        const bool l_alive = (int)(Wd & 0xFFFFu) <= xdrop;       // (:523)
-        const int bestL = ((int)P >> 16) + (int)(P & 0xFFFFu);
+        cls_step(s_tail, (y3 >> 22) & 0x3FCu, P, Wd);
+        const bool l_alive = (int)(short)((CLS_TRACK_DROP ? Wd : P) & 0xFFFFu) >= -xdrop;  // (:523)
+        const int bestL = ((int)P >> 16) - (int)(short)(P & 0xFFFFu);
         const bool fwd = !skip && (r_alive || l_alive || classify(a, bestR + bestL) != 0);
         // what is known travels with the anchor (kernels.h L2Rec): level 2 walks only what is still open
         const unsigned long long fm = __ballot(fwd);
@@ -1040,7 +1060,7 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(E
             cr.ref_loc = ref_loc;
             cr.query_loc = query_loc;
             cr.hidx = (uint32_t)(b << 6) + (uint32_t)lane;
-            cr.state = P;  // (the left walk's packed state: used when only the left side is open)
+            cr.state = (P & 0xFFFF0000u) | ((0u - P) & 0xFFFFu);  // the left walk's state as {T : D = -N}: used when only the left side is open
             const uint32_t fl = (r_alive ? 1u : 0u) | (l_alive ? 2u : 0u);  // 0 (both settled, the bound passes) -> 3: level 2 re-walks both
             cr.meta = (uint32_t)(r_alive ? bestL : bestR) | ((fl ? fl : 3u) << 16);
             // -> the wave's LDS stage (rank by v_mbcnt on the ballot), flushed 64 records at a time
@@ -1067,18 +1087,29 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(E
             wave_append(valid && !skip && !fwd, ar, a.audit_list, a.audit_count, a.audit_cap, lane, lane_lt);
         }
     };
+    // Software pipeline, two register sets: while buffer b is scored the records and query windows of buffer b + 1 are in
+    // flight, the position-record gather of b + 2 and the map word of b + 5.  A wave alone keeps only one buffer's loads in flight;
+    // at 8 waves per SIMD that left the kernel waiting for memory latency (half the record bytes: -9 %; 12 % fewer VALU
+    // instructions: -0 %), not for bandwidth or issue slots.
+    Stage SA, SB;
     {
-        const uint64_t B0 = head[b_lo], B1 = head[b_lo + 1];
-        cbefore = a.td_chunk[c_lo] + 1u - (uint32_t)(B0 & 1ull);
-        hnext = a.td_rec[locate(B0)];
-        B2 = B1;
-        B3 = head[b_lo + 2];
+        const uint64_t h0 = head[b_lo];
+        w0 = head[b_lo + 1];
+        w1 = head[b_lo + 2];
+        w2 = head[b_lo + 3];
+        cbefore = a.td_chunk[c_lo] + 1u - (uint32_t)(h0 & 1ull);
+        hnext = a.td_rec[locate(h0)];
+        request(b_lo, SA);
+        advance_map(b_lo);  // hnext = record of b_lo + 1
     }
-    for (uint64_t b = b_lo; b < b_hi; b++) {
-        Stage S;
-        request(b, S);
-        advance_map(b);
-        score(b, S);
+    for (uint64_t b = b_lo; b < b_hi; b += 2) {
+        request(b + 1, SB);
+        advance_map(b + 1);
+        score(b, SA);
+        if (b + 1 >= b_hi) break;
+        request(b + 2, SA);
+        advance_map(b + 2);
+        score(b + 1, SB);
     }
     stage_flush(stage, n_stage, my_list, my_count, a.l2_cap, lane);
 }

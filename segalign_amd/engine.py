@@ -47,7 +47,7 @@ class CallStats(C.Structure):
     _fields_ = [("num_seeds", C.c_uint64), ("num_hits", C.c_uint64), ("num_survivors", C.c_uint64),
                 ("num_anchors", C.c_uint64), ("num_examined", C.c_uint64), ("num_examined_filter", C.c_uint64),
                 ("num_candidates", C.c_uint64), ("num_entropy", C.c_uint64), ("num_iter", C.c_uint32),
-                ("device", C.c_int), ("lookup_path", C.c_int), ("reserved", C.c_int)]
+                ("device", C.c_int), ("lookup_path", C.c_int), ("reserved", C.c_int), ("num_forwarded", C.c_uint64)]
 
 
 _lib = None

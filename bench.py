@@ -50,6 +50,7 @@ sys.path.insert(0, ROOT)
 
 SHAPE = "TTT0T00TT00T0T0TTTT"  # 12of19, src/main.cpp:160-163
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+STREAM_GBS = 6200.0            # measured on MI355X: what a pure sequential read of 32-byte records reaches (tools/micro/stream_rec2.hip)
 RANDOM_LINES_PER_S = 57e9      # measured on MI355X: random 128-byte line gathers per second (tools/micro/gather_bw.hip)
 FILTER_KERNELS = {0: "extend_filter_kernel", 1: "extend_filter_kernel", 3: "extend_filter_packed_kernel"}
 # event scope of the engine (sa_profile_*) -> device kernels launched inside it (names as rocprofv3 prints them)
@@ -512,6 +513,9 @@ def roofline(args, E, wl, prof, call_stats, run_step, run_job, jobs, elapsed, wo
         "single_stream": single,
         "traffic": traffic, "traffic_source": traffic_src, "profile_check": check,
         "traffic_frac_single_stream": round(traffic / (1e3 * s_ms / max(s_n, 1) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if (traffic and s_ms and s_n) else None,
+        # the same bytes against what a kernel that ONLY streams 32-byte records reaches on this GPU (6.2 of the 8.0 TB/s)
+        "traffic_frac_of_stream_ceiling": round(traffic / (1e3 * s_ms / max(s_n, 1) * 1e-6) / 1e9 / STREAM_GBS, 4) if (traffic and s_ms and s_n) else None,
+        "stream_ceiling_gbs": STREAM_GBS,
         "counters": counters,
         "dominant_share_of_gpu_time": round(ms / gpu_ms, 4) if gpu_ms else None,
         "per_step": {"ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 3),

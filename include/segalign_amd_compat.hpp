@@ -77,6 +77,19 @@ typedef void (*ClearQuery_ptr)(uint32_t buffer);
 
 static_assert(sizeof(segmentPair) == sizeof(sa_segment_pair), "segmentPair layout (src/graph.h:25-30)");
 
+// Flavour guard.  The two binaries declare the SAME g_* names with different signatures, selected above per translation unit; a TU
+// of the repeat-masker binary that includes this header without SEGALIGN_AMD_COMPAT_RM would see the src/ signatures for the same
+// symbols -- a silent type mismatch.  Every TU therefore references a symbol named after ITS flavour, and only the TU that defines
+// the pointers (SEGALIGN_AMD_COMPAT_DEFINE / _DEFINE_RM) defines the one of its own flavour: mixed inclusion fails at link time
+// with "undefined reference to segalign_amd_compat_flavour_...".
+#if defined(SEGALIGN_AMD_COMPAT_RM) || defined(SEGALIGN_AMD_COMPAT_DEFINE_RM)
+extern "C" const int segalign_amd_compat_flavour_repeat_masker;
+namespace { __attribute__((used)) const int* const segalign_amd_compat_flavour_ref = &segalign_amd_compat_flavour_repeat_masker; }
+#else
+extern "C" const int segalign_amd_compat_flavour_src;
+namespace { __attribute__((used)) const int* const segalign_amd_compat_flavour_ref = &segalign_amd_compat_flavour_src; }
+#endif
+
 namespace segalign_amd_compat {
 
 // Where SendQueryWriteRequest finds the query arena.  The reference reads the global `query_DRAM->buffer`
@@ -168,6 +181,7 @@ SendQueryWriteRequest_ptr g_SendQueryWriteRequest = segalign_amd_compat::RmSendQ
 SeedAndFilter_ptr g_SeedAndFilter = segalign_amd_compat::RmSeedAndFilter;                      // :985
 ClearQuery_ptr g_ClearQuery = segalign_amd_compat::RmClearQuery;                               // :986
 ShutdownProcessor_ptr g_ShutdownProcessor = segalign_amd_compat::ShutdownProcessor;            // :987
+extern "C" const int segalign_amd_compat_flavour_repeat_masker = 1;                           // (flavour guard, see above)
 #endif
 
 #ifdef SEGALIGN_AMD_COMPAT_DEFINE
@@ -180,6 +194,7 @@ SendQueryWriteRequest_ptr g_SendQueryWriteRequest = segalign_amd_compat::SendQue
 SeedAndFilter_ptr g_SeedAndFilter = segalign_amd_compat::SeedAndFilter;                        // :944
 ClearQuery_ptr g_ClearQuery = segalign_amd_compat::ClearQuery;                                 // :945
 ShutdownProcessor_ptr g_ShutdownProcessor = segalign_amd_compat::ShutdownProcessor;            // :946
+extern "C" const int segalign_amd_compat_flavour_src = 1;                                     // (flavour guard, see above)
 #endif
 
 #if defined(SEGALIGN_AMD_COMPAT_DEFINE) || defined(SEGALIGN_AMD_COMPAT_DEFINE_RM)

@@ -259,21 +259,32 @@ def main():
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(inflight)  # the reference keeps one seeder body per TBB thread in flight (src/main.cpp:565-573)
 
-    def run_step(k, collect=None, threads=None):
-        """strong: this rank's share of the calls of ONE pass over the query block; weak: all of them, from a rank-dependent start.
-        Plain workloads hand the call list to the engine's own worker pool (sa_seed_calls: `inflight` calls in flight on C++
-        threads, like the reference's TBB seeder bodies); the repeat masker's interval tasks are issued from a Python pool."""
-        todo = shard.partition(jobs, rank, world) if scaling == "strong" else rotate(jobs, rank + k)
+    def step_jobs(k):
+        """strong: this rank's share of the calls of ONE pass over the query block; weak: all of them, from a rank-dependent start"""
+        return shard.partition(jobs, rank, world) if scaling == "strong" else rotate(jobs, rank + k)
+
+    def run_steps(ks, collect=None, threads=None):
+        """The passes `ks` as ONE list of calls: the calls of consecutive passes follow each other without a drain in between, as the
+        intervals of consecutive query blocks do in the host (src/main.cpp:601-737 keeps its seeder threads busy across blocks).
+        Plain workloads hand the list to the engine's own worker pool (sa_seed_calls: `inflight` calls in flight on C++ threads,
+        like the reference's TBB seeder bodies); the repeat masker's interval tasks are issued from a Python pool.
+        -> (query bases, HSPs, checksum of the LAST pass)"""
+        per = [step_jobs(k) for k in ks]
+        todo = [j for p in per for j in p]
+        last0 = len(todo) - len(per[-1]) if per else 0
         if wl["rm"]:
             res = [run_job(j, collect) for j in todo] if threads == 1 else list(pool.map(lambda j: run_job(j, collect), todo))
-            return sum(r[0] for r in res), sum(r[1] for r in res), sum(r[2] for r in res) % CHECK_MOD
+            return sum(r[0] for r in res), sum(r[1] for r in res), sum(r[2] for r in res[last0:]) % CHECK_MOD
         outs, st = E.SeedCalls([(j["a"], j["b"], j["rev"]) for j in todo], 0, threads or inflight)
         if collect is not None:
             collect.append(st)
         chk = 0
-        for j, o in zip(todo, outs):
+        for j, o in zip(todo[last0:], outs[last0:]):
             chk = (chk + shard.hsp_checksum(o, j["rev"])) % CHECK_MOD
         return sum(j["b"] - j["a"] for j in todo if not j["rev"]), sum(int(o.size) for o in outs), chk
+
+    def run_step(k, collect=None, threads=None):
+        return run_steps([k], collect, threads)
 
     if args.one_interval:
         first = [j for j in jobs if j.get("rm") or j["interval"] == 0] if not wl["rm"] else jobs[:1]
@@ -297,17 +308,12 @@ def main():
     call_stats = []
     barrier()
     t0 = time.perf_counter()
-    bases = hsps = 0
-    check = 0
-    for k in range(args.steps):
-        b, h, c = run_step(k, call_stats)
-        bases += b
-        hsps += h
-        check = c  # (every step is the same pass: keep one)
+    bases, hsps, check = run_steps(list(range(args.steps)), call_stats)  # (every step is the same pass: the checksum of one is kept)
     barrier()
     elapsed = time.perf_counter() - t0
     E.profile_enable(False)
     prof = E.profile_entries()
+    busy = {k: E.profile_busy_ms(k) for k in prof}  # per scope: ms with at least one launch running (the slots' launches overlap)
 
     # max over ranks, sums of bases / HSPs / checksum
     if dist is not None:
@@ -323,11 +329,12 @@ def main():
         E.profile_enable(True)
         call_stats = []
         run_step(0, call_stats)
+        busy = {}
         E.profile_enable(False)
         prof = E.profile_entries()
     roof = None
     if rank == 0 and prof and not args.no_roofline:
-        roof = roofline(args, E, wl, prof, call_stats, run_step, run_job, jobs, elapsed, world)
+        roof = roofline(args, E, wl, prof, busy, call_stats, run_step, run_job, jobs, elapsed, world)
         if not wl["rm"] and not args.no_dropin:
             roof["dropin"] = dropin_leg(E, jobs, args, seed_size, 13 if wl["transition"] else 1)
 
@@ -384,14 +391,16 @@ def main():
 # ------------------------------------------------------------------------------------------------------------------
 # roofline block
 # ------------------------------------------------------------------------------------------------------------------
-def roofline(args, E, wl, prof, call_stats, run_step, run_job, jobs, elapsed, world):
+def roofline(args, E, wl, prof, busy, call_stats, run_step, run_job, jobs, elapsed, world):
     """The dominant kernel against the HBM roofline, honest by construction.
 
-    `achieved` = bytes the kernel's data layout makes it MOVE per launch (stated per unit in DESIGN.md 4.5: 32 B of context record
-    per hit + 16 B of position record per non-empty query position + 1 bit per hit of head map + 20 B per forwarded hit), from the
-    exact per-call counts, divided by the kernel's average launch duration from HIP events on the engine's own streams over the
-    timed region.  These are bytes that really cross the memory system, so frac <= 1; the PMC-measured HBM bytes of the committed
-    rocprofv3 collection stand beside it (`traffic`).  SURVEY 8(d)'s reference-layout figure (8*H + 2*E + 20*A: one byte per
+    `achieved` = bytes the kernel's data layout makes it MOVE (stated per unit in DESIGN.md 4.5: 32 B of context record per hit +
+    16 B of position record per non-empty query position + 1 bit per hit of head map + 20 B per forwarded hit), from the exact
+    per-call counts over the timed region, divided by the time during which the kernel was RUNNING in the timed region -- the union
+    of its launches' [start, end] from HIP events on the engine's own streams.  Four calls are in flight, so launches of the same
+    kernel overlap and share the GPU: bytes per launch / average launch duration (kept as `per_launch`) then measures the sharing,
+    not the kernel -- with one call in flight the two definitions coincide (`single_stream`).  These are bytes that really cross the
+    memory system, so frac <= 1; the PMC-measured HBM bytes of the committed rocprofv3 collection stand beside it (`traffic`).  SURVEY 8(d)'s reference-layout figure (8*H + 2*E + 20*A: one byte per
     examined base and sequence) is kept as `algorithmic_equiv` -- the packed design deliberately never moves those bytes, so it
     is an equivalence, not a bandwidth."""
     # the same kernels without a second call overlapping them: one extra (untimed) pass with ONE call in flight
@@ -451,7 +460,9 @@ def roofline(args, E, wl, prof, call_stats, run_step, run_job, jobs, elapsed, wo
                                 else "%g*H + 12*C" % (4.0 if table_direct else 8.0),
                "extend_filter2": "20*F + 12*C", lookup_scope: "37*P  (9 B codes + 12 B scratch + 16 B extent per position)" if table_direct else "16*S",
                "expand_hits": "12*H"}.get(name)
-    achieved = rate(mv_t[name], ms) if name in mv_t else None
+    per_launch = rate(mv_t[name], ms) if name in mv_t else None          # literal: bytes per launch / average launch duration
+    busy_ms = busy.get(name) or None
+    achieved = rate(mv_t[name], busy_ms) if (name in mv_t and busy_ms) else per_launch
     s_ms = solo[name][0] if name in solo else None
     s_n = solo[name][1] if name in solo else 0
     single = None
@@ -506,10 +517,15 @@ def roofline(args, E, wl, prof, call_stats, run_step, run_job, jobs, elapsed, wo
     return {
         "bound": bound, "kernel": name, "kernel_symbol": symbol, "bytes": formula,
         "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac(achieved),
+        "definition": "bytes the dominant kernel moved in the timed region / time with at least one of its launches running (union over the "
+                      "engine's streams, HIP events); per_launch = bytes per launch / average launch duration (launches of the calls in "
+                      "flight overlap, so it measures how the GPU is shared); single_stream = one call in flight, where both coincide",
+        "busy_ms": round(busy_ms, 3) if busy_ms else None,
+        "busy_share_of_timed_region": round(busy_ms / (1e3 * elapsed), 4) if busy_ms else None,
         "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
         "bytes_per_launch": round(mv_t[name] / max(launches, 1)) if name in mv_t else None,
-        "note": "timed region: %d calls in flight share the GPU, so a launch's duration includes the time it waits for CUs held by "
-                "the other calls' kernels; single_stream is the same kernel alone" % (max(1, args.host_threads) * max(1, args.intervals_in_flight)),
+        "per_launch": {"achieved": round(per_launch, 1) if per_launch else None, "frac": frac(per_launch),
+                       "calls_in_flight": max(1, args.host_threads) * max(1, args.intervals_in_flight)},
         "single_stream": single,
         "traffic": traffic, "traffic_source": traffic_src, "profile_check": check,
         "traffic_frac_single_stream": round(traffic / (1e3 * s_ms / max(s_n, 1) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if (traffic and s_ms and s_n) else None,

@@ -259,6 +259,10 @@ void sa_profile_reset(void);
 int sa_profile_num_entries(void);
 /* returns 0 on success; name is NUL-terminated into name_buf */
 int sa_profile_get(int i, char* name_buf, size_t name_cap, double* total_ms, uint64_t* launches);
+/* ms during which at least one launch of scope `name` was running (union over the slots' streams, summed over devices) since
+ * the last sa_profile_reset: with several calls in flight the launches of one kernel overlap, and bytes / this time is the rate
+ * the kernel sustained while it ran. */
+double sa_profile_busy_ms(const char* name);
 
 /* Device -> host copies of engine state on device `dev` (parity tests). */
 uint32_t sa_get_ref_len(void);

@@ -178,14 +178,21 @@ struct PackedBuf {  // phase copies of a packed sequence (packed X-drop filter):
 // ------------------------------------------------------------------------------------------------------------------
 // profiling: HIP events on the engine's own streams
 // ------------------------------------------------------------------------------------------------------------------
+struct ProfSpan {
+    int dev;
+    float t0, t1;  // ms since the device's epoch event
+};
 struct ProfEntry {
     std::string name;
     double total_ms = 0;
     uint64_t launches = 0;
+    std::vector<ProfSpan> spans;  // when every launch ran (several slots overlap): sa_profile_busy_ms
 };
 static std::mutex g_prof_mu;
 static std::vector<ProfEntry> g_prof;
 static bool g_prof_on = false;
+constexpr int PROF_MAX_DEV = 16;
+static hipEvent_t g_prof_epoch[PROF_MAX_DEV] = {};  // per device: recorded by sa_profile_reset
 static int g_trace_scopes = 0;  // option debug >= 2: synchronise after every kernel scope and name it on stderr (fault localisation)
 
 struct Slot;
@@ -609,6 +616,11 @@ static void prof_flush(Slot* sl) {  // call after the slot's stream has been syn
         if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
             g_prof[r.id].total_ms += ms;
             g_prof[r.id].launches += 1;
+            float t0 = 0;
+            if (sl->dev >= 0 && sl->dev < PROF_MAX_DEV && g_prof_epoch[sl->dev] &&
+                hipEventElapsedTime(&t0, g_prof_epoch[sl->dev], r.e0) == hipSuccess)
+                g_prof[r.id].spans.push_back({sl->dev, t0, t0 + ms});
+            else (void)hipGetLastError();
         }
     }
     sl->prof_pending.clear();
@@ -2736,8 +2748,36 @@ int sa_get_lookup_mode(void) {  // how device-seeded calls look seeds up on devi
 uint64_t sa_get_neighbourhood_entries(void) { return (g_ndev > 0 && g_dev[0]->nbr_state == 1) ? g_dev[0]->nbr_total : 0; }
 void sa_profile_enable(int on) { g_prof_on = on != 0; }
 void sa_profile_reset(void) {
+    for (auto* dc : g_dev) {  // a fresh epoch per device: launch times are kept relative to it
+        if (dc->dev < 0 || dc->dev >= PROF_MAX_DEV) continue;
+        check_set_device(dc->dev, "profile reset");
+        if (!g_prof_epoch[dc->dev] && hipEventCreate(&g_prof_epoch[dc->dev]) != hipSuccess) { g_prof_epoch[dc->dev] = nullptr; continue; }
+        hipEventRecord(g_prof_epoch[dc->dev], dc->admin);
+        hipEventSynchronize(g_prof_epoch[dc->dev]);
+    }
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (auto& e : g_prof) { e.total_ms = 0; e.launches = 0; }
+    for (auto& e : g_prof) { e.total_ms = 0; e.launches = 0; e.spans.clear(); }
+}
+// Time during which AT LEAST ONE launch of scope `name` was running (union of its launches' [start, end] over all slots; summed
+// over devices).  With several calls in flight a launch's own duration says how long it shared the GPU, not how fast it is.
+double sa_profile_busy_ms(const char* name) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& e : g_prof) {
+        if (e.name != name) continue;
+        std::vector<ProfSpan> v = e.spans;
+        std::sort(v.begin(), v.end(), [](const ProfSpan& a, const ProfSpan& b) { return a.dev != b.dev ? a.dev < b.dev : a.t0 < b.t0; });
+        double busy = 0;
+        size_t i = 0;
+        while (i < v.size()) {
+            float lo = v[i].t0, hi = v[i].t1;
+            size_t j = i + 1;
+            while (j < v.size() && v[j].dev == v[i].dev && v[j].t0 <= hi) { hi = std::max(hi, v[j].t1); j++; }
+            busy += hi - lo;
+            i = j;
+        }
+        return busy;
+    }
+    return 0.0;
 }
 int sa_profile_num_entries(void) {
     std::lock_guard<std::mutex> lk(g_prof_mu);

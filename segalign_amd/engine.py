@@ -31,7 +31,7 @@ C_ABI_SYMBOLS = [
     "sa_clear_query", "sa_seed_and_filter", "sa_seed_and_filter_range", "sa_free_segments",
     "sa_rm_send_query_write_request", "sa_rm_clear_query", "sa_rm_seed_and_filter", "sa_set_max_hits",
     "sa_get_max_hits", "sa_max_hits_for_mem", "sa_get_last_call_stats", "sa_set_count_examined",
-    "sa_profile_enable", "sa_profile_reset", "sa_profile_num_entries", "sa_profile_get", "sa_get_ref_len",
+    "sa_profile_enable", "sa_profile_reset", "sa_profile_num_entries", "sa_profile_get", "sa_profile_busy_ms", "sa_get_ref_len",
     "sa_get_num_index", "sa_get_index_table_size", "sa_copy_ref_codes", "sa_copy_index_table", "sa_copy_pos_table",
     "sa_copy_query_codes", "sa_get_query_len", "sa_device_make_seeds", "sa_version",
     "sa_rm_mask_interval", "sa_rm_coverage_intervals", "sa_free_intervals", "sa_get_filter_mode",
@@ -101,6 +101,8 @@ def lib():
     L.sa_profile_num_entries.restype = C.c_int
     L.sa_profile_get.restype = C.c_int
     L.sa_profile_get.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.sa_profile_busy_ms.restype = C.c_double
+    L.sa_profile_busy_ms.argtypes = [C.c_char_p]
     for f in ("sa_get_ref_len", "sa_get_num_index", "sa_get_index_table_size"):
         getattr(L, f).restype = C.c_uint32
     L.sa_get_query_len.restype = C.c_uint32
@@ -380,6 +382,11 @@ def profile_entries():
         if L.sa_profile_get(i, name, 64, C.byref(ms), C.byref(n)) == 0:
             out[name.value.decode()] = (ms.value, n.value)
     return out
+
+
+def profile_busy_ms(name):
+    """ms during which at least one launch of the scope was running (union over the slots' streams)."""
+    return float(lib().sa_profile_busy_ms(name.encode()))
 
 
 def copy_ref_codes(dev=0):

@@ -486,11 +486,17 @@ def roofline(args, E, wl, prof, busy, call_stats, run_step, run_job, jobs, elaps
             "lds_wave_insts_per_64_hits": round(c["SQ_INSTS_LDS"] / (hits_per_launch / 64.0), 1) if (hits_per_launch and "SQ_INSTS_LDS" in c) else None,
             "lds_conflict_frac": round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], 3) if c.get("SQ_LDS_IDX_ACTIVE") else None,
             "wait_frac": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3) if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in c else None,
-            # VALU busy share of a SIMD: active VALU quad-cycles over the quad-cycles its (up to) 8 resident waves existed / 8
-            "valu_busy_frac": round(8.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"], 3) if c.get("SQ_WAVE_CYCLES") and "SQ_ACTIVE_INST_VALU" in c else None,
+            # VALU busy share of a SIMD: a wave64 VALU instruction occupies its SIMD for 4 cycles (SQ_ACTIVE_INST_VALU counts them);
+            # the kernel's cycles per SIMD = GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8; 1024 SIMDs
+            "valu_busy_frac": round(4.0 * c["SQ_ACTIVE_INST_VALU"] / 1024.0 / (c["GRBM_GUI_ACTIVE"] / 8.0), 3)
+                              if c.get("GRBM_GUI_ACTIVE") and "SQ_ACTIVE_INST_VALU" in c else None,
+            "lds_busy_frac": round(c["SQ_LDS_IDX_ACTIVE"] / 256.0 / (c["GRBM_GUI_ACTIVE"] / 8.0), 3)
+                             if c.get("GRBM_GUI_ACTIVE") and "SQ_LDS_IDX_ACTIVE" in c else None,
         }
-        hb = (traffic / (1e3 * s_ms / max(s_n, 1) * 1e-6) / 1e9 / HBM_PEAK_GBS) if (traffic and s_ms) else 0.0
-        if (counters["valu_busy_frac"] or 0.0) > max(hb, 0.5):
+        # what binds: the unit closest to what it can deliver -- the memory path against the rate a pure stream of the same records
+        # reaches (STREAM_GBS), the VALU against always-busy
+        mem = (traffic / (1e3 * s_ms / max(s_n, 1) * 1e-6) / 1e9 / STREAM_GBS) if (traffic and s_ms) else 0.0
+        if (counters["valu_busy_frac"] or 0.0) > max(mem, 0.5):
             bound = "valu_issue"
     per_step_scale = 1.0 / max(args.steps, 1)
 

@@ -1255,9 +1255,28 @@ static size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs&
     return (size_t)n_final + 1;
 }
 
+static int g_seed_upload = 0;  // option seed_upload: 0 pinned staging (memcpy + DMA), 1 pageable hipMemcpyAsync, 2 hipHostRegister + DMA
 static void upload_seeds(Slot* sl, const uint64_t* seeds, size_t n) {
     sl->seeds.ensure(std::max<size_t>(n, (size_t)g_max_seeds), "seed_offsets");
     if (n == 0) return;
+    if (g_seed_upload == 1) {  // the runtime stages the pageable vector itself (chunked, synchronous for the caller)
+        ProfScope p(sl, "h2d_seeds");
+        check_memcpy(hipMemcpyAsync(sl->seeds.p, seeds, n * sizeof(uint64_t), hipMemcpyHostToDevice, sl->stream), "seed_offsets");
+        return;
+    }
+    if (g_seed_upload == 2) {  // pin the caller's pages for the duration of the copy
+        const uintptr_t lo = (uintptr_t)seeds & ~(uintptr_t)4095, hi = ((uintptr_t)(seeds + n) + 4095) & ~(uintptr_t)4095;
+        if (hipHostRegister((void*)lo, hi - lo, hipHostRegisterDefault) == hipSuccess) {
+            {
+                ProfScope p(sl, "h2d_seeds");
+                check_memcpy(hipMemcpyAsync(sl->seeds.p, seeds, n * sizeof(uint64_t), hipMemcpyHostToDevice, sl->stream), "seed_offsets");
+            }
+            check_sync(sl->stream, "seed_offsets");
+            hipHostUnregister((void*)lo);
+            return;
+        }
+        (void)hipGetLastError();
+    }
     if (sl->h_seeds_cap < n) {
         if (sl->h_seeds) hipHostFree(sl->h_seeds);
         sl->h_seeds_cap = std::max<size_t>(n, (size_t)g_max_seeds);
@@ -1607,7 +1626,7 @@ static Option g_opts[] = {
     {"long_blocks", 1792, 1, 1 << 20, 0}, {"max_waves", 4096, 4, 1 << 20, 0}, {"packed_waves", 4096, 8, 1 << 20, 0},
     {"l2_blocks", 512, 1, 1 << 20, 0}, {"ctx_waves", 0, 0, 1 << 20, 0}, {"ctx_threads", 0, 0, 1024, 0},
     {"chain_sort_threads", 256, 64, 512, 0}, {"dedup_threads", 0, 0, 1024, 0},
-    {"nbr_one_stage", 0, 0, 1, 0}, {"table_atomic", 0, 0, 1, 0},
+    {"nbr_one_stage", 0, 0, 1, 0}, {"table_atomic", 0, 0, 1, 0}, {"seed_upload", 0, 0, 2, 0},
     // test-only: small capacities that force the overflow / fallback branches
     {"l2_cap", 0, 0, 1 << 30, 1}, {"spec_dedup", 1, 0, 1, 1}, {"spec_recs", 16384, 1, 16384, 1}, {"dedup_seg_max", 0, 0, 1 << 30, 1},
     {"no_small_dedup", 0, 0, 1, 1}, {"chain_cap", 1 << 22, 1, 1 << 30, 1}, {"audit_cap", 0, 0, 1 << 28, 1},
@@ -1656,6 +1675,7 @@ static void resolve_options() {
     g_dedup_threads = (int)opt_value("dedup_threads");
     g_nbr_two_stage = opt_value("nbr_one_stage") ? 0 : 1;
     g_table_atomic = (int)opt_value("table_atomic");
+    g_seed_upload = (int)opt_value("seed_upload");
     g_l2_cap_test = opt_value("l2_cap") ? (uint32_t)std::max<int64_t>(L2_NSUB, opt_value("l2_cap")) : 0u;
     g_spec_dedup = (int)opt_value("spec_dedup");
     SPEC_RECS = (uint32_t)opt_value("spec_recs");

@@ -18,10 +18,10 @@ for t in $TAG ${TAG}_human; do
 done
 timeout 600 python bench.py > gpurun_out/$TAG/bench_line_default.json 2> gpurun_out/$TAG/bench_line_default.err < /dev/null
 for w in notransition rm human; do
-  timeout 900 python bench.py --workload $w --no-cpu-baseline --steps 3 --warmup 1 > gpurun_out/$TAG/bench_line_$w.json 2> /dev/null < /dev/null
+  timeout 900 python bench.py --workload $w --steps 3 --warmup 1 > gpurun_out/$TAG/bench_line_$w.json 2> /dev/null < /dev/null
 done
 # (a plumbing step is ~1 ms: enough of them for a stable figure)
-timeout 900 python bench.py --workload plumbing --no-cpu-baseline --steps 50 --warmup 10 > gpurun_out/$TAG/bench_line_plumbing.json 2> /dev/null < /dev/null
+timeout 900 python bench.py --workload plumbing --steps 50 --warmup 10 > gpurun_out/$TAG/bench_line_plumbing.json 2> /dev/null < /dev/null
 timeout 600 python tools/upload_overlap.py gpurun_out/$TAG/upload_overlap.txt > gpurun_out/upload_overlap.log 2>&1 < /dev/null
 timeout 600 python tools/timeline.py gpurun_out/$TAG/timeline.txt > gpurun_out/timeline.log 2>&1 < /dev/null
 ls -la gpurun_out/$TAG gpurun_out/${TAG}_human

@@ -11,6 +11,6 @@ for w in notransition rm; do
   rm -f gpurun_out/${TAG}_$w/bench_under_pmc*.log
   mkdir -p profiles/${TAG}_$w
   cp gpurun_out/${TAG}_$w/kernel_stats.txt gpurun_out/${TAG}_$w/pmc*.txt gpurun_out/${TAG}_$w/traffic.json gpurun_out/${TAG}_$w/workload.json gpurun_out/${TAG}_$w/commands.txt profiles/${TAG}_$w/ 2> /dev/null
-  timeout 900 python bench.py --workload $w --no-cpu-baseline --steps 3 --warmup 1 > gpurun_out/${TAG}_$w/bench_line_$w.json 2> /dev/null < /dev/null
+  timeout 900 python bench.py --workload $w --steps 3 --warmup 1 > gpurun_out/${TAG}_$w/bench_line_$w.json 2> /dev/null < /dev/null
 done
 ls -la gpurun_out/${TAG}_notransition gpurun_out/${TAG}_rm

@@ -190,8 +190,10 @@ int sa_max_hits_for_mem(uint64_t total_global_mem);
  * choose between implementations of the same reference semantics (src/seed_filter.cu:682-828) or size their launches.
  *
  * Deployment options
- *   slots             calls in flight per device (default 2, max 4; the reference allows 1: its token IS the device)
- *   chunks_per_call   wga_chunk-sized chunks sa_seed_interval / sa_rm_mask_interval hand to one pass (default 16 = maximum)
+ *   slots             calls in flight per device (default 4 = max; the reference allows 1: its token IS the device).  Every slot
+ *                     has its own stream; the library's load-time constructor sets GPU_MAX_HW_QUEUES=8 (unless the variable is
+ *                     set) because slots that share one of the runtime's default four hardware queues run one after the other
+ *   chunks_per_call   wga_chunk-sized chunks sa_seed_interval / sa_rm_mask_interval hand to one pass (default 20, maximum 32)
  *   no_ctx            1: neighbourhood table without target context (lookup mode 1)
  *   no_td             1: no neighbourhood table (lookup mode 0: seed words -> buckets -> hit list, the reference's shape)
  *   arena_gb          GiB of table arena the engine starts mapping in the background at sa_initialize_processor (default 40:
@@ -199,7 +201,9 @@ int sa_max_hits_for_mem(uint64_t total_global_mem);
  *                     beforehand (e.g. 180 for 500 Mbp blocks) takes the allocation off the table build's critical path
  *   no_chain          1: every candidate is extended on its own (no chain shortcut, DESIGN.md 4.5')
  *   no_packed_filter / no_fast_filter   1: fall back to the byte-coded / the exact per-base X-drop filter kernels
- *   debug             1: table-build timings on stderr
+ *   debug             1: table-build timings on stderr; 2: + synchronise after every kernel scope and name it (fault localisation)
+ *   seed_upload       how sa_seed_and_filter brings the host seed vector over: 0 copy into a pinned staging buffer + DMA (default),
+ *                     1 hipMemcpyAsync from the pageable vector (the runtime stages it), 2 hipHostRegister the vector + DMA
  * Launch geometry (defaults are the measured optima, tools/sweep_*.sh)
  *   fin_batch, bufs_per_wave, long_cap, long_blocks, max_waves, packed_waves, l2_blocks, ctx_waves, ctx_threads,
  *   chain_sort_threads, dedup_threads, nbr_one_stage, table_atomic (1: seed table by the atomic counting sort even for seed

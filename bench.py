@@ -93,6 +93,9 @@ def parse():
                     help="do not record per-kernel HIP events in the timed region (roofline block from the untimed passes only)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = the calls of ONE pass are dealt to the ranks (total work fixed); weak = every rank runs the whole pass")
+    ap.add_argument("--partition", default="auto", choices=["auto", "hits", "round-robin"],
+                    help="strong scaling: how the calls of a pass are dealt to the ranks -- by measured seed hits (auto: when there is "
+                         "more than one rank) or round-robin")
     ap.add_argument("--no-dropin", action="store_true",
                     help="skip the drop-in leg (one-chunk g_SeedAndFilter calls): profile collections use it so that per-kernel averages "
                          "describe the calls of the timed region only")
@@ -256,16 +259,33 @@ def main():
             collect.append(st)
         return (0 if job["rev"] else job["b"] - job["a"]), int(outs[0].size), shard.hsp_checksum(outs[0], job["rev"]) % CHECK_MOD
 
+    # Strong scaling over several ranks: the calls are dealt by their seed-hit counts (longest first, to the least loaded rank).  The
+    # counts come from ONE untimed pass over all calls that every rank runs for itself -- same data, same counts, same map on
+    # every rank, no communication; it is part of the warm-up (tables, buffers and clocks are warm afterwards).
+    weights = None
+    imbalance = None
+    if scaling == "strong" and not wl["rm"] and (args.partition == "hits" or (args.partition == "auto" and world > 1)):
+        weights = []
+        E.SeedCalls([(j["a"], j["b"], j["rev"]) for j in jobs], 0, inflight, hits_out=weights)
+    my_jobs = shard.partition(jobs, rank, world, weights) if scaling == "strong" else jobs
+    if weights and world >= 1:
+        # (what the map promises: heaviest rank / mean, by seed hits; and what round-robin would have given)
+        def spread(w_or_none, n):
+            pos = {id(j): k for k, j in enumerate(jobs)}
+            loads = [sum(weights[pos[id(j)]] for j in shard.partition(jobs, r, n, w_or_none)) for r in range(n)]
+            return round(max(loads) / (sum(loads) / n), 4)
+        n_show = world if world > 1 else 8
+        imbalance = {"ranks": n_show, "by_hits": spread(weights, n_show), "round_robin": spread(None, n_show)}
     # never more calls in flight than this rank's share of one pass holds (the 1 Mbp plumbing case is two calls per pass: six
     # tiny calls in flight only contend for the engine's locks, 1.1 -> 0.67 Gbp/s)
-    inflight = max(1, min(inflight, len(shard.partition(jobs, rank, world)) if scaling == "strong" else len(jobs)))
+    inflight = max(1, min(inflight, len(my_jobs)))
 
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(inflight)  # the reference keeps one seeder body per TBB thread in flight (src/main.cpp:565-573)
 
     def step_jobs(k):
         """strong: this rank's share of the calls of ONE pass over the query block; weak: all of them, from a rank-dependent start"""
-        return shard.partition(jobs, rank, world) if scaling == "strong" else rotate(jobs, rank + k)
+        return my_jobs if scaling == "strong" else rotate(jobs, rank + k)
 
     def run_steps(ks, collect=None, threads=None):
         """The passes `ks` as ONE list of calls: the calls of consecutive passes follow each other without a drain in between, as the
@@ -360,11 +380,12 @@ def main():
                                                  "pass over the kernels), device-side seeding" % (query.size, len(intervals), args.interval, args.chunk,
                                                                                                  E.lib().sa_get_chunks_per_call()),
                        "workload_key": args.workload,
-                       "parallelism": ("the %d engine calls of one pass dealt round-robin to %d rank(s): every call on exactly one GPU, target + "
-                                       "tables on every GPU, no collective" % (len(jobs), world)) if scaling == "strong" else
+                       "parallelism": ("the %d engine calls of one pass dealt to %d rank(s) %s: every call on exactly one GPU, target + tables on every GPU, "
+                                       "no collective" % (len(jobs), world, "by seed-hit count (longest first to the least loaded rank; counts from an "
+                                                          "untimed pass every rank runs identically)" if weights else "round-robin")) if scaling == "strong" else
                                       ("every one of %d rank(s) runs all %d calls of a pass (own block pair per rank for `human`), no collective"
                                        % (world, len(jobs))),
-                       "calls_per_step": len(jobs), "calls_in_flight_per_gpu": inflight,
+                       "calls_per_step": len(jobs), "calls_in_flight_per_gpu": inflight, "partition_imbalance": imbalance,
                        "hsps_per_step": hsps // (steps_eff * (world if scaling == "weak" else 1)),
                        # order-independent checksum of one pass's HSP multiset: an N-GPU strong-scaling run reproduces the 1-GPU value
                        "hsp_checksum": check if scaling == "strong" else None},
@@ -692,7 +713,9 @@ def dry_run(args, rank, world, dist, torch, shard, scaling):
     t0 = time.perf_counter()
     bases, check = 0, 0
     for k in range(args.steps):
-        todo = shard.partition(jobs, rank, world) if scaling == "strong" else rotate(jobs, rank + k)
+        # (strong, several ranks: weighted like the real bench -- there by seed hits, here by the calls' lengths)
+        todo = (shard.partition(jobs, rank, world, [j["b"] - j["a"] for j in jobs] if world > 1 else None) if scaling == "strong"
+                else rotate(jobs, rank + k))
         for i, j in enumerate(todo):
             bases += 0 if j["rev"] else j["b"] - j["a"]
             w = 1 if scaling == "strong" else (i + 1)  # (weak: weighted by the walk position, so the walk order is checked too)

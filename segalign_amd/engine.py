@@ -237,9 +237,10 @@ class CallResult(C.Structure):
     _fields_ = [("hsps", C.c_void_p), ("num_hsps", C.c_size_t), ("num_hits", C.c_uint64)]
 
 
-def SeedCalls(calls, buffer=0, threads=4):
+def SeedCalls(calls, buffer=0, threads=4, hits_out=None):
     """calls: [(start, end, rev), ...], each up to sa_max_chunks_per_call() chunks of one strand; `threads` of them in flight on
-    the engine's worker pool.  -> ([HSP array per call (chunks concatenated, headers removed)], summed stats dict)."""
+    the engine's worker pool.  -> ([HSP array per call (chunks concatenated, headers removed)], summed stats dict).
+    hits_out: a list that receives the seed hits of every call (sa_call_result.num_hits)."""
     n = len(calls)
     descs = (CallDesc * max(n, 1))(*[CallDesc(int(a), int(b), int(bool(r))) for (a, b, r) in calls])
     res = (CallResult * max(n, 1))()
@@ -253,6 +254,8 @@ def SeedCalls(calls, buffer=0, threads=4):
         else:
             outs.append(np.zeros(0, dtype=SEG_DTYPE))
         lib().sa_free_segments(res[i].hsps)
+    if hits_out is not None:
+        hits_out.extend(int(res[i].num_hits) for i in range(n))
     return outs, {k: getattr(st, k) for k, _ in CallStats._fields_}
 
 

@@ -45,10 +45,22 @@ def call_jobs(intervals, q_block_len, chunk, chunks_per_call=16):
     return jobs
 
 
-def partition(jobs, rank, world):
-    """Strong scaling: the calls of ONE problem dealt round-robin to the ranks -- every call exactly once.  Consecutive calls
-    (neighbouring query regions, similar hit density) land on different ranks, which balances dense and sparse regions."""
-    return [j for k, j in enumerate(jobs) if k % world == rank]
+def partition(jobs, rank, world, weights=None):
+    """Strong scaling: the calls of ONE problem dealt to the ranks -- every call exactly once, no communication: every rank computes
+    the same map.  Without weights: round-robin (consecutive calls -- neighbouring query regions, similar hit density -- land on
+    different ranks).  With weights (the seed hits of every call, counted by an untimed pass that every rank runs identically):
+    longest-processing-time-first -- calls in descending weight, each to the rank with the least weight so far (ties: lowest rank)
+    -- which bounds the imbalance by one call's weight.  A rank's calls keep their original order."""
+    if weights is None or world <= 1:
+        return [j for k, j in enumerate(jobs) if k % world == rank]
+    assert len(weights) == len(jobs)
+    load = [0] * world
+    owner = [0] * len(jobs)
+    for k in sorted(range(len(jobs)), key=lambda i: (-int(weights[i]), i)):
+        r = min(range(world), key=lambda q: (load[q], q))
+        owner[k] = r
+        load[r] += int(weights[k])
+    return [j for k, j in enumerate(jobs) if owner[k] == rank]
 
 
 def hsp_checksum(segs, rev):

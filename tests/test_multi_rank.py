@@ -83,6 +83,19 @@ def test_call_list_partition_covers_every_call_exactly_once():
         flat = [id(j) for p in parts for j in p]
         assert sorted(flat) == sorted(id(j) for j in jobs)  # exactly once
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+        # weighted map (seed hits per call in the real bench): still every call exactly once, original order inside a rank,
+        # and the heaviest rank carries at most one call's weight more than the lightest
+        rng = __import__("random").Random(7 + world)
+        w = [rng.randint(1, 1000) * (5 if k % 7 == 0 else 1) for k in range(len(jobs))]
+        wparts = [shard.partition(jobs, r, world, w) for r in range(world)]
+        assert sorted(id(j) for p in wparts for j in p) == sorted(id(j) for j in jobs)
+        pos = {id(j): k for k, j in enumerate(jobs)}
+        loads = []
+        for p in wparts:
+            ks = [pos[id(j)] for j in p]
+            assert ks == sorted(ks)
+            loads.append(sum(w[k] for k in ks))
+        assert max(loads) - min(loads) <= max(w)
 
 
 def test_strong_scaling_partition_keeps_the_checksum_for_world_1_2_3():

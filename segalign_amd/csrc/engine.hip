@@ -618,8 +618,10 @@ static void prof_flush(Slot* sl) {  // call after the slot's stream has been syn
             g_prof[r.id].launches += 1;
             float t0 = 0;
             if (sl->dev >= 0 && sl->dev < PROF_MAX_DEV && g_prof_epoch[sl->dev] &&
-                hipEventElapsedTime(&t0, g_prof_epoch[sl->dev], r.e0) == hipSuccess)
-                g_prof[r.id].spans.push_back({sl->dev, t0, t0 + ms});
+                hipEventElapsedTime(&t0, g_prof_epoch[sl->dev], r.e0) == hipSuccess) {
+                if (g_prof[r.id].spans.size() < ((size_t)1 << 20)) g_prof[r.id].spans.push_back({sl->dev, t0, t0 + ms});  // (bounded: a
+                // profile left enabled without a reset keeps its totals, sa_profile_busy_ms then covers the first 2^20 launches)
+            }
             else (void)hipGetLastError();
         }
     }

@@ -565,6 +565,7 @@ def roofline(args, E, wl, prof, busy, call_stats, run_step, run_job, jobs, elaps
         "stream_ceiling_gbs": STREAM_GBS,
         "counters": counters,
         "dominant_share_of_gpu_time": round(ms / gpu_ms, 4) if gpu_ms else None,
+        "whole_pass": whole_pass(prof, traffic_db if check["ok"] else None, elapsed, ctx_filter),
         "per_step": {"ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 3),
                      "moved_bytes_dominant": round(mv_t.get(name, 0.0) * per_step_scale),
                      "counter_bytes_dominant": round(traffic * launches * per_step_scale) if traffic else None,
@@ -583,6 +584,27 @@ def roofline(args, E, wl, prof, busy, call_stats, run_step, run_job, jobs, elaps
         "seed_lookup": first_class(lookup_scope, lookup_scope, 16.0 * S, 16.0 * sS, "16*S"),
         "kernels": kernels,
     }
+
+
+def whole_pass(prof, traffic_db, elapsed, ctx_filter):
+    """Every kernel of the timed region together against the memory system: measured HBM bytes per launch (committed collection)
+    x launches in the timed region, over the timed wall time.  The pass is a handful of streaming / random-line kernels that overlap
+    on four slots; this is the figure that says how close the PASS, not one kernel, is to what the memory path delivers."""
+    if not traffic_db:
+        return None
+    table = PROFILE_SCOPE_KERNELS if ctx_filter else SCOPE_KERNELS
+    total, missing = 0.0, []
+    for scope, (ms_, n) in prof.items():
+        for sym in table.get(scope, []):
+            if sym in traffic_db:
+                total += float(traffic_db[sym]["hbm_bytes"]) * n
+            elif sym not in missing:
+                missing.append(sym)
+    gbs = total / max(elapsed, 1e-9) / 1e9
+    return {"hbm_bytes": int(total), "gbs": round(gbs, 1), "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
+            "frac_of_stream_ceiling": round(gbs / STREAM_GBS, 4), "kernels_without_traffic": missing,
+            "note": "sum over the kernels of the timed region of (HBM bytes per launch, TCC counters of the committed collection) x launches, "
+                    "/ timed wall time"}
 
 
 def moved_formula(scope, table_direct):

@@ -35,7 +35,8 @@ c = Case(target, query).oracle_setup(O)
 print("oracle setup %.1f s" % (time.time() - t0), flush=True)
 t0 = time.time()
 c.engine_setup(E)
-print("engine setup %.2f s (filter mode %d)" % (time.time() - t0, E.filter_mode()), flush=True)
+print("engine setup %.2f s (filter mode %d, lookup mode %d, %.1f M neighbourhood entries = %.1f GB of context records)" %
+      (time.time() - t0, E.filter_mode(), E.lookup_mode(), E.neighbourhood_entries() / 1e6, E.neighbourhood_entries() * 32 / 1e9), flush=True)
 assert np.array_equal(E.copy_index_table(), c.o_index)
 ok = True
 for rev in (False, True):

@@ -21,11 +21,13 @@ def rm_case_small_chunks(oracle, engine):
         cp = synth.mutate(unit, 700 + i, 0.06)
         t[p:p + cp.size] = cp if i % 2 else synth.reverse_complement(cp)
     t = synth.soft_mask(t, 6, 0.03)
+    engine.set_option("chunks_per_call", 20)  # (the grouping the cases below are laid out for, whatever the environment says)
     c = Case(t, t, chunk=8000).oracle_setup(oracle).engine_setup(engine)
     engine.RmSendQueryWriteRequest()
     yield c
     engine.RmClearQuery()
     engine.ShutdownProcessor()
+    engine.reset_option("chunks_per_call")
 
 
 @pytest.mark.parametrize("strands", [1, 2, 3])

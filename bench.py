@@ -364,8 +364,11 @@ def main():
 
     # ---------------- CPU baseline (rank 0, N == 1 only, bounded sample) ----------------
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_roofline and not wl["rm"]:
-        cpu = cpu_baseline(E, target, query, sub_mat, seed_size, kmer, args, xdrop, hspthresh, wl["transition"])
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_roofline:
+        if wl["rm"]:
+            cpu = cpu_baseline_rm(E, target, sub_mat, seed_size, kmer, args, xdrop, hspthresh, jobs)
+        else:
+            cpu = cpu_baseline(E, target, query, sub_mat, seed_size, kmer, args, xdrop, hspthresh, wl["transition"])
 
     if rank == 0:
         value = bases / elapsed / 1e9
@@ -812,6 +815,47 @@ def cpu_baseline(E, target, query, sub_mat, seed_size, kmer, args, xdrop, hspthr
     if lz:
         out["lastz"] = lz
     return out
+
+
+def cpu_baseline_rm(E, target, sub_mat, seed_size, kmer, args, xdrop, hspthresh, jobs):
+    """Repeat-masker workload: the oracle's restatement of the repeat masker's seeder body (repeat_masker_src/seeder.cpp:73-150:
+    chunk loop, minus chunk derived from the plus chunk's end, windowed SeedAndFilter of repeat_masker_src/seed_filter.cu:724-876)
+    on whole chunks of the first interval task, both strands, until ~cpu_seconds have been spent; table copied from the device."""
+    from oracle import oracle as O
+    O.build(with_ref=False)
+    cores = os.cpu_count() or 1
+    O.generate_shape_pos(SHAPE)
+    index = E.copy_index_table()
+    pos = E.copy_pos_table()
+    ref_codes = E.copy_ref_codes()
+    rc_codes = O.rev_comp_codes(ref_codes)
+    L = int(target.size)
+    tb = target.tobytes()
+    rcb = O.rev_comp_ascii(tb, 0, L)
+    job = jobs[0]
+    end_pos_rc = L - 1 - job["a"]
+    done_bases, spent, chunks = 0, 0.0, 0
+    c = job["a"]
+    while spent < args.cpu_seconds and c < job["b"]:
+        e = min(c + args.chunk, job["b"])
+        t0 = time.perf_counter()
+        for rev in (False, True):
+            s0, s1 = c, e
+            if rev:  # repeat_masker_src/seeder.cpp:118-119
+                s0 = L - 1 - e
+                s1 = min(s0 + args.chunk, end_pos_rc)
+            s1 = min(s1, L - seed_size + 1)
+            seeds = O.make_seeds(rcb if rev else tb, 0, s0, s1, seed_size, kmer, True)
+            if seeds.size:
+                O.seed_and_filter(ref_codes, rc_codes if rev else ref_codes, index, pos, seeds, sub_mat, seed_size=seed_size, xdrop=xdrop,
+                                  hspthresh=hspthresh, noentropy=False, num_threads=cores, rm=(rev, job["ref_start"], job["ref_end"]))
+        spent += time.perf_counter() - t0
+        done_bases += e - c
+        chunks += 1
+        c = e
+    return {"value": round(done_bases / spent / 1e9, 6), "unit": "Gbp/s", "cores": cores, "kind": "port",
+            "sample": "%d x %d bp chunks of the first interval task, both strands, self-alignment inside its window (%.1f s CPU wall); "
+                      "host seeding loop + OpenMP extension of oracle/segalign_oracle.c (repeat-masker variant)" % (chunks, args.chunk, spent)}
 
 
 def lastz_row(target, query, args):

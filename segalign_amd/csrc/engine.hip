@@ -402,6 +402,13 @@ static bool arena_wait(Arena& A, size_t bytes) {
     A.cv.wait(lk, [&] { return A.mapped >= bytes || A.failed || !A.busy; });
     return A.mapped >= bytes;
 }
+// The block's need is known and mapped: stop mapping ahead (the default goal is a guess made before any sequence was seen; what is
+// mapped stays).  Mapping is page clearing on the device: left running it takes memory bandwidth from the first query pass.
+static void arena_settle(Arena& A, size_t need) {
+    std::lock_guard<std::mutex> lk(A.mu);
+    const size_t n = (need + ARENA_CHUNK - 1) / ARENA_CHUNK * ARENA_CHUNK;
+    if (A.goal > std::max(n, A.mapped)) A.goal = std::max(n, A.mapped);
+}
 // give everything beyond `keep` bytes back to the device (the worker is stopped first)
 static void arena_trim(Arena& A, size_t keep) {
     std::unique_lock<std::mutex> lk(A.mu);
@@ -1413,6 +1420,7 @@ static bool ensure_nbr(DevCtx* dc) {
         const bool two_stage = g_nbr_two_stage && tmask != 0 && rec_b + scratch_b + reserve <= free_b + have;
         const size_t need = rec_b + (two_stage ? scratch_b : 0);
         if (arena_wait(dc->arena, need)) {
+            arena_settle(dc->arena, need);
             uint8_t* arena = dc->arena.base;
             dc->nbr_ctx = reinterpret_cast<CtxRec*>(arena);
             if (dbg) fprintf(stderr, "neighbourhood table: %.1f M entries, waited %.1f ms for %.1f GB of arena\n", total / 1e6, now() - t_a, need / 1e9);

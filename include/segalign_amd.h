@@ -45,6 +45,9 @@ int sa_initialize_interface(int num_gpu);
 /* One-process-per-GPU deployments: restrict the NEXT sa_initialize_interface to these HIP device ordinals
  * (engine device g = ids[g]).  n = 0 restores the reference behaviour (devices 0..num_gpu-1). */
 void sa_select_devices(const int* ids, int n);
+/* (An ordinal may appear more than once in ids[]: every entry becomes an engine device of its own -- context, streams, target,
+ *  tables, arena, token-pool slots -- on that GPU.  tests/test_gpu_multi_device.py exercises the multi-device paths that way on a
+ *  one-GPU box.) */
 
 /* g_InitializeProcessor, src/seed_filter.h:4,10 ; def src/seed_filter.cu:830-897.
  * sub_mat: 64 ints, sub_mat[r*8+q] over codes A0 C1 G2 T3 L4 N5 X6 E7 (common/parameters.h:4-13). */
@@ -53,6 +56,10 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
 
 /* g_ShutdownProcessor, src/seed_filter.h:8,14 ; def src/seed_filter.cu:932-940. */
 void sa_shutdown_processor(void);
+/* (additive) The reference's shutdown resets the device (src/seed_filter.cu:939); the engine keeps ONE thing across
+ * ShutdownProcessor: the table arena, a cache of cleared device pages that cost seconds to obtain.  This gives it back
+ * to the device(s); call after sa_shutdown_processor.  Option arena_gb = 0 makes ShutdownProcessor do it itself. */
+void sa_release_arena(void);
 
 /* ---- target block ---------------------------------------------------------------------------------------- */
 
@@ -132,9 +139,15 @@ typedef struct sa_call_result {
     sa_segment_pair* hsps;
     size_t num_hsps;
     uint64_t num_hits;
+    int32_t device;   /* engine device (0 .. devices in use - 1) the call ran on */
+    int32_t reserved;
 } sa_call_result;
 size_t sa_seed_calls(const sa_call_desc* calls, size_t num_calls, uint32_t buffer, int threads, sa_call_result* results,
                      struct sa_call_stats* totals /* nullable: sums over the calls */);
+/* Seed hits of every call of such a list, WITHOUT filtering or extending them: lookup only (the table-direct position probe and its
+ * chunk plans, ~0.2 ms per twenty-chunk call against ~2.6 ms for the call itself).  A multi-GPU host weighs the calls of a pass with
+ * these counts before it deals them out (longest first); every rank computes the same numbers from the same resident blocks. */
+void sa_count_call_hits(const sa_call_desc* calls, size_t num_calls, uint32_t buffer, int threads, uint64_t* hits);
 
 /* ---- repeat-masker variant (repeat_masker_src/seed_filter.h:4-8) ----------------------------------------- */
 
@@ -252,7 +265,7 @@ int sa_get_filter_mode(void);
 /* Seed lookup path of the device-seeded entry points (sa_seed_and_filter_range / _chunks, sa_seed_interval,
  * sa_rm_mask_interval) on device 0: 0 = general path (seed words -> find_num_hits / find_hits shape, also used by the drop-in
  * sa_seed_and_filter), 1 = table-direct (neighbourhood table + position probe, no seed words, no hit list), 2 = table-direct
- * with target context in the table (the X-drop filter streams 28-byte records).  Chosen by available HBM;
+ * with target context in the table (the X-drop filter streams 32-byte records).  Chosen by available HBM;
  * options no_ctx / no_td force 1 / 0.  Results are identical on every path. */
 int sa_get_lookup_mode(void);
 uint64_t sa_get_neighbourhood_entries(void); /* run entries of the neighbourhood table (0 when not built) */

@@ -1,0 +1,332 @@
+// api_calls.hip -- C-ABI, the hot calls: g_SeedAndFilter (src/seed_filter.cu:682-828) and its additive forms.
+#include "engine_internal.h"
+
+using namespace sa;
+
+extern "C" {
+
+// ---- hot calls ------------------------------------------------------------------------------------------------------
+size_t sa_seed_and_filter(const uint64_t* seeds, size_t num_seeds, int rev, uint32_t buffer, sa_segment_pair** out) {
+    require_proc("SeedAndFilter", buffer);
+    if ((int64_t)num_seeds > g_max_seeds) {  // :688-692
+        printf("MAX_SEEDS exceeded\n");
+        fflush(stdout);
+        fprintf(stderr, "Assertion `num_seeds <= MAX_SEEDS' failed.\n");
+        abort();
+    }
+    Slot* sl = acquire_slot();
+    DevCtx* dc = sl->ctx;
+    upload_seeds(sl, seeds, num_seeds);
+    CoreArgs ca = {rev ? dc->query_rc[buffer].codes : dc->query[buffer].codes, g_query_len[buffer], 0, 0, 0, 0, 0, 0, nullptr, 0,
+                   rev ? &dc->query4_rc[buffer] : &dc->query4[buffer]};  // :762-767
+    set_query2(ca, dc, buffer, rev);
+    uint32_t lo = 0, hi = 0, words = 0;
+    if (dropin_td_front(dc, sl, ca.query, ca.query_len, seeds, num_seeds, ca.query4, ca.q2_own, ca.q2_other, 0, &lo, &hi, &words) != 0xFFFFFFFFu) {
+        ca.td = 1;
+        ca.td_words = words;
+        ca.q_lo = lo;
+        ca.q_hi = hi;
+    }
+    size_t n = saf_core(dc, sl, (uint32_t)num_seeds, ca, out);
+    release_slot(sl);
+    return n;
+}
+
+size_t sa_seed_and_filter_range(uint32_t start, uint32_t end, int rev, uint32_t buffer, sa_segment_pair** out) {
+    require_proc("SeedAndFilterRange", buffer);
+    Slot* sl = acquire_slot();
+    DevCtx* dc = sl->ctx;
+    const uint8_t* q = rev ? dc->query_rc[buffer].codes : dc->query[buffer].codes;
+    uint32_t qlen = g_query_len[buffer];
+    // a seed window must lie inside the block: positions j with j + span <= len
+    uint32_t lim = qlen >= g_seed_size ? qlen - g_seed_size + 1 : 0;
+    if (end > lim) end = lim;
+    const PackedBuf* q4 = rev ? &dc->query4_rc[buffer] : &dc->query4[buffer];
+    uint32_t ns = 0xFFFFFFFFu, words = 0;
+    if (td_eligible(dc, q4, rev ? &dc->query2_rc[buffer] : &dc->query2[buffer], rev ? &dc->query2[buffer] : &dc->query2_rc[buffer])) {
+        const uint32_t bp[2] = {start, std::max(start, end)};
+        ns = td_front(dc, sl, q, 1, bp, 0, &words);
+    }
+    const bool td = ns != 0xFFFFFFFFu;
+    if (!td) ns = device_seeds(sl, q, start, end);
+    size_t n = 0;
+    *out = nullptr;
+    if (ns > 0) {  // seeder.cpp:76: the engine is only called for a non-empty seed vector
+        CoreArgs ca = {q, qlen, 0, 0, 0, 0, start, end, nullptr, 0, q4};
+        set_query2(ca, dc, buffer, rev);
+        ca.td = td ? 1 : 0;
+        ca.td_words = words;
+        n = saf_core(dc, sl, ns, ca, out);
+    } else {
+        prof_flush(sl);
+        memset(&t_stats, 0, sizeof(t_stats));
+    }
+    release_slot(sl);
+    return n;
+}
+
+// Up to SA_MAX_CHUNKS consecutive wga_chunk-sized chunks of one strand in ONE pass over the kernels: the chunks share the
+// seeding, lookup, expansion, extension, grouping and ordering launches and the host syncs, while every chunk keeps its own
+// iteration plan, dedup scope and return vector -- bit for bit what one sa_seed_and_filter_range call per chunk returns.
+int sa_max_chunks_per_call(void) { return SA_MAX_CHUNKS; }
+int sa_get_chunks_per_call(void) { return g_chunks_per_call; }  // what sa_seed_interval hands to one call (SEGALIGN_AMD_CHUNKS_PER_CALL)
+size_t sa_seed_and_filter_chunks(uint32_t start, uint32_t end, int rev, uint32_t buffer, sa_segment_pair** outs, size_t* counts) {
+    require_proc("SeedAndFilterChunks", buffer);
+    const uint32_t chunk = g_wga_chunk;
+    const int K = end > start ? (int)(((uint64_t)end - start + chunk - 1) / chunk) : 0;
+    if (K > SA_MAX_CHUNKS) {
+        fprintf(stderr, "Error: SeedAndFilterChunks takes at most %d chunks per call\n", SA_MAX_CHUNKS);
+        exit(1);
+    }
+    for (int c = 0; c < K; c++) { outs[c] = nullptr; counts[c] = 0; }
+    if (K == 0) return 0;
+    if (K == 1) {
+        counts[0] = sa_seed_and_filter_range(start, end, rev, buffer, &outs[0]);
+        return counts[0];
+    }
+    Slot* sl = acquire_slot();
+    DevCtx* dc = sl->ctx;
+    const uint8_t* q = rev ? dc->query_rc[buffer].codes : dc->query[buffer].codes;
+    const uint32_t qlen = g_query_len[buffer];
+    const uint32_t lim = qlen >= g_seed_size ? qlen - g_seed_size + 1 : 0;
+    const uint32_t send = std::min(end, lim);  // a seed window must lie inside the block
+    uint32_t bpos[SA_MAX_CHUNKS + 1], bseed[SA_MAX_CHUNKS + 1];
+    for (int c = 0; c <= K; c++) bpos[c] = (uint32_t)std::min<uint64_t>((uint64_t)start + (uint64_t)c * chunk, send);
+    const PackedBuf* q4 = rev ? &dc->query4_rc[buffer] : &dc->query4[buffer];
+    uint32_t ns = 0xFFFFFFFFu, words = 0;
+    if (td_eligible(dc, q4, rev ? &dc->query2_rc[buffer] : &dc->query2[buffer], rev ? &dc->query2[buffer] : &dc->query2_rc[buffer]))
+        ns = td_front(dc, sl, q, K, bpos, 0, &words);
+    const bool td = ns != 0xFFFFFFFFu;
+    if (!td) ns = device_seeds(sl, q, start, send, K + 1, bpos, bseed);
+    size_t total = 0;
+    if (ns > 0) {
+        CoreArgs ca = {q, qlen, 0, 0, 0, 0, start, send, nullptr, 0, q4};
+        set_query2(ca, dc, buffer, rev);
+        ca.nchunks = K;
+        ca.td = td ? 1 : 0;
+        ca.td_words = words;
+        for (int c = 0; c <= K; c++) ca.seed_bound[c] = td ? 0u : bseed[c];  // (a table-direct call derives them from its chunk plans)
+        ca.outs = outs;
+        ca.counts = counts;
+        saf_core(dc, sl, ns, ca, nullptr);
+        for (int c = 0; c < K; c++) total += counts[c];
+    } else {
+        prof_flush(sl);
+        memset(&t_stats, 0, sizeof(t_stats));
+    }
+    release_slot(sl);
+    return total;
+}
+
+void sa_free_segments(sa_segment_pair* p) { free(p); }
+
+// Introspection (tests): the extension stage alone -- find_hsps + compaction of the passing hits (src/seed_filter.cu:232-680)
+// -- for caller-supplied anchors {ref_loc, query_loc} on the resident target / query strand.  Returns 1 + the number of
+// passing hits; out[0] is a header {len = count}, the records follow in no particular order and are NOT de-duplicated,
+// except that exact duplicates may already be merged (the chain shortcut extends one member of a run of anchors that
+// provably produce the identical record).
+size_t sa_extend_hits(const uint32_t* ref_query_pairs, size_t num_hits, int rev, uint32_t buffer, sa_segment_pair** out) {
+    require_init("ExtendHits");
+    if (buffer >= SA_BUFFER_DEPTH) {
+        fprintf(stderr, "Error: query buffer %u out of range\n", buffer);
+        exit(1);
+    }
+    Slot* sl = acquire_slot();
+    DevCtx* dc = sl->ctx;
+    size_t n = 0;
+    *out = nullptr;
+    if (num_hits > 0) {
+        sl->hits.ensure(num_hits, "hits");
+        check_memcpy(hipMemcpyAsync(sl->hits.p, ref_query_pairs, num_hits * sizeof(Hit), hipMemcpyHostToDevice, sl->stream), "hits");
+        CoreArgs ca = {rev ? dc->query_rc[buffer].codes : dc->query[buffer].codes, g_query_len[buffer], 0, 0, 0, 0, 0, 0, nullptr, 0,
+                       rev ? &dc->query4_rc[buffer] : &dc->query4[buffer]};
+        set_query2(ca, dc, buffer, rev);
+        ca.raw_hits = num_hits;
+        n = saf_core(dc, sl, 1, ca, out);
+    }
+    release_slot(sl);
+    return n;
+}
+
+// seeder_body::operator() of src/seeder.cpp:12-127 for one query interval: plus-strand chunks [start, end) in steps of
+// wga_chunk, then the minus-strand chunks of the same interval in reverse-complement coordinates (:33-34,89-91), every
+// chunk through sa_seed_and_filter_range; `threads` chunk calls are kept in flight (the reference keeps one per TBB
+// worker).  HSPs are concatenated per strand in chunk order, headers removed (:80-85,115-120).
+size_t sa_seed_interval(uint32_t start, uint32_t end, uint32_t q_len, int strands, uint32_t buffer, int threads,
+                        sa_segment_pair** out_fw, size_t* n_fw, sa_segment_pair** out_rc, size_t* n_rc, sa_call_stats* totals) {
+    require_proc("SeedInterval", buffer);
+    struct Job { uint32_t a, b; int rev; int k; sa_segment_pair* res[SA_MAX_CHUNKS]; size_t n[SA_MAX_CHUNKS]; };
+    std::vector<Job> jobs;
+    const int per_job = g_chunks_per_call;  // chunks of one strand that share one pass over the kernels
+    for (int rev = 0; rev < 2; rev++) {
+        if (!(strands & (rev ? SA_STRAND_MINUS : SA_STRAND_PLUS))) continue;
+        const uint32_t a = rev ? q_len - end : start, b = rev ? q_len - start : end;
+        // equal groups: 40 chunks go as 14 + 14 + 12, not 16 + 16 + 8 (the calls of an interval finish together)
+        const uint64_t nchunks = b > a ? ((uint64_t)b - a + g_wga_chunk - 1) / g_wga_chunk : 0;
+        const uint64_t ncalls = (nchunks + per_job - 1) / per_job;
+        const uint64_t group = ncalls ? (nchunks + ncalls - 1) / ncalls : 1;
+        for (uint64_t i = a; i < b; i += (uint64_t)g_wga_chunk * group) {
+            Job jb;
+            memset(&jb, 0, sizeof(jb));
+            jb.a = (uint32_t)i;
+            jb.b = (uint32_t)std::min<uint64_t>(i + (uint64_t)g_wga_chunk * group, b);
+            jb.rev = rev;
+            jb.k = (int)(((uint64_t)jb.b - jb.a + g_wga_chunk - 1) / g_wga_chunk);
+            jobs.push_back(jb);
+        }
+    }
+    sa_call_stats tot;
+    memset(&tot, 0, sizeof(tot));
+    std::mutex mu;
+    run_parallel(jobs.size(), threads, [&](size_t j) {  // (pool threads of the engine: nothing is created per interval)
+        Job& jb = jobs[j];
+        sa_seed_and_filter_chunks(jb.a, jb.b, jb.rev, buffer, jb.res, jb.n);
+        std::lock_guard<std::mutex> lk(mu);
+        tot.num_seeds += t_stats.num_seeds;
+        tot.num_hits += t_stats.num_hits;
+        tot.num_survivors += t_stats.num_survivors;
+        tot.num_anchors += t_stats.num_anchors;
+        tot.num_examined += t_stats.num_examined;
+        tot.num_examined_filter += t_stats.num_examined_filter;
+        tot.num_candidates += t_stats.num_candidates;
+        tot.num_forwarded += t_stats.num_forwarded;
+        tot.num_entropy += t_stats.num_entropy;
+        tot.num_iter += t_stats.num_iter;
+        tot.device = t_stats.device;
+        tot.lookup_path = t_stats.lookup_path;
+    });
+    size_t cnt[2] = {0, 0};
+    for (const Job& jb : jobs)
+        for (int c = 0; c < jb.k; c++) if (jb.n[c] > 1) cnt[jb.rev] += jb.n[c] - 1;
+    sa_segment_pair* dst[2];
+    for (int r = 0; r < 2; r++) dst[r] = (sa_segment_pair*)malloc(std::max<size_t>(cnt[r], 1) * sizeof(sa_segment_pair));
+    size_t off[2] = {0, 0};
+    for (Job& jb : jobs)
+        for (int c = 0; c < jb.k; c++) {
+            if (jb.n[c] > 1) {
+                memcpy(dst[jb.rev] + off[jb.rev], jb.res[c] + 1, (jb.n[c] - 1) * sizeof(sa_segment_pair));
+                off[jb.rev] += jb.n[c] - 1;
+            }
+            free(jb.res[c]);
+        }
+    *out_fw = dst[0]; *n_fw = cnt[0];
+    *out_rc = dst[1]; *n_rc = cnt[1];
+    if (totals) *totals = tot;
+    return cnt[0] + cnt[1];
+}
+
+// A list of independent calls -- each up to sa_max_chunks_per_call() consecutive chunks of one strand -- run with `threads` of
+// them in flight on the engine's worker pool.  This is the unit a multi-GPU host deals out: any subset of the calls of a pass
+// may run on any device.  results[i]: the HSPs of call i, its chunks concatenated in order, headers removed.
+size_t sa_seed_calls(const sa_call_desc* calls, size_t num_calls, uint32_t buffer, int threads, sa_call_result* results,
+                     sa_call_stats* totals) {
+    require_proc("SeedCalls", buffer);
+    sa_call_stats tot;
+    memset(&tot, 0, sizeof(tot));
+    std::mutex mu;
+    run_parallel(num_calls, threads, [&](size_t i) {
+        sa_segment_pair* res[SA_MAX_CHUNKS];
+        size_t cnt[SA_MAX_CHUNKS];
+        const sa_call_desc& c = calls[i];
+        const int K = c.end > c.start ? (int)(((uint64_t)c.end - c.start + g_wga_chunk - 1) / g_wga_chunk) : 0;
+        sa_seed_and_filter_chunks(c.start, c.end, c.rev, buffer, res, cnt);
+        size_t n = 0;
+        for (int k = 0; k < K; k++)
+            if (cnt[k] > 0) n += cnt[k] - 1;
+        sa_segment_pair* out = (sa_segment_pair*)malloc(std::max<size_t>(n, 1) * sizeof(sa_segment_pair));
+        size_t off = 0;
+        for (int k = 0; k < K; k++) {
+            if (cnt[k] > 1) {
+                memcpy(out + off, res[k] + 1, (cnt[k] - 1) * sizeof(sa_segment_pair));
+                off += cnt[k] - 1;
+            }
+            free(res[k]);
+        }
+        results[i].device = K > 0 ? t_stats.device : 0;
+        results[i].reserved = 0;
+        results[i].hsps = out;
+        results[i].num_hsps = n;
+        results[i].num_hits = K > 0 ? t_stats.num_hits : 0;  // (an empty call leaves the thread's statistics of its previous call alone)
+        std::lock_guard<std::mutex> lk(mu);
+        tot.num_seeds += t_stats.num_seeds;
+        tot.num_hits += t_stats.num_hits;
+        tot.num_survivors += t_stats.num_survivors;
+        tot.num_anchors += t_stats.num_anchors;
+        tot.num_examined += t_stats.num_examined;
+        tot.num_examined_filter += t_stats.num_examined_filter;
+        tot.num_candidates += t_stats.num_candidates;
+        tot.num_forwarded += t_stats.num_forwarded;
+        tot.num_entropy += t_stats.num_entropy;
+        tot.num_iter += t_stats.num_iter;
+        tot.device = t_stats.device;
+        tot.lookup_path = t_stats.lookup_path;
+    });
+    size_t total = 0;
+    for (size_t i = 0; i < num_calls; i++) total += results[i].num_hsps;
+    if (totals) *totals = tot;
+    return total;
+}
+
+// The seed hits of every call of a list, lookup only (see the header): what a multi-GPU host weighs the calls of a pass with.
+void sa_count_call_hits(const sa_call_desc* calls, size_t num_calls, uint32_t buffer, int threads, uint64_t* hits) {
+    require_proc("CountCallHits", buffer);
+    run_parallel(num_calls, threads, [&](size_t i) {
+        const sa_call_desc& c = calls[i];
+        hits[i] = 0;
+        const uint32_t chunk = g_wga_chunk;
+        const int K = c.end > c.start ? (int)(((uint64_t)c.end - c.start + chunk - 1) / chunk) : 0;
+        if (K == 0) return;
+        if (K > SA_MAX_CHUNKS) {
+            fprintf(stderr, "Error: CountCallHits takes at most %d chunks per call\n", SA_MAX_CHUNKS);
+            exit(1);
+        }
+        Slot* sl = acquire_slot();
+        DevCtx* dc = sl->ctx;
+        const int rev = c.rev ? 1 : 0;
+        const uint8_t* q = rev ? dc->query_rc[buffer].codes : dc->query[buffer].codes;
+        const uint32_t qlen = g_query_len[buffer];
+        const uint32_t lim = qlen >= g_seed_size ? qlen - g_seed_size + 1 : 0;
+        const uint32_t send = std::min(c.end, lim);
+        uint32_t bpos[SA_MAX_CHUNKS + 1];
+        for (int k = 0; k <= K; k++) bpos[k] = (uint32_t)std::min<uint64_t>((uint64_t)c.start + (uint64_t)k * chunk, send);
+        const PackedBuf* q4 = rev ? &dc->query4_rc[buffer] : &dc->query4[buffer];
+        uint32_t ns = 0xFFFFFFFFu, words = 0;
+        if (td_eligible(dc, q4, rev ? &dc->query2_rc[buffer] : &dc->query2[buffer], rev ? &dc->query2[buffer] : &dc->query2_rc[buffer]))
+            ns = td_front(dc, sl, q, K, bpos, 0, &words);
+        if (ns != 0xFFFFFFFFu) {
+            if (ns > 0) hits[i] = sl->h_td_plan[K - 1].hit_base + sl->h_td_plan[K - 1].num_hits;
+            prof_flush(sl);
+            release_slot(sl);
+            return;
+        }
+        // no table-direct lookup for this call (general path, MAX_HITS split): the call's own statistics
+        prof_flush(sl);
+        release_slot(sl);
+        sa_segment_pair* res[SA_MAX_CHUNKS];
+        size_t cnt[SA_MAX_CHUNKS];
+        sa_seed_and_filter_chunks(c.start, c.end, rev, buffer, res, cnt);
+        for (int k = 0; k < K; k++) free(res[k]);
+        hits[i] = t_stats.num_hits;
+    });
+}
+
+size_t sa_device_make_seeds(uint32_t start, uint32_t end, int rev, uint32_t buffer, uint64_t* dst, size_t cap) {
+    require_proc("DeviceMakeSeeds", buffer);
+    Slot* sl = acquire_slot();
+    DevCtx* dc = sl->ctx;
+    const uint8_t* q = rev ? dc->query_rc[buffer].codes : dc->query[buffer].codes;
+    uint32_t qlen = g_query_len[buffer];
+    uint32_t lim = qlen >= g_seed_size ? qlen - g_seed_size + 1 : 0;
+    if (end > lim) end = lim;
+    uint32_t ns = device_seeds(sl, q, start, end);
+    size_t ncopy = std::min<size_t>(ns, cap);
+    if (ncopy) {
+        check_memcpy(hipMemcpyAsync(dst, sl->seeds.p, ncopy * sizeof(uint64_t), hipMemcpyDeviceToHost, sl->stream), "seeds d2h");
+        check_sync(sl->stream, "seeds d2h");
+    }
+    prof_flush(sl);
+    release_slot(sl);
+    return ns;
+}
+
+}  // extern "C"

@@ -1,0 +1,450 @@
+// api_setup.hip -- C-ABI, set-up side: InitializeInterface / InitializeProcessor / ShutdownProcessor, target and query upload,
+// GenerateShapePos / GenerateSeedPosTable (common/seed_filter_interface.cu, common/seed_pos_table.cu, src/seed_filter.cu:830-940).
+#include "engine_internal.h"
+
+namespace sa {
+
+// Every slot issues its kernels on a stream of its own, next to the upload stream.  The HIP runtime multiplexes streams onto
+// GPU_MAX_HW_QUEUES hardware queues (default 4), and two slots that share a queue run one after the other: with four slots the
+// small kernels of one call then wait behind another call's filter kernel instead of overlapping it (0.94 -> 1.03 Gbp/s on the
+// default workload with 8 queues).  The runtime reads the variable when it initialises, i.e. at the first HIP call of the process;
+// a value the user has set is left alone.
+static bool g_hwq_ours = false;  // the variable was unset when the library was loaded, i.e. the value 8 is this library's
+__attribute__((constructor)) static void default_hw_queues() {
+    g_hwq_ours = getenv("GPU_MAX_HW_QUEUES") == nullptr;
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
+// (No API reports how many hardware queues the runtime really uses.  When HIP was initialised before this library was loaded --
+//  a Python host that imported torch first -- the setenv above came too late and four slots run pairwise one after the other
+//  (1.03 -> 0.94 Gbp/s); such hosts export GPU_MAX_HW_QUEUES=8 themselves, as bench.py does.  Option debug says what applies.)
+static void report_hw_queues() {
+    const char* v = getenv("GPU_MAX_HW_QUEUES");
+    fprintf(stderr, "engine: %d slot(s) per device, GPU_MAX_HW_QUEUES=%s (%s)\n", SLOTS_PER_DEVICE, v ? v : "unset",
+            g_hwq_ours ? "set by this library at load time: in effect only if HIP was initialised afterwards" : "set by the host");
+}
+
+// ---- ASCII upload through the pinned ring (see DevCtx) -------------------------------------------------------------
+constexpr size_t UP_CHUNK = (size_t)32 << 20;
+const uint8_t* upload_ascii(DevCtx* dc, const char* src, size_t len, const char* tag) {
+    hipStream_t st = dc->admin;
+    dc->up_tmp.ensure(len + 64, tag);
+    for (int k = 0; k < 2; k++)
+        if (!dc->up_pinned[k]) {
+            if (hipHostMalloc((void**)&dc->up_pinned[k], UP_CHUNK) != hipSuccess || hipEventCreateWithFlags(&dc->up_ev[k], hipEventDisableTiming) != hipSuccess) {
+                fprintf(stderr, "Error: hipHostMalloc for the upload ring failed\n");
+                exit(12);
+            }
+        }
+    size_t i = 0;
+    for (size_t off = 0; off < len; off += UP_CHUNK, i++) {
+        const int k = (int)(i & 1);
+        const size_t n = std::min(UP_CHUNK, len - off);
+        if (i >= 2) hipEventSynchronize(dc->up_ev[k]);  // the DMA that last used this pinned buffer has finished
+        memcpy(dc->up_pinned[k], src + off, n);
+        check_memcpy(hipMemcpyAsync(dc->up_tmp.p + off, dc->up_pinned[k], n, hipMemcpyHostToDevice, st), tag);
+        hipEventRecord(dc->up_ev[k], st);
+    }
+    return dc->up_tmp.p;
+}
+
+// code presence of a freshly encoded block -> *host_mask (one small D2H; the callers synchronise the admin stream anyway)
+void presence_of(DevCtx* dc, const uint8_t* codes, uint32_t len, int slot, uint32_t* host_mask) {
+    if (!dc->d_present) dc->d_present = (uint32_t*)dev_malloc((1 + SA_BUFFER_DEPTH) * sizeof(uint32_t), "code presence");
+    check_memcpy(hipMemsetAsync(dc->d_present + slot, 0, sizeof(uint32_t), dc->admin), "code presence");
+    launch_code_presence(codes, len, dc->d_present + slot, dc->admin);
+    check_memcpy(hipMemcpyAsync(host_mask, dc->d_present + slot, sizeof(uint32_t), hipMemcpyDeviceToHost, dc->admin), "code presence");
+}
+
+}  // namespace sa
+
+using namespace sa;
+
+extern "C" {
+
+const char* sa_version(void) { return "segalign_amd 0.1 (gfx950)"; }
+
+void sa_select_devices(const int* ids, int n) {
+    g_selected.clear();
+    for (int i = 0; i < n; i++) g_selected.push_back(ids[i]);
+}
+
+void sa_shutdown_processor(void);
+static void destroy_interface();
+
+int sa_initialize_interface(int num_gpu) {  // seed_filter_interface.cu:49-80
+    int n = 0;
+    hipError_t err = hipGetDeviceCount(&n);
+    if (err != hipSuccess || n <= 0) {
+        fprintf(stderr, "Error: No GPU device found!\n");
+        exit(1);
+    }
+    if (!g_selected.empty()) {
+        // (an ordinal may be named more than once: every entry becomes an engine device of its own -- contexts, streams, tables,
+        //  arena, token-pool slots -- on that GPU.  That is how the multi-device paths are exercised on a one-GPU box.)
+        for (int id : g_selected)
+            if (id < 0 || id >= n) {
+                fprintf(stderr, "Requested GPUs greater than available GPUs\n");
+                exit(10);
+            }
+        n = (int)g_selected.size();
+    }
+    int use;
+    if (num_gpu == -1) use = n;
+    else if (num_gpu <= n) use = num_gpu;
+    else {
+        fprintf(stderr, "Requested GPUs greater than available GPUs\n");
+        exit(10);
+    }
+    fprintf(stderr, "Using %d GPU(s)\n", use);
+    if (!g_dev.empty()) destroy_interface();  // re-initialisation: release the previous contexts first
+    g_ndev = use;
+    for (int g = 0; g < use; g++) {
+        const int ord = g_selected.empty() ? g : g_selected[g];
+        check_set_device(ord, "InitializeInterface");
+        int twin = 0;  // how many earlier engine devices sit on the same ordinal (sa_select_devices with a repeated id)
+        for (int h = 0; h < g; h++) if (!g_selected.empty() && g_selected[h] == ord) twin++;
+        DevCtx* dc = new DevCtx(arena_of(ord + 64 * twin, ord));
+        dc->dev = ord;
+        dc->index = g;
+        hipStreamCreateWithFlags(&dc->admin, hipStreamNonBlocking);
+        hipDeviceProp_t prop;
+        hipGetDeviceProperties(&prop, ord);
+        dc->total_mem = prop.totalGlobalMem;
+        g_dev.push_back(dc);
+    }
+    return use;
+}
+
+void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_size, const int* sub_mat, int xdrop,
+                             int hspthresh, int noentropy) {  // src/seed_filter.cu:830-897
+    require_init("InitializeProcessor");
+    resolve_options();
+    if (xdrop >= (1 << 25) || xdrop <= -(1 << 25)) {
+        fprintf(stderr, "Error: |xdrop| must be below 2^25\n");
+        exit(1);
+    }
+    g_transition = transition ? 1 : 0;
+    g_wga_chunk = wga_chunk;
+    g_max_seeds = transition ? 13ll * wga_chunk : (int64_t)wga_chunk;  // :836-839
+    if (!g_max_hits_overridden) g_max_hits = max_hits_for_mem(g_dev[0]->total_mem);  // :832-841 (device 0)
+    g_seed_size = seed_size;
+    memcpy(g_sub_mat, sub_mat, sizeof(g_sub_mat));
+    g_xdrop = xdrop;
+    g_hspthresh = hspthresh;
+    g_noentropy = noentropy ? 1 : 0;
+    {
+        int mx = g_sub_mat[0];
+        for (int i = 1; i < 64; i++) mx = std::max(mx, g_sub_mat[i]);
+        g_fast_filter = (xdrop >= 0 && (int64_t)7 * std::max(mx, 0) <= (int64_t)xdrop) ? 1 : 0;
+        // int16 score arithmetic: the best of a side (<= max(M) * long_cap rounded up to whole 64-base windows) and xdrop itself must stay well inside
+        // the saturation range, or a walk could never satisfy the drop test and every hit would become a candidate
+        // the 4-bit query copies carry PACK_PAD bytes = 2 * PACK_PAD bases of padding: a capped walk must end inside it
+        if (g_long_cap > 2 * PACK_PAD) g_long_cap = 2 * PACK_PAD;
+        g_packed_filter = (xdrop >= 0 && xdrop <= 16383 && (int64_t)std::max(mx, 0) * (((int64_t)g_long_cap + 63) / 64 * 64) <= 16383 &&
+                           !opt_value("no_packed_filter")) ? 1 : 0;
+        if (opt_value("no_fast_filter")) { g_fast_filter = 0; g_packed_filter = 0; }
+    }
+    if (opt_value("debug")) report_hw_queues();
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_tokens.clear();
+    for (int g = 0; g < g_ndev; g++) {
+        DevCtx* dc = g_dev[g];
+        check_set_device(dc->dev, "InitializeProcessor");
+        if (!dc->d_sub_mat) dc->d_sub_mat = (int*)dev_malloc(64 * sizeof(int), "sub_mat");
+        check_memcpy(hipMemcpy(dc->d_sub_mat, g_sub_mat, 64 * sizeof(int), hipMemcpyHostToDevice), "sub_mat");
+        for (int k = 0; k < SLOTS_PER_DEVICE; k++) {
+            if (!dc->slots[k].stream) slot_init(dc->slots[k], dc);
+            dc->slots[k].seeds.ensure((size_t)g_max_seeds, "seed_offsets");
+        }
+        // start mapping the table arena now: the host still has its FASTA files to read (src/main.cpp:300-549)
+        if (g_arena_gb > 0 && g_td && g_ctx && g_packed_filter) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const size_t reserve = ((size_t)8 << 30) + ((size_t)4 << 30) * (size_t)SLOTS_PER_DEVICE;
+                const size_t have = arena_mapped(dc->arena);  // (no worker is running: ShutdownProcessor / process start)
+                const size_t room = free_b + have > reserve ? free_b + have - reserve : 0;
+                arena_request(dc->arena, std::min<size_t>((size_t)g_arena_gb << 30, room));
+            }
+        }
+    }
+    // LIFO pool like available_gpus (:895): slot-major so that concurrent callers spread over devices first
+    for (int k = SLOTS_PER_DEVICE - 1; k >= 0; k--)
+        for (int g = g_ndev - 1; g >= 0; g--) g_tokens.push_back({g, k});
+    g_proc_init = true;
+}
+
+// everything the engine holds on one device except the context itself (what the reference's cudaDeviceReset() wipes, :939)
+static void release_device_state(DevCtx* dc) {
+    check_set_device(dc->dev, "ShutdownProcessor");
+    hipDeviceSynchronize();
+    for (int k = 0; k < MAX_SLOTS_PER_DEVICE; k++) if (dc->slots[k].stream) slot_destroy(dc->slots[k]);
+    dc->ref.release("d_ref_seq");
+    dc->ref8.release("d_ref_seq rows");
+    dc->ref2.release("d_ref_seq 2-bit");
+    dc->ref_rc.release("d_seq_rc");
+    dc->ref4.release("d_seq 4-bit");
+    dc->ref4_rc.release("d_seq_rc 4-bit");
+    dc->refq2.release("d_seq 2-bit shifted");
+    dc->refq2_rc.release("d_seq_rc 2-bit shifted");
+    dev_free(dc->d_present, "code presence");
+    dc->d_present = nullptr;
+    dc->ref_host_ptr = nullptr;
+    nbr_release(dc);
+    // (the table arena stays mapped: it is a process-wide cache of cleared device pages that cost seconds to get; its background
+    //  worker is stopped here.  Option arena_gb = 0 gives the pages back now, sa_release_arena() whenever the host wants them)
+    if (g_arena_gb == 0) arena_destroy(dc->arena);
+    dev_free(dc->bucket_start, "d_index_table");
+    dev_free(dc->pos_table, "d_pos_table");
+    dc->bucket_start = dc->pos_table = nullptr;
+    dc->num_index = 0;
+    for (int b = 0; b < SA_BUFFER_DEPTH; b++) {
+        dc->query[b].release("d_query_seq");
+        dc->query_rc[b].release("d_query_rc_seq");
+        dc->query4[b].release("d_query_seq 4-bit");
+        dc->query4_rc[b].release("d_query_rc_seq 4-bit");
+        dc->query2[b].release("d_query_seq 2-bit");
+        dc->query2_rc[b].release("d_query_rc_seq 2-bit");
+    }
+    dc->up_tmp.release("upload staging");
+    for (int k = 0; k < 2; k++) {
+        if (dc->up_pinned[k]) hipHostFree(dc->up_pinned[k]);
+        if (dc->up_ev[k]) hipEventDestroy(dc->up_ev[k]);
+        dc->up_pinned[k] = nullptr;
+        dc->up_ev[k] = nullptr;
+    }
+    dev_free(dc->d_sub_mat, "sub_mat");
+    dc->d_sub_mat = nullptr;
+}
+
+// g_ShutdownProcessor (src/seed_filter.cu:932-940): the reference clears its device vectors and resets the device, which
+// also drops the target and the tables.  Same here; the INTERFACE (device list, contexts) stays, so a host may run
+// InitializeProcessor / SendRefWriteRequest again without a second InitializeInterface.
+void sa_shutdown_processor(void) {
+    arena_stop_all();
+    for (auto* dc : g_dev) release_device_state(dc);
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_tokens.clear();
+    }
+    g_proc_init = false;
+    for (uint32_t b = 0; b < SA_BUFFER_DEPTH; b++) g_query_len[b] = 0;
+}
+
+// The reference's cudaDeviceReset() (src/seed_filter.cu:939) frees everything; the engine keeps the table arena as a cache (see
+// release_device_state).  A host that wants the memory back -- before handing the GPU to LASTZ's gapped stage, say -- calls this
+// after ShutdownProcessor.
+void sa_release_arena(void) {
+    if (g_proc_init) {
+        fprintf(stderr, "Error: ReleaseArena while the processor is initialised (call ShutdownProcessor first)\n");
+        exit(1);
+    }
+    arena_release_all();
+}
+
+static void destroy_interface() {  // re-initialisation of the interface: contexts go too
+    sa_shutdown_processor();
+    for (auto* dc : g_dev) {
+        check_set_device(dc->dev, "InitializeInterface");
+        if (dc->admin) hipStreamDestroy(dc->admin);
+        delete dc;
+    }
+    g_dev.clear();
+    g_ndev = 0;
+}
+
+// ---- target ---------------------------------------------------------------------------------------------------------
+void sa_send_ref_write_request(const char* seq, size_t addr, uint32_t len) {  // seed_filter_interface.cu:82-101
+    require_init("SendRefWriteRequest");
+    for (auto* dc : g_dev) {
+        check_set_device(dc->dev, "SendRefWriteRequest");
+        const uint8_t* tmp = upload_ascii(dc, seq + addr, len, "ref_seq");
+        dc->ref.create(len, "ref_seq", dc->admin);
+        launch_encode(tmp, dc->ref.codes, len, dc->admin);
+        dc->ref8.create(len, "ref_seq rows", dc->admin, true);
+        launch_row_code(dc->ref.codes, dc->ref8.codes, len, dc->admin);
+        dc->ref2.create(dc->ref.codes, len, 2, "ref_seq 2-bit", dc->admin);
+        presence_of(dc, dc->ref.codes, len, 0, &dc->ref_present);
+        check_launch("compress_string");
+        check_sync(dc->admin, "SendRefWriteRequest");
+        dc->ref_host_ptr = seq + addr;
+        nbr_release(dc);  // a neighbourhood table built for another block must not survive (its context records are target bases)
+    }
+}
+
+void sa_clear_ref(void) {  // seed_filter_interface.cu:103-113
+    for (auto* dc : g_dev) {
+        check_set_device(dc->dev, "ClearRef");
+        dc->ref.release("d_ref_seq");
+        dc->ref8.release("d_ref_seq rows");
+        dc->ref2.release("d_ref_seq 2-bit");
+        dc->ref_host_ptr = nullptr;
+        nbr_release(dc);
+        dev_free(dc->bucket_start, "d_index_table");
+        dev_free(dc->pos_table, "d_pos_table");
+        dc->bucket_start = dc->pos_table = nullptr;
+        dc->num_index = 0;
+    }
+}
+
+int sa_generate_shape_pos(const char* shape) {  // ntcoding.cpp:21-37
+    SeedShape sh;
+    memset(&sh, 0, sizeof(sh));
+    int n = 0, span = 0;
+    for (int i = 0; shape[i] != '\0'; i++, span++) {
+        if (shape[i] == '1' || shape[i] == 'T') {
+            if (n >= MAX_CARE) {
+                fprintf(stderr, "Error: seed weight above %d is not supported\n", MAX_CARE - 1);
+                exit(1);
+            }
+            sh.pos[n] = (uint8_t)i;
+            if (shape[i] == 'T') sh.transition_mask |= 1u << n;
+            n++;
+        }
+    }
+    if (span > 32) {
+        fprintf(stderr, "Error: seed span above 32 is not supported\n");
+        exit(1);
+    }
+    sh.weight = n;
+    sh.span = span;
+    g_shape = sh;
+    return n;
+}
+
+void sa_generate_seed_pos_table(const char* ref_str, size_t start_addr, uint32_t ref_length, uint32_t step, int shape_size,
+                                int kmer_size) {  // seed_pos_table.cu:49-109
+    require_init("GenerateSeedPosTable");
+    if (!(kmer_size <= 15 && kmer_size > 3)) {  // asserts at :51-52
+        fprintf(stderr, "Error: GenerateSeedPosTable requires 3 < kmer_size <= 15\n");
+        exit(1);
+    }
+    if (step == 0) step = 1;
+    const uint32_t offset = (uint32_t)(shape_size + 1) % step;                       // :58
+    const uint32_t start_offset = step - offset;                                     // :59
+    const uint32_t nkeys = (uint32_t)1 << (2 * kmer_size);                           // :61
+    const uint32_t num_steps = ref_length >= (uint32_t)shape_size ? (ref_length - (uint32_t)shape_size + offset) / step : 0;  // :64
+    SeedShape sh = g_shape;
+    sh.span = shape_size;
+    // every device builds its own copy of the tables (the reference builds once on the host and replicates, seed_pos_table.cu:
+    // 33-47); the builds are independent, so with several devices they run CONCURRENTLY, one host thread per device
+    auto build_on = [&](DevCtx* dc) {
+        check_set_device(dc->dev, "GenerateSeedPosTable");
+        hipStream_t st = dc->admin;
+        const uint8_t* codes = dc->ref.codes;
+        SeqBuf tmp_codes;
+        if (!(dc->ref.codes && dc->ref_host_ptr == ref_str + start_addr && dc->ref.len == ref_length)) {
+            // not the resident block: encode a private copy
+            const uint8_t* tmp = upload_ascii(dc, ref_str + start_addr, ref_length, "table seq");
+            tmp_codes.create(ref_length, "table codes", st);
+            launch_encode(tmp, tmp_codes.codes, ref_length, st);
+            check_sync(st, "table encode");
+            codes = tmp_codes.codes;
+        }
+        nbr_release(dc);
+        dev_free(dc->bucket_start, "d_index_table");
+        dev_free(dc->pos_table, "d_pos_table");
+        dc->bucket_start = (uint32_t*)dev_malloc(((size_t)nkeys + 1) * sizeof(uint32_t), "index_table");
+        uint32_t num_index = 0;
+        if (table_partition_build_supported(kmer_size) && !g_table_atomic) {
+            // PARTITION build (table.hip): keys + coarse histogram -> offsets of the 4096 coarse partitions -> two LDS-staged
+            // partition passes -> one workgroup per partition finishes its slice of bucket_start and pos_table in LDS
+            const size_t pw = table_partition_part_start_words();
+            uint32_t* keys = (uint32_t*)dev_malloc((size_t)std::max<uint32_t>(num_steps, 1) * sizeof(uint32_t), "kmer keys");
+            uint32_t* coarse = (uint32_t*)dev_malloc(3 * pw * sizeof(uint32_t) + 4096, "coarse histogram");  // hist | part_start | cursor | flags
+            uint32_t* part_start = coarse + pw;
+            uint32_t* cursor = part_start + pw;
+            uint8_t* part_unsorted = reinterpret_cast<uint8_t*>(cursor + pw);
+            void* scan_tmp = dev_malloc(scan_temp_bytes(pw), "scan temp");
+            check_memcpy(hipMemsetAsync(coarse, 0, pw * sizeof(uint32_t), st), "coarse histogram");
+            launch_table_keys(codes, num_steps, start_offset, step, sh, keys, coarse, st);
+            launch_exclusive_scan_u32(coarse, part_start, pw - 1, scan_tmp, st);
+            check_launch("table keys/scan");
+            check_memcpy(hipMemcpyAsync(&num_index, part_start + (pw - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st), "num_index");
+            check_sync(st, "table keys");
+            const size_t np = std::max<uint32_t>(num_index, 1);
+            dc->pos_table = (uint32_t*)dev_malloc(np * sizeof(uint32_t), "pos_table");
+            uint32_t* pairs = (uint32_t*)dev_malloc(4 * np * sizeof(uint32_t), "partition pairs");  // key_a | pos_a | key_b | pos_b
+            launch_table_partition_build(keys, num_steps, start_offset, step, kmer_size, part_start, num_index, cursor, pairs, pairs + np,
+                                         pairs + 2 * np, pairs + 3 * np, part_unsorted, dc->bucket_start, dc->pos_table, st);
+            check_launch("table partition");
+            check_sync(st, "table partition");
+            dev_free(pairs, "partition pairs");
+            dev_free(keys, "kmer keys");
+            dev_free(coarse, "coarse histogram");
+            dev_free(scan_tmp, "scan temp");
+        } else {
+            // ATOMIC build: histogram + scatter with one global atomic per position (any seed weight)
+            uint32_t* hist = (uint32_t*)dev_malloc(((size_t)nkeys + 1) * sizeof(uint32_t), "kmer histogram");
+            void* scan_tmp = dev_malloc(scan_temp_bytes(nkeys), "scan temp");
+            check_memcpy(hipMemsetAsync(hist, 0, ((size_t)nkeys + 1) * sizeof(uint32_t), st), "histogram");
+            launch_table_count(codes, num_steps, start_offset, step, sh, hist, st);
+            launch_exclusive_scan_u32(hist, dc->bucket_start, nkeys, scan_tmp, st);
+            check_launch("table count/scan");
+            check_memcpy(hipMemcpyAsync(&num_index, dc->bucket_start + nkeys, sizeof(uint32_t), hipMemcpyDeviceToHost, st),
+                         "num_index");
+            check_sync(st, "table count");
+            dc->pos_table = (uint32_t*)dev_malloc((size_t)std::max<uint32_t>(num_index, 1) * sizeof(uint32_t), "pos_table");
+            check_memcpy(hipMemsetAsync(hist, 0, ((size_t)nkeys + 1) * sizeof(uint32_t), st), "cursor");
+            launch_table_fill(codes, num_steps, start_offset, step, sh, dc->bucket_start, hist, dc->pos_table, st);
+            launch_table_sort_buckets(dc->bucket_start, nkeys, dc->pos_table, st);
+            check_launch("table fill/sort");
+            check_sync(st, "table fill");
+            dev_free(hist, "kmer histogram");
+            dev_free(scan_tmp, "scan temp");
+        }
+        tmp_codes.release("table codes");
+        dc->num_index = num_index;
+        dc->nkeys = nkeys;
+        // the neighbourhood table belongs to the table build when the processor parameters are already known (the reference
+        // calls InitializeProcessor first, src/main.cpp:298 before :621); otherwise the first table-direct call builds it
+        if (g_proc_init && g_packed_filter) ensure_nbr(dc);
+    };
+    if (g_dev.size() <= 1) {
+        for (auto* dc : g_dev) build_on(dc);
+    } else {
+        std::vector<std::thread> builders;
+        for (auto* dc : g_dev) builders.emplace_back(build_on, dc);
+        for (auto& t : builders) t.join();
+    }
+}
+
+// ---- query ----------------------------------------------------------------------------------------------------------
+void sa_send_query_write_request(const char* query_buffer, size_t addr, uint32_t len, uint32_t buffer) {  // :899-919
+    require_init("SendQueryWriteRequest");
+    if (buffer >= SA_BUFFER_DEPTH) {
+        fprintf(stderr, "Error: query buffer %u out of range\n", buffer);
+        exit(1);
+    }
+    g_query_len[buffer] = len;
+    for (auto* dc : g_dev) {
+        check_set_device(dc->dev, "SendQueryWriteRequest");
+        hipStream_t st = dc->admin;
+        const uint8_t* tmp = upload_ascii(dc, query_buffer + addr, len, "query_seq");
+        dc->query[buffer].create(len, "query_seq", st);
+        dc->query_rc[buffer].create(len, "query_rc_seq", st);
+        launch_encode_rev_comp(tmp, dc->query[buffer].codes, dc->query_rc[buffer].codes, len, st);
+        dc->query4[buffer].create(dc->query[buffer].codes, len, 4, "query_seq 4-bit", st);
+        dc->query4_rc[buffer].create(dc->query_rc[buffer].codes, len, 4, "query_rc_seq 4-bit", st);
+        dc->query2[buffer].create_q2(dc->query[buffer].codes, len, "query_seq 2-bit", st);
+        dc->query2_rc[buffer].create_q2(dc->query_rc[buffer].codes, len, "query_rc_seq 2-bit", st);
+        presence_of(dc, dc->query[buffer].codes, len, 1 + (int)buffer, &dc->query_present[buffer]);
+        check_launch("compress_string_rev_comp");
+        check_sync(st, "SendQueryWriteRequest");
+    }
+}
+
+void sa_clear_query(uint32_t buffer) {  // :921-930
+    if (buffer >= SA_BUFFER_DEPTH) return;
+    for (auto* dc : g_dev) {
+        // the reference frees here (:921-930); the engine keeps the allocations for the next block of this buffer: a
+        // hipFree would synchronise the device under the calls that are running on the OTHER query buffer
+        dc->query[buffer].clear();
+        dc->query_rc[buffer].clear();
+        dc->query4[buffer].clear();
+        dc->query4_rc[buffer].clear();
+        dc->query2[buffer].clear();
+        dc->query2_rc[buffer].clear();
+    }
+}
+
+}  // extern "C"

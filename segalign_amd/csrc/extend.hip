@@ -1553,7 +1553,7 @@ void launch_extend_filter(const ExtendArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL((extend_filter_kernel<false, false>), dim3(blocks), dim3(EXT_THREADS), 0, s, a);
 }
 
-// class filter (1d): table-direct calls whose neighbourhood table carries 28-byte context records; fills a.l2_list
+// class filter (1d): table-direct calls whose neighbourhood table carries 32-byte context records; fills a.l2_list
 void launch_extend_filter_cls(const ExtendArgs& a, hipStream_t s) {
     if (a.num_hits == 0) return;
     uint64_t waves = (a.num_hits + TD_CHUNK_HITS - 1) / TD_CHUNK_HITS;  // at most one wave per chunk

@@ -1,0 +1,329 @@
+// front.hip -- the front of a call: seed-vector upload, the device-side seeder (8f-1), the neighbourhood table build and the
+// table-direct position probe with its chunk plans (probe.hip), and the on-device check that lets g_SeedAndFilter take that path.
+#include "engine_internal.h"
+
+namespace sa {
+
+void upload_seeds(Slot* sl, const uint64_t* seeds, size_t n) {
+    sl->seeds.ensure(std::max<size_t>(n, (size_t)g_max_seeds), "seed_offsets");
+    if (n == 0) return;
+    if (g_seed_upload == 1) {  // the runtime stages the pageable vector itself (chunked, synchronous for the caller)
+        ProfScope p(sl, "h2d_seeds");
+        check_memcpy(hipMemcpyAsync(sl->seeds.p, seeds, n * sizeof(uint64_t), hipMemcpyHostToDevice, sl->stream), "seed_offsets");
+        return;
+    }
+    if (g_seed_upload == 2) {  // pin the caller's pages for the duration of the copy
+        const uintptr_t lo = (uintptr_t)seeds & ~(uintptr_t)4095, hi = ((uintptr_t)(seeds + n) + 4095) & ~(uintptr_t)4095;
+        if (hipHostRegister((void*)lo, hi - lo, hipHostRegisterDefault) == hipSuccess) {
+            {
+                ProfScope p(sl, "h2d_seeds");
+                check_memcpy(hipMemcpyAsync(sl->seeds.p, seeds, n * sizeof(uint64_t), hipMemcpyHostToDevice, sl->stream), "seed_offsets");
+            }
+            check_sync(sl->stream, "seed_offsets");
+            hipHostUnregister((void*)lo);
+            return;
+        }
+        (void)hipGetLastError();
+    }
+    if (sl->h_seeds_cap < n) {
+        if (sl->h_seeds) hipHostFree(sl->h_seeds);
+        sl->h_seeds_cap = std::max<size_t>(n, (size_t)g_max_seeds);
+        if (hipHostMalloc((void**)&sl->h_seeds, sl->h_seeds_cap * sizeof(uint64_t)) != hipSuccess) {
+            fprintf(stderr, "Error: hipHostMalloc for seed_offsets failed\n");
+            exit(12);
+        }
+    }
+    memcpy(sl->h_seeds, seeds, n * sizeof(uint64_t));  // reference copies the vector too (:694-697)
+    ProfScope p(sl, "h2d_seeds");
+    check_memcpy(hipMemcpyAsync(sl->seeds.p, sl->h_seeds, n * sizeof(uint64_t), hipMemcpyHostToDevice, sl->stream),
+                 "seed_offsets");  // :710
+}
+
+// device-side seeder (8f-1): fills sl->seeds for query positions [start,end); returns number of seed words
+// nb > 0: also reports, for nb positions bpos[] in [start, end], the number of seed words emitted before them
+uint32_t device_seeds(Slot* sl, const uint8_t* qcodes, uint32_t start, uint32_t end, int nb, const uint32_t* bpos, uint32_t* bseed) {
+    for (int b = 0; b < nb; b++) bseed[b] = 0;
+    if (end <= start) return 0;
+    hipStream_t st = sl->stream;
+    const uint32_t n = end - start;
+    SeedShape sh = g_shape;
+    sh.span = (int)g_seed_size;
+    const uint32_t tmask = g_transition ? (sh.transition_mask & ((1u << sh.weight) - 1u)) : 0u;
+    const uint32_t per = 1u + (uint32_t)__builtin_popcount(tmask);
+    sl->flags.ensure(n, "seed flags");
+    sl->flag_prefix.ensure((size_t)n + 1, "seed flag prefix");
+    sl->scan_temp.ensure(scan_temp_bytes(n), "scan temp");
+    {
+        ProfScope p(sl, "seed_flags");
+        launch_seed_flags(qcodes, start, end, sh, sl->flags.p, st);
+    }
+    {
+        ProfScope p(sl, "seed_flag_scan");
+        launch_exclusive_scan_u32(sl->flags.p, sl->flag_prefix.p, n, sl->scan_temp.p, st);
+    }
+    check_launch("seed flags");
+    uint32_t nvalid = 0;
+    check_memcpy(hipMemcpyAsync(&sl->h_cnt->pad, sl->flag_prefix.p + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st), "nvalid");
+    for (int b = 0; b < nb; b++)
+        check_memcpy(hipMemcpyAsync(&sl->h_bounds[b], sl->flag_prefix.p + (std::min(std::max(bpos[b], start), end) - start), sizeof(uint32_t),
+                                    hipMemcpyDeviceToHost, st), "chunk bounds");
+    check_sync(st, "seed flags");
+    nvalid = sl->h_cnt->pad;
+    for (int b = 0; b < nb; b++) bseed[b] = sl->h_bounds[b] * per;
+    const uint64_t nseeds = (uint64_t)nvalid * per;
+    if (nseeds == 0) return 0;
+    sl->seeds.ensure(std::max<size_t>((size_t)nseeds, (size_t)g_max_seeds), "seed_offsets");
+    {
+        ProfScope p(sl, "seed_emit");
+        launch_seed_emit(qcodes, start, end, sh, g_transition, sl->flag_prefix.p, sl->seeds.p, st);
+    }
+    check_launch("seed emit");
+    return (uint32_t)nseeds;
+}
+
+// ---- table-direct lookup (probe.hip) -----------------------------------------------------------------------------------
+uint32_t seed_tmask() {
+    return g_transition ? (g_shape.transition_mask & ((1u << g_shape.weight) - 1u)) : 0u;
+}
+
+__global__ void widen_u32_kernel(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[i];
+}
+
+void nbr_release(DevCtx* dc) {
+    dev_free(dc->nbr_start, "nbr_start");
+    if (!dc->nbr_alias) dev_free(dc->nbr_pos, "nbr_pos");
+    dc->nbr_start = nullptr;
+    dc->nbr_pos = nullptr;
+    dc->nbr_ctx = nullptr;  // (the memory stays with the arena)
+    dc->nbr_alias = false;
+    dc->nbr_total = 0;
+    dc->nbr_state = 0;
+}
+
+// Builds (once per table and transition mask) the neighbourhood table of the device; false when it is not available:
+// no table yet, a merged run longer than 2^32 entries, or not enough free HBM for (words per position) x pos_table.
+bool ensure_nbr(DevCtx* dc) {
+    if (!g_td || !dc->bucket_start || !dc->pos_table) return false;
+    const uint32_t tmask = seed_tmask();
+    std::lock_guard<std::mutex> lk(dc->nbr_mu);
+    if (dc->nbr_state != 0 && dc->nbr_tmask == tmask) return dc->nbr_state == 1;
+    check_set_device(dc->dev, "neighbourhood table");
+    hipStream_t st = dc->admin;
+    nbr_release(dc);
+    dc->nbr_tmask = tmask;
+    dc->nbr_state = -1;
+    const uint32_t nkeys = dc->nkeys;
+    dc->nbr_start = (uint64_t*)dev_malloc(((size_t)nkeys + 1) * sizeof(uint64_t), "nbr_start");
+    uint64_t total = dc->num_index;
+    if (tmask == 0) {  // one word per position: the runs ARE the buckets
+        hipLaunchKernelGGL(widen_u32_kernel, dim3(4096), dim3(256), 0, st, dc->bucket_start, dc->nbr_start, nkeys + 1);
+        check_launch("nbr widen");
+        check_sync(st, "nbr widen");
+    } else {
+        uint32_t* cnt = (uint32_t*)dev_malloc(((size_t)nkeys + 1) * sizeof(uint32_t), "nbr counts");
+        void* scan_tmp = dev_malloc(scan_temp_bytes(nkeys), "scan temp");
+        check_memcpy(hipMemsetAsync(cnt + nkeys, 0, sizeof(uint32_t), st), "nbr overflow flag");  // cnt[nkeys] doubles as the flag
+        launch_nbr_count(dc->bucket_start, nkeys, tmask, g_shape.weight, cnt, cnt + nkeys, st);
+        launch_exclusive_scan_u64(cnt, dc->nbr_start, nkeys, scan_tmp, st);
+        check_launch("nbr count/scan");
+        uint32_t overflow = 0;
+        check_memcpy(hipMemcpyAsync(&total, dc->nbr_start + nkeys, sizeof(uint64_t), hipMemcpyDeviceToHost, st), "nbr total");
+        check_memcpy(hipMemcpyAsync(&overflow, cnt + nkeys, sizeof(uint32_t), hipMemcpyDeviceToHost, st), "nbr overflow");
+        check_sync(st, "nbr count");
+        dev_free(cnt, "nbr counts");
+        dev_free(scan_tmp, "scan temp");
+        if (overflow) {
+            dev_free(dc->nbr_start, "nbr_start");
+            dc->nbr_start = nullptr;
+            return false;
+        }
+    }
+    const bool dbg = opt_value("debug") != 0;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_a = now();
+    // (what the arena already holds does not count against the free memory.  Read BEFORE the free figure: a chunk the background
+    //  worker maps in between is then missing from both, never counted twice)
+    const size_t have = arena_mapped(dc->arena);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = total_b = 0;  // (then only the plain lookup modes are tried)
+    // keep room for the slots' work buffers: at human-scale hit density a sixteen-chunk call holds ~6 GB of lists per slot
+    const size_t reserve = ((size_t)8 << 30) + ((size_t)4 << 30) * (size_t)SLOTS_PER_DEVICE;
+    const size_t need_pos = (size_t)std::max<uint64_t>(total, 1) * sizeof(uint32_t);
+    // context records (class filter): 32 bytes per entry; the two-stage fill wants num_index records of scratch behind them, which is
+    // given up (one-stage fill) when only the table itself fits.  (+ 16 KB of slack: the filter requests two buffers ahead, so
+    // its lanes read up to 3 x 64 entries past the last run)
+    const size_t rec_b = (size_t)std::max<uint64_t>(total, 1) * sizeof(CtxRec) + 16384;
+    const size_t scratch_b = (size_t)dc->num_index * sizeof(CtxRec);
+    bool built = false;
+    if (g_ctx && dc->ref2.base && rec_b + reserve <= free_b + have) {
+        const bool two_stage = g_nbr_two_stage && tmask != 0 && rec_b + scratch_b + reserve <= free_b + have;
+        const size_t need = rec_b + (two_stage ? scratch_b : 0);
+        if (arena_wait(dc->arena, need)) {
+            arena_settle(dc->arena, need);
+            uint8_t* arena = dc->arena.base;
+            dc->nbr_ctx = reinterpret_cast<CtxRec*>(arena);
+            if (dbg) fprintf(stderr, "neighbourhood table: %.1f M entries, waited %.1f ms for %.1f GB of arena\n", total / 1e6, now() - t_a, need / 1e9);
+            const double t_b = now();
+            launch_nbr_fill_ctx(dc->bucket_start, dc->pos_table, nkeys, tmask, g_shape.weight, dc->nbr_start, dc->ref2.base, dc->ref2.stride,
+                                g_seed_size, dc->nbr_ctx, two_stage ? reinterpret_cast<CtxRec*>(arena + rec_b) : nullptr, (uint32_t)dc->num_index, st);
+            check_launch("nbr fill ctx");
+            check_sync(st, "nbr fill ctx");
+            if (dbg) fprintf(stderr, "neighbourhood table: context fill (%s) took %.1f ms\n", two_stage ? "two-stage" : "one-stage", now() - t_b);
+            built = true;
+        }
+    }
+    if (built) {
+        // (nothing else to do)
+    } else if (tmask == 0) {
+        dc->nbr_pos = dc->pos_table;
+        dc->nbr_alias = true;
+    } else if ([&] {  // positions only: an arena kept from an earlier (smaller) block gives its memory back first
+                   if (arena_mapped(dc->arena)) {
+                       arena_trim(dc->arena, 0);
+                       hipDeviceSynchronize();
+                       if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+                   }
+                   if (dbg) fprintf(stderr, "neighbourhood table: no room for the context table (%.1f GB + %.1f GB reserve), positions only need %.1f GB, free %.1f GB\n",
+                                    rec_b / 1e9, reserve / 1e9, need_pos / 1e9, free_b / 1e9);
+                   return need_pos + reserve <= free_b;
+               }()) {
+        dc->nbr_pos = (uint32_t*)dev_malloc(need_pos, "nbr_pos");
+        launch_nbr_fill(dc->bucket_start, dc->pos_table, nkeys, tmask, g_shape.weight, dc->nbr_start, dc->nbr_pos, st);
+        check_launch("nbr fill");
+        check_sync(st, "nbr fill");
+    } else {
+        dev_free(dc->nbr_start, "nbr_start");
+        dc->nbr_start = nullptr;
+        return false;
+    }
+    dc->nbr_total = total;
+    dc->nbr_state = 1;
+    return true;
+}
+
+// may this call take the table-direct path?  (the anchors are only ever read by the packed filter's TD fetch)
+// With the context table resident the only anchor source of a table-direct call is the class filter, which needs the 2-bit shifted
+// copies of BOTH query strands, all sixteen of a strand below `q2_limit` bytes (one 32-bit offset next to a scalar base: blocks of up
+// to ~1 Gbp).  A call that cannot have them takes the general path.
+bool q2_usable(const PackedBuf* q2_own, const PackedBuf* q2_other) {
+    return q2_own && q2_own->base && q2_other && q2_other->base && q2_own->stride * Q2_COPIES < g_q2_limit &&
+           q2_other->stride * Q2_COPIES < g_q2_limit;
+}
+bool td_eligible(DevCtx* dc, const PackedBuf* query4, const PackedBuf* q2_own, const PackedBuf* q2_other) {
+    if (!(g_td && g_packed_filter && !g_count_examined && query4 && query4->base && dc->ref2.base && ensure_nbr(dc))) return false;
+    return !dc->nbr_ctx || q2_usable(q2_own, q2_other);
+}
+
+// Position probe + chunk plans for query positions [bpos[0], bpos[K]) (chunk c = [bpos[c], bpos[c+1])); one D2H, one sync.
+// Returns the number of seed words the reference would have been handed (0: nothing to do), or UINT32_MAX when the call must
+// take the general path: a chunk with num_hits >= MAX_HITS (more than two reference iterations), hit counts that wrap the
+// reference's uint32 arithmetic, or more than 2^32 hits in the call (the filter indexes hits with 32 bits).
+uint32_t td_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, int K, const uint32_t* bpos, int rm, uint32_t* words_out) {
+    hipStream_t st = sl->stream;
+    const uint32_t start = bpos[0], end = bpos[K];
+    const uint32_t tmask = seed_tmask();
+    const uint32_t words = 1u + (uint32_t)__builtin_popcount(tmask);
+    *words_out = words;
+    if (end <= start) return 0;
+    const uint32_t n = end - start;
+    SeedShape sh = g_shape;
+    sh.span = (int)g_seed_size;
+    sl->td_toff.ensure(n, "probe scratch");
+    sl->td_tcnt.ensure(n, "probe scratch");
+    sl->td_rec.ensure((size_t)n + 1, "probe records");
+    sl->td_chunk.ensure(TD_CHUNK_CAP, "probe chunk starts");
+    sl->td_partial.ensure(probe_partial_bytes(n), "probe partials");
+    TdBounds tb;
+    tb.nb = K + 1;
+    for (int c = 0; c <= K; c++) tb.pos[c] = bpos[c];
+    {
+        ProfScope p(sl, "seed_probe");
+        launch_probe_lookup(qcodes, start, n, sh, dc->nbr_start, dc->nkeys, sl->td_toff.p, sl->td_tcnt.p, sl->td_partial.p, st);
+    }
+    // head-bit map for the class filter: sized for 128 hits per position; a denser call regrows it (it stays) and repeats the compaction
+    const bool want_bits = dc->nbr_ctx != nullptr;
+    if (want_bits) sl->td_bits.ensure(std::max<size_t>((size_t)n * 4 + 64, 1u << 16), "probe head bits");
+    // the device-side state the later stages of the call expect zeroed is cleared by the probe's own clearing kernel
+    sl->l2_counts.ensure((size_t)L2_NSUB * L2_CNT_STRIDE, "second-level counters");
+    sl->chain_bucket_cnt.ensure(chain_num_buckets(), "chain buckets");
+    ZeroList zl;
+    zl.p[0] = reinterpret_cast<uint32_t*>(sl->d_cnt);  zl.n[0] = (uint32_t)(sizeof(Counters) / sizeof(uint32_t));
+    zl.p[1] = sl->l2_counts.p;                         zl.n[1] = (uint32_t)(L2_NSUB * L2_CNT_STRIDE);
+    zl.p[2] = sl->chain_bucket_cnt.p;                  zl.n[2] = chain_num_buckets();
+    zl.p[3] = sl->d_seg_info;                          zl.n[3] = dedup_seg_info_words();
+    for (bool first_pass = true;; first_pass = false) {
+        {
+            ProfScope p(sl, "probe_compact");
+            launch_probe_compact(start, n, sl->td_toff.p, sl->td_tcnt.p, sl->td_partial.p, sl->d_td_bounds, sl->td_rec.p, sl->td_chunk.p, TD_CHUNK_CAP,
+                                 want_bits ? sl->td_bits.p : nullptr, (uint32_t)std::min<size_t>(sl->td_bits.cap, 0xFFFFFFFFu), zl, tb, first_pass, st);
+        }
+        {
+            ProfScope p(sl, "iteration_plan");
+            launch_probe_plan(qcodes, sh, tmask, dc->bucket_start, sl->d_td_bounds, K, sl->td_rec.p, sl->d_td_plan, st);
+        }
+        check_launch("probe");
+        check_memcpy(hipMemcpyAsync(sl->h_td_plan, sl->d_td_plan, sizeof(TdPlan) * K, hipMemcpyDeviceToHost, st), "probe plan");
+        check_sync(st, "probe plan");
+        const uint64_t call_hits = sl->h_td_plan[K - 1].hit_base + sl->h_td_plan[K - 1].num_hits;
+        const uint64_t need_words = ((call_hits + 63) >> 6) * 2 + 16;  // (the filter reads up to six 64-bit words past the last buffer)
+        if (!want_bits || need_words <= sl->td_bits.cap || call_hits > 0xFFFFFFFFull) break;
+        sl->td_bits.ensure((size_t)need_words + need_words / 4, "probe head bits(grow)");
+    }
+    uint64_t nvalid = 0;
+    for (int c = 0; c < K; c++) {
+        const TdPlan& tp = sl->h_td_plan[c];
+        nvalid += tp.num_valid;
+        if (tp.num_hits >= (uint64_t)(uint32_t)g_max_hits) return 0xFFFFFFFFu;
+        if (!rm && tp.num_hits > 0xFFFFFFFFull) return 0xFFFFFFFFu;
+    }
+    if (sl->h_td_plan[K - 1].hit_base + sl->h_td_plan[K - 1].num_hits >= 0xFFFFFFFFull) return 0xFFFFFFFFu;  // (hit indices are 32-bit, 2^32 - 1 is a sentinel)
+    if (nvalid * words >= 0xFFFFFFFFull) return 0xFFFFFFFFu;
+    return (uint32_t)(nvalid * words);
+}
+
+// DROP-IN FAST PATH.  g_SeedAndFilter hands the engine a host seed vector (src/seeder.cpp:57-78).  When that vector is exactly
+// what the device seeder would emit for the positions it spans -- checked on the device, one lane per position group, plus the
+// probe's own count of valid positions -- the call is the same as sa_seed_and_filter_range(first, last + 1) and takes the
+// table-direct path (one probe per position, record-stream filter).  Anything else keeps the reference-shaped path on the
+// uploaded words: hand-made vectors, and the reference's minus-strand arena when the query holds other IUPAC letters (H14).
+// Returns the seed-word count of the table-direct call, or UINT32_MAX.
+uint32_t dropin_td_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, uint32_t qlen, const uint64_t* host_seeds, size_t n,
+                                const PackedBuf* q4, const PackedBuf* q2_own, const PackedBuf* q2_other, int rm, uint32_t* first_out,
+                                uint32_t* end_out, uint32_t* words_out) {
+    if (n == 0 || !td_eligible(dc, q4, q2_own, q2_other)) return 0xFFFFFFFFu;
+    const uint32_t tmask = seed_tmask();
+    const uint32_t per = 1u + (uint32_t)__builtin_popcount(tmask);
+    if (n % per != 0 || n > 0xFFFFFFFFull) return 0xFFFFFFFFu;
+    const uint32_t first = (uint32_t)host_seeds[0], last = (uint32_t)host_seeds[n - 1];
+    if (last < first || (uint64_t)last + g_seed_size > qlen) return 0xFFFFFFFFu;
+    hipStream_t st = sl->stream;
+    SeedShape sh = g_shape;
+    sh.span = (int)g_seed_size;
+    *sl->h_verify = 0;
+    check_memcpy(hipMemsetAsync(sl->d_verify, 0xFF, sizeof(uint32_t), st), "seed verify flag");
+    {
+        ProfScope p(sl, "seed_verify");
+        launch_seed_verify(sl->seeds.p, (uint32_t)(n / per), per, qcodes, qlen, sh, tmask, sl->d_verify, st);
+    }
+    check_memcpy(hipMemcpyAsync(sl->h_verify, sl->d_verify, sizeof(uint32_t), hipMemcpyDeviceToHost, st), "seed verify flag");
+    const uint32_t bp[2] = {first, last + 1u};
+    const uint32_t ns = td_front(dc, sl, qcodes, 1, bp, rm, words_out);  // (synchronises the stream: the flag has arrived)
+    if (ns == 0xFFFFFFFFu || *sl->h_verify == 0u || (uint64_t)ns != (uint64_t)n) return 0xFFFFFFFFu;
+    *first_out = first;
+    *end_out = last + 1u;
+    return ns;
+}
+
+void set_query2(CoreArgs& ca, DevCtx* dc, uint32_t buffer, int rev) {  // plain calls: strand copies of query buffer `buffer`
+    ca.q2_own = rev ? &dc->query2_rc[buffer] : &dc->query2[buffer];
+    ca.q2_other = rev ? &dc->query2[buffer] : &dc->query2_rc[buffer];
+    ca.q_present = dc->query_present[buffer];
+}
+void set_query2_rm(CoreArgs& ca, DevCtx* dc, int rev) {  // repeat masker: the query is the target
+    ca.q2_own = rev ? &dc->refq2_rc : &dc->refq2;
+    ca.q2_other = rev ? &dc->refq2 : &dc->refq2_rc;
+    ca.q_present = dc->ref_present;
+}
+
+}  // namespace sa

@@ -251,7 +251,7 @@ void launch_plan(const uint64_t* hit_prefix_excl, uint32_t num_seeds, uint64_t m
 
 // ---- extend.hip ------------------------------------------------------------------------------------------------
 void launch_extend_filter(const ExtendArgs& a, hipStream_t s);   // hits -> candidates
-void launch_extend_filter_cls(const ExtendArgs& a, hipStream_t s);  // table-direct hits + their 28-byte target context -> l2_list (1d)
+void launch_extend_filter_cls(const ExtendArgs& a, hipStream_t s);  // table-direct hits + their 32-byte context records -> l2_list (1d)
 void launch_extend_exact(const ExtendArgs& a, hipStream_t s);    // candidates -> survivors + entropy records
 // chain shortcut: keys -> (sort, dedup.hip) -> links/run heads -> one exact extension per run
 void launch_chain_group(const ExtendArgs& a, hipStream_t s);

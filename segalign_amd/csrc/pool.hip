@@ -1,0 +1,176 @@
+// pool.hip -- slots and their staging, the (device, slot) token pool (src/seed_filter.cu:699-708,798-803) and the persistent host
+// worker pool (the engine's own seeder threads).
+#include "engine_internal.h"
+
+namespace sa {
+
+// ---- token pool ------------------------------------------------------------------------------------------------------
+Slot* acquire_slot() {  // src/seed_filter.cu:699-708
+    std::unique_lock<std::mutex> lk(g_mu);
+    g_cv.wait(lk, [] { return !g_tokens.empty(); });
+    auto t = g_tokens.back();
+    g_tokens.pop_back();
+    lk.unlock();
+    check_set_device(g_dev[t.first]->dev, "SeedAndFilter");
+    return &g_dev[t.first]->slots[t.second];
+}
+void release_slot(Slot* s) {  // src/seed_filter.cu:798-803
+    int di = -1, si = -1;
+    for (int d = 0; d < g_ndev; d++)
+        for (int k = 0; k < SLOTS_PER_DEVICE; k++)
+            if (&g_dev[d]->slots[k] == s) { di = d; si = k; }
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_tokens.push_back({di, si});
+    }
+    g_cv.notify_one();
+}
+
+void slot_init(Slot& s, DevCtx* dc) {
+    s.dev = dc->dev;
+    s.ctx = dc;
+    hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+    s.d_plan = (IterPlan*)dev_malloc(sizeof(IterPlan) * SA_MAX_CHUNKS, "plan");
+    s.d_cnt = (Counters*)dev_malloc(sizeof(Counters), "counters");
+    s.d_verify = (uint32_t*)dev_malloc(sizeof(uint32_t), "seed verify flag");
+    s.d_cov_range = (uint32_t*)dev_malloc(2 * sizeof(uint32_t), "coverage range");
+    s.d_td_bounds = dev_malloc(probe_bounds_bytes(), "probe bounds");
+    s.d_seg_info = (uint32_t*)dev_malloc(dedup_seg_info_words() * sizeof(uint32_t), "segment info");
+    s.d_td_plan = (TdPlan*)dev_malloc(sizeof(TdPlan) * SA_MAX_CHUNKS, "probe plan");
+    if (hipHostMalloc((void**)&s.h_cov, 8 * sizeof(uint32_t)) != hipSuccess ||
+        hipHostMalloc((void**)&s.h_bounds, (SA_MAX_CHUNKS + 2) * sizeof(uint32_t)) != hipSuccess ||
+        hipHostMalloc((void**)&s.h_plan, sizeof(IterPlan) * SA_MAX_CHUNKS) != hipSuccess ||
+        hipHostMalloc((void**)&s.h_td_plan, sizeof(TdPlan) * SA_MAX_CHUNKS) != hipSuccess ||
+        hipHostMalloc((void**)&s.h_seg_info, dedup_seg_info_words() * sizeof(uint32_t)) != hipSuccess ||
+        hipHostMalloc((void**)&s.h_verify, sizeof(uint32_t)) != hipSuccess ||
+        hipHostMalloc((void**)&s.h_cnt, sizeof(Counters)) != hipSuccess) {
+        fprintf(stderr, "Error: hipHostMalloc for slot staging failed\n");
+        exit(12);
+    }
+}
+void slot_destroy(Slot& s) {
+    s.seeds.release("seeds"); s.start.release("start"); s.count.release("count"); s.flags.release("flags");
+    s.flag_prefix.release("flag_prefix"); s.prefix.release("prefix"); s.scan_temp.release("scan_temp");
+    s.sort_temp.release("sort_temp"); s.hits.release("hits"); s.recA.release("recA"); s.recB.release("recB");
+    s.out16.release("out16");
+    s.cand_list.release("candidate list");
+    s.l2_list.release("second-level list");
+    s.audit.release("audit list");
+    s.l2_counts.release("second-level counters");
+    s.chain_tmp.release("chain"); s.chain_sorted.release("chain"); s.chain_is_head.release("chain");
+    s.chain_heads.release("chain"); s.chain_bucket_cnt.release("chain"); s.chain_bucket_start.release("chain"); s.ent_list.release("entropy list");
+    s.cov_diff.release("coverage"); s.cov_pre.release("coverage"); s.cov_is_start.release("coverage");
+    s.cov_is_end.release("coverage"); s.cov_sidx.release("coverage"); s.cov_eidx.release("coverage"); s.cov_pairs.release("coverage");
+    s.td_toff.release("probe"); s.td_tcnt.release("probe"); s.td_rec.release("probe"); s.td_chunk.release("probe"); s.td_bits.release("probe"); s.td_partial.release("probe");
+    dev_free(s.d_td_bounds, "probe bounds"); dev_free(s.d_td_plan, "probe plan"); dev_free(s.d_seg_info, "segment info");
+    s.d_td_bounds = nullptr; s.d_td_plan = nullptr; s.d_seg_info = nullptr;
+    if (s.h_seg_info) hipHostFree(s.h_seg_info);
+    s.h_seg_info = nullptr;
+    if (s.h_td_plan) hipHostFree(s.h_td_plan);
+    s.h_td_plan = nullptr;
+    dev_free(s.d_plan, "plan"); dev_free(s.d_cnt, "counters"); dev_free(s.d_cov_range, "coverage range");
+    dev_free(s.d_verify, "seed verify flag");
+    if (s.h_verify) hipHostFree(s.h_verify);
+    s.d_plan = nullptr; s.d_cnt = nullptr; s.d_cov_range = nullptr; s.d_verify = nullptr; s.h_verify = nullptr;
+    if (s.h_cov) hipHostFree(s.h_cov);
+    s.h_cov = nullptr;
+    s.out_seg.release("out seg");
+    if (s.h_seg) hipHostFree(s.h_seg);
+    if (s.h_bounds) hipHostFree(s.h_bounds);
+    s.h_seg = nullptr; s.h_bounds = nullptr; s.h_seg_cap = 0;
+    if (s.h_plan) hipHostFree(s.h_plan);
+    if (s.h_cnt) hipHostFree(s.h_cnt);
+    if (s.h_seeds) hipHostFree(s.h_seeds);
+    if (s.h_out) hipHostFree(s.h_out);
+    s.h_plan = nullptr; s.h_cnt = nullptr; s.h_seeds = nullptr; s.h_out = nullptr;
+    s.h_seeds_cap = s.h_out_cap = 0;
+    for (auto& e : s.event_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    s.event_pool.clear();
+    if (s.stream) hipStreamDestroy(s.stream);
+    s.stream = nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent host worker pool: the engine's own seeder threads (the reference keeps one seeder body per TBB worker,
+// src/main.cpp:565-573).  run_parallel(n, threads, fn) executes fn(0) .. fn(n-1) with at most `threads` of them in flight on pool
+// threads that live as long as the process -- no std::thread is created per interval call.  Several run_parallel calls may be
+// active at once (the host keeps several intervals in flight); each gets its own share of workers.
+// ------------------------------------------------------------------------------------------------------------------
+struct PoolBatch {
+    std::function<void(size_t)> fn;
+    size_t n = 0;
+    int want = 1;                 // workers this batch may occupy
+    int joined = 0;               // workers that took it (guarded by the pool mutex)
+    std::atomic<size_t> next{0};
+    std::atomic<size_t> done{0};
+    std::mutex mu;
+    std::condition_variable cv;
+};
+struct WorkPool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::shared_ptr<PoolBatch>> batches;
+    int workers = 0;
+};
+static WorkPool* g_pool = new WorkPool();  // (never destroyed: its detached workers wait on it until the process ends)
+
+static void pool_worker() {
+    WorkPool& P = *g_pool;
+    std::unique_lock<std::mutex> lk(P.mu);
+    for (;;) {
+        std::shared_ptr<PoolBatch> b;
+        for (auto& c : P.batches)
+            if (c->joined < c->want && c->next.load() < c->n) { b = c; break; }
+        if (!b) {
+            P.cv.wait(lk);
+            continue;
+        }
+        b->joined++;
+        lk.unlock();
+        for (;;) {
+            const size_t i = b->next.fetch_add(1);
+            if (i >= b->n) break;
+            b->fn(i);
+            if (b->done.fetch_add(1) + 1 == b->n) {
+                std::lock_guard<std::mutex> g(b->mu);
+                b->cv.notify_all();
+            }
+        }
+        lk.lock();
+    }
+}
+
+void run_parallel(size_t n, int threads, std::function<void(size_t)> fn) {
+    if (n == 0) return;
+    threads = std::max(1, std::min<int>(threads, (int)n));
+    if (threads == 1) {  // the caller's own thread is the one seeder body
+        for (size_t i = 0; i < n; i++) fn(i);
+        return;
+    }
+    auto b = std::make_shared<PoolBatch>();
+    b->fn = std::move(fn);
+    b->n = n;
+    b->want = threads;
+    {
+        WorkPool& P = *g_pool;
+        std::lock_guard<std::mutex> lk(P.mu);
+        P.batches.push_back(b);
+        int wanted = 0;  // one worker per call the active batches may have in flight; the pool grows on demand and stays
+        for (auto& c : P.batches) wanted += c->want;
+        while (P.workers < std::min(wanted, 64)) {
+            std::thread(pool_worker).detach();
+            P.workers++;
+        }
+        P.cv.notify_all();
+    }
+    {
+        std::unique_lock<std::mutex> g(b->mu);
+        b->cv.wait(g, [&] { return b->done.load() == b->n; });
+    }
+    WorkPool& P = *g_pool;
+    std::lock_guard<std::mutex> lk(P.mu);
+    for (auto it = P.batches.begin(); it != P.batches.end(); ++it)
+        if (it->get() == b.get()) { P.batches.erase(it); break; }
+}
+
+}  // namespace sa

@@ -23,6 +23,8 @@
 //   pos_table[num_index]   block-relative seed start positions, ascending inside a bucket
 // Position rule (hazard H6): positions start_offset + i*step, i < num_steps, with
 //   offset = (span+1) % step, start_offset = step - offset, num_steps = (len - span + offset)/step  (:58-64)
+#include <string.h>
+
 #include "kernels.h"
 #include "kmer_dev.h"
 
@@ -307,7 +309,30 @@ __global__ __launch_bounds__(1024) void table_finish_kernel(const uint32_t* __re
     for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) pos_table[lo + i] = s_out[i];
 }
 
-bool table_partition_build_supported(int weight) { return weight >= 9 && weight <= 12; }
+// The partition build stages its tiles in up to ~120 KB of dynamic LDS; a device that cannot grant that (anything but gfx950's 160 KB)
+// keeps the atomic build.  Asked once per process and device.
+static bool lds_budget_ok() {
+    static int cached[64] = {0};  // 0 unknown, 1 ok, -1 no
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (cached[dev] == 0) {
+        const int want = 160 * 1024 - 256;
+        bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&table_partition_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess &&
+                  hipFuncSetAttribute(reinterpret_cast<const void*>(&table_partition_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess &&
+                  hipFuncSetAttribute(reinterpret_cast<const void*>(&table_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        // (the runtime accepts the attribute on devices that cannot honour it; ask the device as well)
+        int max_lds = 0;
+        hipDeviceProp_t prop;
+        const bool have_prop = hipGetDeviceProperties(&prop, dev) == hipSuccess;
+        if (hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) { (void)hipGetLastError(); max_lds = 0; }
+        const bool gfx950 = have_prop && strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+        ok = ok && (max_lds >= want || gfx950);
+        cached[dev] = ok ? 1 : -1;
+    }
+    return cached[dev] == 1;
+}
+bool table_partition_build_supported(int weight) { return weight >= 9 && weight <= 12 && lds_budget_ok(); }
 size_t table_partition_part_start_words() { return (1u << TB_COARSE_BITS) + 1; }
 
 void launch_table_keys(const uint8_t* ref, uint32_t num_steps, uint32_t start_offset, uint32_t step, SeedShape sh, uint32_t* keys,

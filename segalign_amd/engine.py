@@ -37,7 +37,7 @@ C_ABI_SYMBOLS = [
     "sa_rm_mask_interval", "sa_rm_coverage_intervals", "sa_free_intervals", "sa_get_filter_mode",
     "sa_seed_interval", "sa_seed_and_filter_chunks", "sa_max_chunks_per_call", "sa_get_chunks_per_call", "sa_extend_hits",
     "sa_get_lookup_mode", "sa_get_neighbourhood_entries",
-    "sa_seed_calls", "sa_set_option", "sa_reset_option", "sa_get_option", "sa_option_count", "sa_option_name", "sa_get_audit",
+    "sa_seed_calls", "sa_count_call_hits", "sa_release_arena", "sa_set_option", "sa_reset_option", "sa_get_option", "sa_option_count", "sa_option_name", "sa_get_audit",
 ]
 IVL_DTYPE = np.dtype([("query_start", "<u4"), ("len", "<u4")])  # struct Segment, repeat_masker_src/graph.h:32-35
 STRAND_PLUS, STRAND_MINUS, STRAND_BOTH = 1, 2, 3
@@ -119,6 +119,7 @@ def lib():
     L.sa_version.restype = C.c_char_p
     L.sa_seed_calls.restype = C.c_size_t
     L.sa_seed_calls.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_void_p, C.POINTER(CallStats)]
+    L.sa_count_call_hits.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_void_p]
     L.sa_set_option.restype = C.c_int
     L.sa_set_option.argtypes = [C.c_char_p, C.c_int64]
     L.sa_reset_option.restype = C.c_int
@@ -234,10 +235,24 @@ class CallDesc(C.Structure):
 
 
 class CallResult(C.Structure):
-    _fields_ = [("hsps", C.c_void_p), ("num_hsps", C.c_size_t), ("num_hits", C.c_uint64)]
+    _fields_ = [("hsps", C.c_void_p), ("num_hsps", C.c_size_t), ("num_hits", C.c_uint64), ("device", C.c_int32), ("reserved", C.c_int32)]
 
 
-def SeedCalls(calls, buffer=0, threads=4, hits_out=None):
+def CountCallHits(calls, buffer=0, threads=4):
+    """Seed hits of every call [(start, end, rev), ...], lookup only (no filtering, no extension): the weights a multi-GPU host
+    deals the calls of a pass by."""
+    n = len(calls)
+    descs = (CallDesc * max(n, 1))(*[CallDesc(int(a), int(b), int(bool(r))) for (a, b, r) in calls])
+    hits = (C.c_uint64 * max(n, 1))()
+    lib().sa_count_call_hits(descs, n, buffer, threads, hits)
+    return [int(hits[i]) for i in range(n)]
+
+
+def ReleaseArena():
+    lib().sa_release_arena()
+
+
+def SeedCalls(calls, buffer=0, threads=4, hits_out=None, devices_out=None):
     """calls: [(start, end, rev), ...], each up to sa_max_chunks_per_call() chunks of one strand; `threads` of them in flight on
     the engine's worker pool.  -> ([HSP array per call (chunks concatenated, headers removed)], summed stats dict).
     hits_out: a list that receives the seed hits of every call (sa_call_result.num_hits)."""
@@ -256,6 +271,8 @@ def SeedCalls(calls, buffer=0, threads=4, hits_out=None):
         lib().sa_free_segments(res[i].hsps)
     if hits_out is not None:
         hits_out.extend(int(res[i].num_hits) for i in range(n))
+    if devices_out is not None:
+        devices_out.extend(int(res[i].device) for i in range(n))
     return outs, {k: getattr(st, k) for k, _ in CallStats._fields_}
 
 

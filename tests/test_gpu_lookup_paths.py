@@ -196,3 +196,33 @@ def test_lookup_paths_repeat_masker(oracle, clean, mode, env):
         got, gt = c.E.RmMaskInterval(s, e, ws, we, strands, 1)
         assert as_list(got) == as_list(want) and gt == wt, (mode, s, e, ws, we, strands)
     c.E.RmClearQuery()
+
+
+def test_query_block_beyond_the_2bit_copy_limit_takes_the_general_path(oracle, clean):
+    """The class filter addresses the sixteen 2-bit copies of a query strand with one 32-bit offset (4 GiB: blocks of ~1 Gbp).  A
+    block beyond that must not take the table-direct path against the context table (its run entries carry no plain positions) --
+    it falls back to the reference-shaped path, same results.  The limit is lowered through the test option q2_limit_mb."""
+    with_env({})
+    E = clean
+    t, q = synth.make_pair(300000, 61, 62, sub_rate=0.09, mask_frac=0.1, records=2, indel_every=500)
+    try:
+        E.set_option("q2_limit_mb", 1)  # 16 copies x ~75 KB = 1.2 MB > 1 MB
+        c = Case(t, q, chunk=100000).oracle_setup(oracle).engine_setup(E)
+        assert E.lookup_mode() == 2     # the table itself is the context table ...
+        n = 0
+        for rev in (False, True):
+            for (s, e) in c.chunks():
+                seeds = c.host_seeds(s, e, rev)
+                want, _ = c.oracle_saf(seeds, rev)
+                assert seg_equal(E.SeedAndFilterRange(s, e, rev, 0), want)
+                assert E.last_call_stats()["lookup_path"] == 0   # ... but the calls cannot use it
+                assert seg_equal(E.SeedAndFilter(seeds, rev, 0), want)
+                assert E.last_call_stats()["lookup_path"] == 0
+                n += want.size - 1
+            ch = c.chunks()
+            outs = E.SeedAndFilterChunks(ch[0][0], ch[-1][1], rev, 0)
+            for j, (s, e) in enumerate(ch):
+                assert seg_equal(outs[j], c.oracle_saf(c.host_seeds(s, e, rev), rev)[0])
+        assert n > 50
+    finally:
+        E.reset_option("q2_limit_mb")

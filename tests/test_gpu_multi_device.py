@@ -1,27 +1,40 @@
 """GPU, multi-device (the reference's own model: ONE process, all visible devices, calls handed to whichever device has a
-free token -- common/seed_filter_interface.cu:49-80, src/seed_filter.cu:699-706,798-803).  The driver's test box has one
-GPU, so this module skips there with a reason; on a multi-GPU node it runs 8 host threads over every device and checks
-every call against the oracle, both through the drop-in entry (host seed words) and the device-seeded entry."""
+free token -- common/seed_filter_interface.cu:49-80, src/seed_filter.cu:699-706,798-803; tables replicated on every device,
+common/seed_pos_table.cu:33-47).
+
+On a node with several GPUs these tests use them.  On a one-GPU box (the driver's test box) they still run: sa_select_devices
+accepts an ordinal more than once, and every entry becomes an engine device of its own -- context, admin stream, target, seed
+tables, table arena, four token-pool slots -- on that GPU.  Everything the multi-device code does differently from the
+single-device code is exercised that way: N DevCtx, concurrent table builds (one host thread per engine device), the slot-major
+token order, calls of one list landing on different engine devices, g_ClearRef + a block switch across contexts."""
 import threading
 
 import numpy as np
 import pytest
 
 from helpers import Case, seg_equal
-from segalign_amd import synth
+from segalign_amd import shard, synth
 
 pytestmark = pytest.mark.gpu
 
 
-def device_count():
+def engine_devices(E, want=2):
+    """Select `want` engine devices: distinct GPUs when the process sees that many, otherwise twins on ordinal 0."""
     import torch
-    return torch.cuda.device_count()
+    n = torch.cuda.device_count()
+    ids = list(range(want)) if n >= want else [0] * want
+    E.select_devices(ids)
+    return ids
 
 
-def test_all_devices_token_pool_matches_oracle(oracle, engine):
-    n = device_count()
-    if n < 2:
-        pytest.skip("needs >= 2 GPUs in this process (found %d): sa_initialize_interface(-1) over several devices" % n)
+@pytest.fixture
+def two_devices(engine):
+    ids = engine_devices(engine, 2)
+    yield ids
+    engine.select_devices([])
+
+
+def test_all_devices_token_pool_matches_oracle(oracle, engine, two_devices):
     E = engine
     t, q = synth.make_pair(300000, 13, 14, sub_rate=0.1, mask_frac=0.1, records=2, indel_every=600)
     c = Case(t, q, chunk=25000).oracle_setup(oracle)
@@ -47,7 +60,82 @@ def test_all_devices_token_pool_matches_oracle(oracle, engine):
         [th.join() for th in threads]
         assert all(seg_equal(got[j], want[j]) and seg_equal(got_dev[j], want[j]) for j in jobs)
         assert len(devices) >= 2, devices  # the pool really spread the calls
-        for d in range(n):  # replicated state is identical on every device
+        for d in range(len(two_devices)):  # replicated state is identical on every device
             assert np.array_equal(E.copy_index_table(d), c.o_index) and np.array_equal(E.copy_pos_table(d), c.o_pos)
+    finally:
+        E.ShutdownProcessor()
+
+
+def _pass(E, jobs, threads):
+    devs = []
+    outs, st = E.SeedCalls([(j["a"], j["b"], j["rev"]) for j in jobs], 0, threads, devices_out=devs)
+    return outs, st, devs
+
+
+def test_call_list_over_two_devices_equals_one_device_and_survives_a_block_switch(oracle, engine, two_devices):
+    """20 Mbp block pair, multi-chunk calls through the engine's worker pool (what bench.py and segalign_host issue): the HSPs of
+    every call from two engine devices equal those from one, both devices take calls, and after g_ClearRef + a new target block
+    (tables rebuilt concurrently on both) the same holds again."""
+    E = engine
+    sub_mat = oracle.build_sub_mat(910)
+    blocks = [synth.make_pair(20_000_000, 31, 32, sub_rate=0.08, mask_frac=0.2, records=3, invert_frac=0.3, invert_block=100_000),
+              synth.make_pair(12_000_000, 33, 34, sub_rate=0.10, mask_frac=0.1, records=2, invert_frac=0.2, invert_block=50_000)]
+    shape = "TTT0T00TT00T0T0TTTT"
+
+    def run(ids):
+        E.select_devices(ids)
+        E.InitializeInterface(len(ids))
+        k = E.GenerateShapePos(shape)
+        E.InitializeProcessor(True, 250_000, 19, sub_mat, 910, 3000, False)
+        res = []
+        for (t, q) in blocks:
+            keep = E.SendRefWriteRequest(t, 0, t.size)
+            E.GenerateSeedPosTable(keep, 0, t.size, 1, 19, k)
+            E.SendQueryWriteRequest(q, 0, q.size, 0)
+            ivs = shard.plan_intervals(q.size, 19, 10_000_000)
+            jobs = shard.call_jobs(ivs, q.size - 19, 250_000, 10)
+            outs, st, devs = _pass(E, jobs, 6)
+            tables = [(E.copy_index_table(d), E.copy_pos_table(d)) for d in range(len(ids))]
+            res.append((outs, st, devs, tables))
+            E.ClearQuery(0)
+            E.ClearRef()
+        E.ShutdownProcessor()
+        return res
+
+    try:
+        one = run(two_devices[:1])
+        two = run(two_devices)
+    finally:
+        E.select_devices([])
+    for b in range(len(blocks)):
+        o1, s1, d1, t1 = one[b]
+        o2, s2, d2, t2 = two[b]
+        assert len(o1) == len(o2) and sum(o.size for o in o1) > 1000
+        assert all(seg_equal(a, c) for a, c in zip(o1, o2))
+        assert s1["num_hits"] == s2["num_hits"] and s1["num_anchors"] == s2["num_anchors"]
+        assert set(d1) == {0} and set(d2) == {0, 1}, (set(d1), set(d2))
+        # both devices carry the same tables as the single-device run
+        for (ix, ps) in t2:
+            assert np.array_equal(ix, t1[0][0]) and np.array_equal(ps, t1[0][1])
+
+
+def test_hit_counts_by_lookup_equal_the_calls_own_counts(oracle, engine, two_devices):
+    """sa_count_call_hits (the cheap weighting pass of a multi-GPU host) reports exactly the hits the calls themselves see."""
+    E = engine
+    sub_mat = oracle.build_sub_mat(910)
+    t, q = synth.make_pair(6_000_000, 41, 42, sub_rate=0.08, mask_frac=0.2, records=2, invert_frac=0.3, invert_block=100_000)
+    try:
+        E.InitializeInterface(len(two_devices))
+        k = E.GenerateShapePos("TTT0T00TT00T0T0TTTT")
+        E.InitializeProcessor(True, 250_000, 19, sub_mat, 910, 3000, False)
+        keep = E.SendRefWriteRequest(t, 0, t.size)
+        E.GenerateSeedPosTable(keep, 0, t.size, 1, 19, k)
+        E.SendQueryWriteRequest(q, 0, q.size, 0)
+        jobs = shard.call_jobs(shard.plan_intervals(q.size, 19, 10_000_000), q.size - 19, 250_000, 8)
+        calls = [(j["a"], j["b"], j["rev"]) for j in jobs]
+        counted = E.CountCallHits(calls, 0, 4)
+        seen = []
+        E.SeedCalls(calls, 0, 4, hits_out=seen)
+        assert counted == seen and sum(counted) > 0
     finally:
         E.ShutdownProcessor()

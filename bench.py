@@ -17,12 +17,14 @@ src/main.cpp:617-629).
 Other workloads (--workload): `notransition` = configs[4] (--notransition --step=1), `rm` = configs[3] (repeat-masker
 path: the target self-aligned through sa_rm_mask_interval over the reference's interval plan), `human` = one block pair
 of configs[2] (a 500 Mbp target block, the size at which the reference closes a block, x a 100 Mbp query block of 1.2
-%-diverged shuffled pieces; every rank of an N-GPU run holds its own block pair, as the 6 x 6 block pairs of a 3 Gbp x 3 Gbp
-run are independent), `plumbing` = configs[0] (1 Mbp x 1 Mbp).
+%-diverged shuffled pieces.  --scaling strong, the default: the SAME block pair on every rank, its calls dealt to the ranks by
+seed hits -- the sharding BASELINE configs[2] names; --scaling weak: every rank on a block pair of its own, as the 6 x 6 block
+pairs of a 3 Gbp x 3 Gbp run are independent), `plumbing` = configs[0] (1 Mbp x 1 Mbp).
 
 Multi-GPU: the unit of work is one engine CALL (up to 32 consecutive 250 kbp chunks of one strand of one interval; 20 by
 default, so a strand's 40 chunks of an interval are two calls and a pass of the default workload is 40 calls); calls are independent and their output position is fixed by the host loop.  Default
-`--scaling strong`: the calls of ONE pass are dealt round-robin to the N ranks -- every call on exactly one GPU, total work fixed,
+`--scaling strong`: the calls of ONE pass are dealt to the N ranks (by their seed hits, counted by a lookup-only pass every rank
+runs identically; --partition round-robin: in turn) -- every call on exactly one GPU, total work fixed,
 `value` = query bases of the block / max-rank time, and the order-independent HSP checksum of the pass must equal the 1-GPU
 checksum.  `--scaling weak`: every rank runs the whole pass (rank-dependent start).  Every rank holds target + tables; there is
 NO data-path collective (torch.distributed only carries the barrier and the max / sum of the timing and counts).
@@ -100,6 +102,15 @@ def parse():
                     help="skip the drop-in leg (one-chunk g_SeedAndFilter calls): profile collections use it so that per-kernel averages "
                          "describe the calls of the timed region only")
     ap.add_argument("--no-roofline", action="store_true", help="timed region only: no extra passes at all (tools/timeline.py)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process group of an N > 1 run: nccl (= RCCL; the driver's launch) or gloo (barrier and reductions on the host: "
+                         "what a rehearsal of the N-rank path on fewer GPUs uses)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="every rank uses HIP device 0 (with --backend gloo): the N-rank strong-scaling path -- partition, per-rank engines, "
+                         "reductions, checksum -- on a one-GPU box; the timing then says nothing about scaling")
+    ap.add_argument("--chunks-per-call", type=int, default=None,
+                    help="chunks of a strand that share one engine call (engine option chunks_per_call, default 20): smaller calls give the "
+                         "partition of a pass over many GPUs a finer grain")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU-only rehearsal of the launch/shard/reduce/JSON contract (gloo, no GPU): real shard + chunk "
                          "arithmetic around a stub engine")
@@ -187,13 +198,20 @@ def main():
         dist = dist_mod
         if args.dry_run:
             dist.init_process_group(backend="gloo")
+        elif args.backend == "gloo":
+            torch.cuda.set_device(0 if args.share_gpu else local_rank)
+            dist.init_process_group(backend="gloo")
+            dev = "cpu"  # (the reductions below run on host tensors)
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # "nccl" IS RCCL on ROCm
     elif not args.dry_run:
-        torch.cuda.set_device(local_rank)
-    # human: every rank holds its own block pair (the 6 x 6 block pairs of a 3 Gbp x 3 Gbp run are independent) => weak
-    scaling = "weak" if (args.scaling == "weak" or args.workload == "human") else "strong"
+        torch.cuda.set_device(0 if args.share_gpu else local_rank)
+    if args.share_gpu:
+        local_rank = 0
+    # strong (default): ONE problem -- the same block pair on every rank, its calls dealt to the ranks.  weak: every rank runs a whole
+    # pass; for `human` on a block pair of its own (the 6 x 6 block pairs of a 3 Gbp x 3 Gbp run are independent)
+    scaling = args.scaling
 
     if args.dry_run:
         return dry_run(args, rank, world, dist, torch, shard, scaling)
@@ -213,10 +231,12 @@ def main():
     os.environ.setdefault("SEGALIGN_AMD_SLOTS", str(max(2, inflight)))  # one engine slot per call in flight (default 2)
     if args.workload == "human":
         os.environ.setdefault("SEGALIGN_AMD_ARENA_GB", "180")
+    if args.chunks_per_call:
+        E.set_option("chunks_per_call", args.chunks_per_call)
     E.InitializeProcessor(args.workload != "notransition", args.chunk, seed_size, sub_mat, xdrop, hspthresh, False)
 
     t_gen0 = time.time()
-    wl = make_workload(args, rank)
+    wl = make_workload(args, rank if scaling == "weak" else 0)  # (strong: every rank generates the SAME block pair)
     target, query = wl["target"], wl["query"]
     t_gen = time.time() - t_gen0
 
@@ -264,9 +284,13 @@ def main():
     # every rank, no communication; it is part of the warm-up (tables, buffers and clocks are warm afterwards).
     weights = None
     imbalance = None
+    t_weigh = None
     if scaling == "strong" and not wl["rm"] and (args.partition == "hits" or (args.partition == "auto" and world > 1)):
-        weights = []
-        E.SeedCalls([(j["a"], j["b"], j["rev"]) for j in jobs], 0, inflight, hits_out=weights)
+        # lookup only (sa_count_call_hits: the position probe + chunk plans of every call, no filtering, no extension): what the map
+        # costs a production host per (target block, query block) pair -- reported as partition_cost_ms
+        t0 = time.perf_counter()
+        weights = E.CountCallHits([(j["a"], j["b"], j["rev"]) for j in jobs], 0, inflight)
+        t_weigh = time.perf_counter() - t0
     my_jobs = shard.partition(jobs, rank, world, weights) if scaling == "strong" else jobs
     if weights and world >= 1:
         # (what the map promises: heaviest rank / mean, by seed hits; and what round-robin would have given)
@@ -339,7 +363,22 @@ def main():
     prof = E.profile_entries()
     busy = {k: E.profile_busy_ms(k) for k in prof}  # per scope: ms with at least one launch running (the slots' launches overlap)
 
+    # the same passes ONE AT A TIME, a barrier + device drain between them: what one query block against one target block costs
+    # when nothing follows it (the tail of the slowest rank's last call shows here; the concatenated figure above hides it)
+    drained = []
+    if not args.no_roofline:
+        for k in range(min(args.steps, 3)):
+            barrier()
+            t1 = time.perf_counter()
+            run_step(k)
+            barrier()
+            drained.append(time.perf_counter() - t1)
+
     # max over ranks, sums of bases / HSPs / checksum
+    if dist is not None and drained:
+        td = torch.tensor(drained, dtype=torch.float64, device=dev)
+        dist.all_reduce(td, op=dist.ReduceOp.MAX)
+        drained = [float(x) for x in td.tolist()]
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -386,10 +425,17 @@ def main():
                        "parallelism": ("the %d engine calls of one pass dealt to %d rank(s) %s: every call on exactly one GPU, target + tables on every GPU, "
                                        "no collective" % (len(jobs), world, "by seed-hit count (longest first to the least loaded rank; counts from an "
                                                           "untimed pass every rank runs identically)" if weights else "round-robin")) if scaling == "strong" else
-                                      ("every one of %d rank(s) runs all %d calls of a pass (own block pair per rank for `human`), no collective"
+                                      ("every one of %d rank(s) runs all %d calls of a pass (`human`: on a block pair of its own), no collective"
                                        % (world, len(jobs))),
                        "calls_per_step": len(jobs), "calls_in_flight_per_gpu": inflight, "partition_imbalance": imbalance,
+                       # what the by-hits map costs: one lookup-only pass over all calls on every rank (outside the timed region)
+                       "partition_cost_ms": round(1e3 * t_weigh, 3) if t_weigh is not None else None,
+                       # one pass at a time with a barrier + drain on both sides (max over ranks), next to ms_per_step of the
+                       # concatenated passes: the difference is the tail of a single pass
+                       "ms_per_pass_drained": [round(1e3 * x, 3) for x in drained] or None,
+                       "backend": (args.backend + (", all ranks on HIP device 0" if args.share_gpu else "")) if world > 1 else None,
                        "hsps_per_step": hsps // (steps_eff * (world if scaling == "weak" else 1)),
+                       "query_bases_per_step": bases // (steps_eff * (world if scaling == "weak" else 1)),
                        # order-independent checksum of one pass's HSP multiset: an N-GPU strong-scaling run reproduces the 1-GPU value
                        "hsp_checksum": check if scaling == "strong" else None},
             "setup_s": {"generate": round(t_gen, 2), "target_upload_encode": round(t_ref, 3),
@@ -778,13 +824,17 @@ def default_sub_mat(xdrop):
 
 
 def cpu_baseline(E, target, query, sub_mat, seed_size, kmer, args, xdrop, hspthresh, transition):
-    """The oracle (a port: the reference cannot be compiled here and LASTZ is absent) timed on the host cores on a
-    bounded sample of the SAME workload: whole 250 kbp chunks, both strands, until ~cpu_seconds have been spent.
-    The seed table is copied from the device (it is parity-tested; building it on one CPU core takes longer than
-    the whole budget) -- table build is outside the metric on both sides."""
+    """The oracle (a port: the reference cannot be compiled here and LASTZ is absent) timed on the host cores on a bounded sample of
+    the SAME workload, run the way a CPU host would run it: ONE (chunk, strand) task per core -- min(cores, 64) tasks in flight,
+    each single-threaded (host seeding loop + extension + ordering of oracle/segalign_oracle.c), like the reference's one seeder body
+    per TBB worker -- over whole 250 kbp chunks until ~cpu_seconds have been spent.  The single-core rate (one task alone) is
+    measured first and stated.  The seed table is copied from the device (it is parity-tested; building it on one CPU core takes
+    longer than the whole budget) -- table build is outside the metric on both sides."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     O.build(with_ref=False)
     cores = os.cpu_count() or 1
+    used = max(1, min(cores, 64))
     O.generate_shape_pos(SHAPE)
     index = E.copy_index_table()
     pos = E.copy_pos_table()
@@ -793,24 +843,41 @@ def cpu_baseline(E, target, query, sub_mat, seed_size, kmer, args, xdrop, hspthr
     qrc_codes = E.copy_query_codes(0, True)
     qb = query.tobytes()
     qrc = O.rev_comp_ascii(qb, 0, query.size)
-    done_bases, spent, chunks = 0, 0.0, 0
     end_pos = query.size - seed_size
-    c = 0
-    while spent < args.cpu_seconds and c < end_pos:
+
+    def task(t):  # (the oracle's entry points are plain C calls: ctypes releases the GIL for their duration)
+        c, rev = t
         e = min(c + args.chunk, end_pos)
-        t0 = time.perf_counter()
-        for rev, buf, codes in ((False, qb, q_codes), (True, qrc, qrc_codes)):
-            a, b = (c, e) if not rev else (end_pos - e, end_pos - c)
-            seeds = O.make_seeds(buf, 0, a, b, seed_size, kmer, transition)
-            O.seed_and_filter(ref_codes, codes, index, pos, seeds, sub_mat, seed_size=seed_size, xdrop=xdrop,
-                              hspthresh=hspthresh, noentropy=False, num_threads=cores)
-        spent += time.perf_counter() - t0
-        done_bases += e - c
-        chunks += 1
-        c = e
-    out = {"value": round(done_bases / spent / 1e9, 6), "unit": "Gbp/s", "cores": cores, "kind": "port",
-           "sample": "%d x %d bp query chunks, both strands, vs the full target (%.1f s CPU wall); host seeding loop + "
-                     "OpenMP extension of oracle/segalign_oracle.c" % (chunks, args.chunk, spent)}
+        a, b = (c, e) if not rev else (end_pos - e, end_pos - c)
+        seeds = O.make_seeds(qrc if rev else qb, 0, a, b, seed_size, kmer, transition)
+        O.seed_and_filter(ref_codes, qrc_codes if rev else q_codes, index, pos, seeds, sub_mat, seed_size=seed_size, xdrop=xdrop,
+                          hspthresh=hspthresh, noentropy=False, num_threads=1)
+        return (e - c) * 0.5  # (a chunk is done when both of its strands are)
+
+    starts = list(range(0, max(end_pos, 0), args.chunk))
+    # single-core rate: one task alone (a quarter chunk when the budget is small, so that the leg stays bounded)
+    t0 = time.perf_counter()
+    single_bases = task((starts[len(starts) // 2], False))  # (one strand of a chunk counts half its bases)
+    single_s = time.perf_counter() - t0
+    single_rate = single_bases / single_s
+    # waves of `used` tasks until the budget is spent (a wave is never cut: its tasks finish together, like a TBB arena's)
+    tasks = [(c, rev) for c in starts for rev in (False, True)]
+    done_bases, spent, ntasks, k = 0.0, 0.0, 0, 0
+    with ThreadPoolExecutor(used) as ex:
+        while k < len(tasks) and spent < args.cpu_seconds:
+            wave = tasks[k:k + used]
+            t0 = time.perf_counter()
+            done_bases += sum(ex.map(task, wave))
+            spent += time.perf_counter() - t0
+            ntasks += len(wave)
+            k += len(wave)
+    value = done_bases / spent / 1e9
+    out = {"value": round(value, 6), "unit": "Gbp/s", "cores": used, "cores_available": cores, "kind": "port",
+           "single_core": {"value": round(single_rate / 1e9, 7), "unit": "Gbp/s",
+                           "sample": "one strand of one %d bp chunk, one thread (%.1f s)" % (args.chunk, single_s)},
+           "parallel_efficiency": round(value * 1e9 / (used * single_rate), 3),
+           "sample": "%d (chunk, strand) tasks of %d bp vs the full target, %d in flight, one thread each (%.1f s wall); host seeding loop + "
+                     "extension + ordering of oracle/segalign_oracle.c" % (ntasks, args.chunk, used, spent)}
     lz = lastz_row(target, query, args)
     if lz:
         out["lastz"] = lz
@@ -820,10 +887,13 @@ def cpu_baseline(E, target, query, sub_mat, seed_size, kmer, args, xdrop, hspthr
 def cpu_baseline_rm(E, target, sub_mat, seed_size, kmer, args, xdrop, hspthresh, jobs):
     """Repeat-masker workload: the oracle's restatement of the repeat masker's seeder body (repeat_masker_src/seeder.cpp:73-150:
     chunk loop, minus chunk derived from the plus chunk's end, windowed SeedAndFilter of repeat_masker_src/seed_filter.cu:724-876)
-    on whole chunks of the first interval task, both strands, until ~cpu_seconds have been spent; table copied from the device."""
+    on whole chunks of the first interval task, ONE (chunk, strand) task per core (min(cores, 64) in flight, one thread each), until
+    ~cpu_seconds have been spent; table copied from the device."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     O.build(with_ref=False)
     cores = os.cpu_count() or 1
+    used = max(1, min(cores, 64))
     O.generate_shape_pos(SHAPE)
     index = E.copy_index_table()
     pos = E.copy_pos_table()
@@ -834,28 +904,44 @@ def cpu_baseline_rm(E, target, sub_mat, seed_size, kmer, args, xdrop, hspthresh,
     rcb = O.rev_comp_ascii(tb, 0, L)
     job = jobs[0]
     end_pos_rc = L - 1 - job["a"]
-    done_bases, spent, chunks = 0, 0.0, 0
-    c = job["a"]
-    while spent < args.cpu_seconds and c < job["b"]:
+
+    def task(t):
+        c, rev = t
         e = min(c + args.chunk, job["b"])
-        t0 = time.perf_counter()
-        for rev in (False, True):
-            s0, s1 = c, e
-            if rev:  # repeat_masker_src/seeder.cpp:118-119
-                s0 = L - 1 - e
-                s1 = min(s0 + args.chunk, end_pos_rc)
-            s1 = min(s1, L - seed_size + 1)
-            seeds = O.make_seeds(rcb if rev else tb, 0, s0, s1, seed_size, kmer, True)
-            if seeds.size:
-                O.seed_and_filter(ref_codes, rc_codes if rev else ref_codes, index, pos, seeds, sub_mat, seed_size=seed_size, xdrop=xdrop,
-                                  hspthresh=hspthresh, noentropy=False, num_threads=cores, rm=(rev, job["ref_start"], job["ref_end"]))
-        spent += time.perf_counter() - t0
-        done_bases += e - c
-        chunks += 1
-        c = e
-    return {"value": round(done_bases / spent / 1e9, 6), "unit": "Gbp/s", "cores": cores, "kind": "port",
-            "sample": "%d x %d bp chunks of the first interval task, both strands, self-alignment inside its window (%.1f s CPU wall); "
-                      "host seeding loop + OpenMP extension of oracle/segalign_oracle.c (repeat-masker variant)" % (chunks, args.chunk, spent)}
+        s0, s1 = c, e
+        if rev:  # repeat_masker_src/seeder.cpp:118-119
+            s0 = L - 1 - e
+            s1 = min(s0 + args.chunk, end_pos_rc)
+        s1 = min(s1, L - seed_size + 1)
+        seeds = O.make_seeds(rcb if rev else tb, 0, s0, s1, seed_size, kmer, True)
+        if seeds.size:
+            O.seed_and_filter(ref_codes, rc_codes if rev else ref_codes, index, pos, seeds, sub_mat, seed_size=seed_size, xdrop=xdrop,
+                              hspthresh=hspthresh, noentropy=False, num_threads=1, rm=(rev, job["ref_start"], job["ref_end"]))
+        return (e - c) * 0.5
+
+    starts = list(range(job["a"], job["b"], args.chunk))
+    t0 = time.perf_counter()
+    single_bases = task((starts[len(starts) // 2], False))
+    single_s = time.perf_counter() - t0
+    single_rate = single_bases / single_s
+    tasks = [(c, rev) for c in starts for rev in (False, True)]
+    done_bases, spent, ntasks, k = 0.0, 0.0, 0, 0
+    with ThreadPoolExecutor(used) as ex:
+        while k < len(tasks) and spent < args.cpu_seconds:
+            wave = tasks[k:k + used]
+            t0 = time.perf_counter()
+            done_bases += sum(ex.map(task, wave))
+            spent += time.perf_counter() - t0
+            ntasks += len(wave)
+            k += len(wave)
+    value = done_bases / spent / 1e9
+    return {"value": round(value, 6), "unit": "Gbp/s", "cores": used, "cores_available": cores, "kind": "port",
+            "single_core": {"value": round(single_rate / 1e9, 7), "unit": "Gbp/s",
+                            "sample": "one strand of one %d bp chunk, one thread (%.1f s)" % (args.chunk, single_s)},
+            "parallel_efficiency": round(value * 1e9 / (used * single_rate), 3),
+            "sample": "%d (chunk, strand) tasks of %d bp of the first interval task, self-alignment inside its window, %d in flight, one thread "
+                      "each (%.1f s wall); host seeding loop + extension + ordering of oracle/segalign_oracle.c (repeat-masker variant)"
+                      % (ntasks, args.chunk, used, spent)}
 
 
 def lastz_row(target, query, args):

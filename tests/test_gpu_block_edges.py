@@ -50,12 +50,13 @@ def block_start_case(O, seed, rev, homol=44, tx=5000):
     return None
 
 
-@pytest.mark.parametrize("seed", [0, 1, 3, 4, 5])
+# (PRNG seeds for which the search below finds a case -- seed positions 0, 3, 12, 1, 23, 25 in the block: all shifts of the packed copies;
+#  a seed without a case is a test failure, not a skip)
+@pytest.mark.parametrize("seed", [0, 1, 3, 4, 8, 9])
 @pytest.mark.parametrize("rev", [False, True])
 def test_single_seed_hsp_at_query_block_start(oracle, engine, seed, rev):
     made = block_start_case(oracle, seed, rev)
-    if made is None:
-        pytest.skip("no single-seed block-start HSP for this PRNG seed")
+    assert made is not None, "no single-seed block-start HSP for PRNG seed %d: pick another seed" % seed
     c, seed_pos, hsp = made
     c.engine_setup(engine)
     try:

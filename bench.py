@@ -76,7 +76,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="ce11cb4", choices=["ce11cb4", "notransition", "rm", "human", "plumbing"])
+    ap.add_argument("--workload", default="ce11cb4", choices=["ce11cb4", "notransition", "rm", "human", "plumbing", "lumpy", "lumpy_rm"])
     ap.add_argument("--target-fasta", default=None, help="real target FASTA (e.g. ce11.fa[.gz]); first 500 Mbp block is used")
     ap.add_argument("--query-fasta", default=None, help="real query FASTA (e.g. cb4.fa[.gz]); first 500 Mbp block is used")
     ap.add_argument("--target-mbp", type=float, default=None, help="synthetic target size (default per workload)")
@@ -144,6 +144,17 @@ def make_workload(args, rank=0):
                  "rm": "repeat-masker path (BASELINE configs[3]): %.0f Mbp ce11 stand-in self-aligned, neighbor_proportion 0.2, M 1"}[w]
         return dict(target=target, query=target if w == "rm" else query, transition=w != "notransition", rm=w == "rm",
                     data="synthetic", label=label % (tlen / 1e6))
+    if w in ("lumpy", "lumpy_rm"):
+        # realistic composition (segalign_amd/synth.py make_realistic): AT-rich Markov background, microsatellites, dispersed repeat
+        # families (70 % of the copies soft-masked), segmental duplications, N gaps; the query a diverged, rearranged copy with
+        # conserved islands and insertions of its own -- a skewed k-mer spectrum instead of ~6 entries in every bucket
+        tlen = int((args.target_mbp or 100.0) * 1e6)
+        target, query = synth.make_realistic(tlen)
+        rm = w == "lumpy_rm"
+        return dict(target=target, query=target if rm else query, transition=True, rm=rm, data="synthetic",
+                    label=("repeat-masker path on the lumpy stand-in: %.0f Mbp realistic-composition target self-aligned, neighbor_proportion 0.2, M 1"
+                           if rm else "lumpy ce11 x cb4 stand-in: %.0f Mbp 7-record realistic-composition target (Markov background, microsatellites, "
+                                      "repeat families, segmental duplications) x diverged rearranged copy, 12of19 + transitions") % (tlen / 1e6))
     if w == "plumbing":
         target, query = synth.make_pair(int((args.target_mbp or 1.0) * 1e6), 1, 2, sub_rate=0.15, indel_every=500, invert_frac=0.0)
         return dict(target=target, query=query, transition=True, rm=False, data="synthetic",
@@ -285,7 +296,7 @@ def main():
     weights = None
     imbalance = None
     t_weigh = None
-    if scaling == "strong" and not wl["rm"] and (args.partition == "hits" or (args.partition == "auto" and world > 1)):
+    if scaling == "strong" and not wl["rm"] and (args.partition == "hits" or (args.partition == "auto" and (world > 1 or args.workload in ("lumpy", "human")))):
         # lookup only (sa_count_call_hits: the position probe + chunk plans of every call, no filtering, no extension): what the map
         # costs a production host per (target block, query block) pair -- reported as partition_cost_ms
         t0 = time.perf_counter()
@@ -401,6 +412,18 @@ def main():
         if not wl["rm"] and not args.no_dropin:
             roof["dropin"] = dropin_leg(E, jobs, args, seed_size, 13 if wl["transition"] else 1)
 
+    # how evenly the seed hits are spread over the 250 kbp chunks of the pass (lookup only; rank 0, outside the timed region)
+    hit_spread = None
+    if rank == 0 and not wl["rm"] and not args.no_roofline:
+        one = []
+        for j in jobs:
+            for c in range(j["a"], j["b"], args.chunk):
+                one.append((c, min(c + args.chunk, j["b"]), j["rev"]))
+        ch = np.array(E.CountCallHits(one, 0, inflight), dtype=np.float64)
+        if ch.size and ch.sum() > 0:
+            hit_spread = {"chunks": int(ch.size), "hits_per_pass": int(ch.sum()), "heaviest_chunk_over_mean": round(float(ch.max() / ch.mean()), 3),
+                          "lightest_chunk_over_mean": round(float(ch.min() / ch.mean()), 3)}
+
     # ---------------- CPU baseline (rank 0, N == 1 only, bounded sample) ----------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_roofline:
@@ -427,7 +450,7 @@ def main():
                                                           "untimed pass every rank runs identically)" if weights else "round-robin")) if scaling == "strong" else
                                       ("every one of %d rank(s) runs all %d calls of a pass (`human`: on a block pair of its own), no collective"
                                        % (world, len(jobs))),
-                       "calls_per_step": len(jobs), "calls_in_flight_per_gpu": inflight, "partition_imbalance": imbalance,
+                       "calls_per_step": len(jobs), "calls_in_flight_per_gpu": inflight, "partition_imbalance": imbalance, "hit_spread": hit_spread,
                        # what the by-hits map costs: one lookup-only pass over all calls on every rank (outside the timed region)
                        "partition_cost_ms": round(1e3 * t_weigh, 3) if t_weigh is not None else None,
                        # one pass at a time with a barrier + drain on both sides (max over ranks), next to ms_per_step of the

@@ -253,9 +253,16 @@ typedef struct sa_call_stats {
     int device;
     int lookup_path;        /* seed lookup path the call took: 0 general (seed words -> buckets -> hit list), 1 table-direct,
                                2 table-direct with target context (sa_get_lookup_mode) */
-    int reserved;
+    uint32_t path_flags;    /* SA_PATH_*: which of the engine's rare branches the call took (diagnostics; the results never depend on them).
+                               Summed statistics (sa_seed_calls, sa_seed_interval) carry the OR over their calls */
     uint64_t num_forwarded; /* context-table calls: hits the class filter (level 1) handed to the second level; 0 otherwise */
 } sa_call_stats;
+#define SA_PATH_LIST_REGROWN 1u          /* a device list (second-level / candidate / entropy / survivor) overflowed: regrown, batch rerun */
+#define SA_PATH_DEDUP_FALLBACK 2u        /* a segment held more survivors than the LDS chain takes: library sorts + unique */
+#define SA_PATH_CHAIN_BUCKET_OVERFLOW 4u /* a chain bucket above its LDS capacity was left unsorted (costs extensions, never results) */
+#define SA_PATH_CHAIN_SKIPPED 8u         /* more candidates than the chain buffers hold: every candidate extended on its own */
+#define SA_PATH_HEAD_BITS_REGROWN 16u    /* the head-bit map of the call's hits was regrown and the compaction repeated */
+#define SA_PATH_GENERAL_FALLBACK 32u     /* a device-seeded call could not take the table-direct path (MAX_HITS split, > 2^32 hits, ...) */
 void sa_get_last_call_stats(sa_call_stats* out); /* stats of the calling thread's most recent hot call */
 void sa_set_count_examined(int on);
 /* X-drop filter kernel selected by InitializeProcessor for plain calls: 0 = exact per-base walk, 1 = fast per-base

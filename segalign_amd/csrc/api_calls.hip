@@ -48,7 +48,7 @@ size_t sa_seed_and_filter_range(uint32_t start, uint32_t end, int rev, uint32_t 
         ns = td_front(dc, sl, q, 1, bp, 0, &words);
     }
     const bool td = ns != 0xFFFFFFFFu;
-    if (!td) ns = device_seeds(sl, q, start, end);
+    if (!td) { ns = device_seeds(sl, q, start, end); t_front_flags |= SA_PATH_GENERAL_FALLBACK; }
     size_t n = 0;
     *out = nullptr;
     if (ns > 0) {  // seeder.cpp:76: the engine is only called for a non-empty seed vector
@@ -60,6 +60,7 @@ size_t sa_seed_and_filter_range(uint32_t start, uint32_t end, int rev, uint32_t 
     } else {
         prof_flush(sl);
         memset(&t_stats, 0, sizeof(t_stats));
+        t_front_flags = 0;
     }
     release_slot(sl);
     return n;
@@ -97,7 +98,7 @@ size_t sa_seed_and_filter_chunks(uint32_t start, uint32_t end, int rev, uint32_t
     if (td_eligible(dc, q4, rev ? &dc->query2_rc[buffer] : &dc->query2[buffer], rev ? &dc->query2[buffer] : &dc->query2_rc[buffer]))
         ns = td_front(dc, sl, q, K, bpos, 0, &words);
     const bool td = ns != 0xFFFFFFFFu;
-    if (!td) ns = device_seeds(sl, q, start, send, K + 1, bpos, bseed);
+    if (!td) { ns = device_seeds(sl, q, start, send, K + 1, bpos, bseed); t_front_flags |= SA_PATH_GENERAL_FALLBACK; }
     size_t total = 0;
     if (ns > 0) {
         CoreArgs ca = {q, qlen, 0, 0, 0, 0, start, send, nullptr, 0, q4};
@@ -113,6 +114,7 @@ size_t sa_seed_and_filter_chunks(uint32_t start, uint32_t end, int rev, uint32_t
     } else {
         prof_flush(sl);
         memset(&t_stats, 0, sizeof(t_stats));
+        t_front_flags = 0;
     }
     release_slot(sl);
     return total;
@@ -194,6 +196,7 @@ size_t sa_seed_interval(uint32_t start, uint32_t end, uint32_t q_len, int strand
         tot.num_iter += t_stats.num_iter;
         tot.device = t_stats.device;
         tot.lookup_path = t_stats.lookup_path;
+        tot.path_flags |= t_stats.path_flags;
     });
     size_t cnt[2] = {0, 0};
     for (const Job& jb : jobs)
@@ -260,6 +263,7 @@ size_t sa_seed_calls(const sa_call_desc* calls, size_t num_calls, uint32_t buffe
         tot.num_iter += t_stats.num_iter;
         tot.device = t_stats.device;
         tot.lookup_path = t_stats.lookup_path;
+        tot.path_flags |= t_stats.path_flags;
     });
     size_t total = 0;
     for (size_t i = 0; i < num_calls; i++) total += results[i].num_hsps;

@@ -14,6 +14,8 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
     uint32_t n_final = 0;
     uint32_t survivors = 0;
     uint64_t n_cand_total = 0, n_ent_total = 0, n_fwd_total = 0;
+    uint32_t path_flags = t_front_flags;  // SA_PATH_* of this call (the front of the call may have set some already)
+    t_front_flags = 0;
     // chunks of the seed vector (one for an ordinary call)
     const int K = ca.nchunks > 1 ? ca.nchunks : 1;
     uint32_t sbound[SA_MAX_CHUNKS + 1] = {0, num_seeds};
@@ -240,6 +242,7 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                     ea.chain_is_head = sl->chain_is_head.p;
                     ea.chain_heads = sl->chain_heads.p;
                     ea.chain_head_count = &sl->d_cnt->n_heads;
+                    ea.chain_big = &sl->d_cnt->n_chain_big;
                 }
                 sl->ent_list.ensure((size_t)std::max<uint64_t>(1u << 16, bh / 32), "entropy list");
                 Counters before = *sl->h_cnt;  // counters as of the previous batch (zero for the first)
@@ -259,6 +262,7 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                     ea.audit_cap = g_audit_cap;
                 }
                 before.n_audit = 0;
+                before.n_chain_big = 0;
                 for (;;) {  // rerun the batch with larger lists if one overflowed (device writes are guarded)
                     ea.out = sl->recA.p;
                     ea.out_cap = (uint32_t)std::min<size_t>(sl->recA.cap, 0xFFFFFFFFu);
@@ -312,6 +316,7 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                     spec_done = spec && sl->h_seg_info[seg_words - 1] == 0;
                     if (ea.chain_cap && sl->h_cnt->n_long > ea.chain_cap && sl->h_cnt->n_long <= ea.cand_cap_recs) {
                         spec_done = false;  // (the chain ran on an unfinished survivor list)
+                        path_flags |= SA_PATH_CHAIN_SKIPPED;
                         // more candidates than the chain buffers hold: the chain kernels left the batch alone (device-side
                         // test on the same counter); extend every candidate on its own
                         ExtendArgs eb = ea;
@@ -325,6 +330,7 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                     const Counters& c = *sl->h_cnt;
                     const bool l2_ok = !(ea.td && ea.td_ctx) || c.n_l2_max <= ea.l2_cap;
                     if (c.survivors <= ea.out_cap && c.n_long <= ea.cand_cap_recs && c.n_ent <= ea.ent_cap_recs && l2_ok) break;
+                    path_flags |= SA_PATH_LIST_REGROWN;
                     if (!l2_ok)  // (the later stages saw a truncated list)
                         sl->l2_list.ensure((size_t)c.n_l2_max * L2_NSUB + ((size_t)c.n_l2_max * L2_NSUB) / 4, "second-level list(grow)");
                     // an overflowing long list also truncates what the later kernels saw: size everything from the
@@ -339,6 +345,7 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                     cleared = false;  // (the rerun of the batch clears its lists itself)
                 }
                 survivors = sl->h_cnt->survivors;
+                if (sl->h_cnt->n_chain_big) path_flags |= SA_PATH_CHAIN_BUCKET_OVERFLOW;
                 n_cand_total += sl->h_cnt->n_long;
                 n_fwd_total += sl->h_cnt->n_l2;
                 n_ent_total += sl->h_cnt->n_ent;
@@ -416,6 +423,7 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                         done = true;
                     }
                 }
+                if (!done && !ca.rm && segs.size() <= dedup_small_max_segs() && !g_no_small_dedup) path_flags |= SA_PATH_DEDUP_FALLBACK;
                 if (done) {
                     // nothing left to do on the device
                 } else if (!ca.rm) {
@@ -468,6 +476,7 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
     }
     prof_flush(sl);
 
+    t_stats.path_flags = path_flags;
     t_stats.lookup_path = ca.td ? ((dc->nbr_ctx && ca.q2_own && ca.q2_own->base) ? 2 : 1) : 0;
     t_stats.num_hits = num_hits;
     t_stats.num_survivors = survivors;

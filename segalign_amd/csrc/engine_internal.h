@@ -230,7 +230,8 @@ struct Counters {  // device-side scalars of one slot
     uint32_t n_l2;    // hits the context filter handed to the second level (this batch)
     uint32_t n_l2_max;  // largest sub-list of them (compared with the sub-list capacity)
     uint32_t n_audit;   // (tests) hits the filters rejected, see the audit option
-    uint32_t pad2[2];
+    uint32_t n_chain_big;  // bucket groups the chain sort left unordered (a bucket above its LDS capacity)
+    uint32_t pad2;
 };
 
 struct DevCtx;
@@ -415,6 +416,7 @@ extern SeedShape g_shape;
 extern uint32_t g_query_len[SA_BUFFER_DEPTH];
 extern thread_local sa_call_stats t_stats;
 extern thread_local std::vector<uint2> t_audit;
+extern thread_local uint32_t t_front_flags;  // SA_PATH_* bits the front of the calling thread's current call has set (front.hip -> core.hip)
 
 int64_t opt_value(const char* name);  // the option table (options.hip)
 void resolve_options();

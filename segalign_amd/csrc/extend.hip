@@ -1365,6 +1365,7 @@ __global__ __launch_bounds__(512) void chain_bucket_sort_kernel(ExtendArgs a) {
     for (uint32_t j = 0; j < CHAIN_SORT_GROUP; j++) big = big || (s_b[j + 1] - s_b[j]) > CHAIN_SORT_MAX;
     if (big) {
         for (uint32_t i = threadIdx.x; i < m_all; i += blockDim.x) a.chain_sorted[g0 + i] = a.chain_tmp[g0 + i];
+        if (threadIdx.x == 0 && a.chain_big) atomicAdd(a.chain_big, 1u);
         return;
     }
     for (uint32_t i = threadIdx.x; i < m_all; i += blockDim.x) s_key[i] = chain_key(a, a.chain_tmp[g0 + i]);

@@ -269,6 +269,7 @@ uint32_t td_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, int K, const uint
         const uint64_t need_words = ((call_hits + 63) >> 6) * 2 + 16;  // (the filter reads up to six 64-bit words past the last buffer)
         if (!want_bits || need_words <= sl->td_bits.cap || call_hits > 0xFFFFFFFFull) break;
         sl->td_bits.ensure((size_t)need_words + need_words / 4, "probe head bits(grow)");
+        t_front_flags |= SA_PATH_HEAD_BITS_REGROWN;
     }
     uint64_t nvalid = 0;
     for (int c = 0; c < K; c++) {

@@ -127,6 +127,7 @@ struct ExtendArgs {
     uint32_t* chain_is_head;                 // [chain_cap]
     uint32_t* chain_heads;                   // [chain_cap] indices of run heads
     uint32_t* chain_head_count;
+    uint32_t* chain_big;                     // -> number of bucket groups the sort left unordered (bucket above its LDS capacity): diagnostics
     uint32_t max_waves;       // wave budget of the main kernel (resident waves of the chip)
     uint32_t long_blocks, ent_blocks;  // grid sizes of the long / entropy kernels (they read their counts on device)
     const Hit* hits;

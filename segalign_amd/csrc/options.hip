@@ -50,7 +50,8 @@ SeedShape g_shape = {0, 0, 0, {0}};
 uint32_t g_query_len[SA_BUFFER_DEPTH] = {0, 0};
 
 thread_local sa_call_stats t_stats;
-thread_local std::vector<uint2> t_audit;  // rejected hits of the calling thread's last hot call (audit option)
+thread_local std::vector<uint2> t_audit;
+thread_local uint32_t t_front_flags = 0;  // rejected hits of the calling thread's last hot call (audit option)
 uint32_t SPEC_RECS = 16384;
 uint32_t g_dedup_seg_max = 0;
 int SLOTS_PER_DEVICE = 4;

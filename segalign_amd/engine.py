@@ -41,13 +41,14 @@ C_ABI_SYMBOLS = [
 ]
 IVL_DTYPE = np.dtype([("query_start", "<u4"), ("len", "<u4")])  # struct Segment, repeat_masker_src/graph.h:32-35
 STRAND_PLUS, STRAND_MINUS, STRAND_BOTH = 1, 2, 3
+PATH_LIST_REGROWN, PATH_DEDUP_FALLBACK, PATH_CHAIN_BUCKET_OVERFLOW, PATH_CHAIN_SKIPPED, PATH_HEAD_BITS_REGROWN, PATH_GENERAL_FALLBACK = 1, 2, 4, 8, 16, 32
 
 
 class CallStats(C.Structure):
     _fields_ = [("num_seeds", C.c_uint64), ("num_hits", C.c_uint64), ("num_survivors", C.c_uint64),
                 ("num_anchors", C.c_uint64), ("num_examined", C.c_uint64), ("num_examined_filter", C.c_uint64),
                 ("num_candidates", C.c_uint64), ("num_entropy", C.c_uint64), ("num_iter", C.c_uint32),
-                ("device", C.c_int), ("lookup_path", C.c_int), ("reserved", C.c_int), ("num_forwarded", C.c_uint64)]
+                ("device", C.c_int), ("lookup_path", C.c_int), ("path_flags", C.c_uint32), ("num_forwarded", C.c_uint64)]
 
 
 _lib = None

@@ -77,3 +77,24 @@ def canonical_pos_table(index, pos):
     bucket_of = np.repeat(np.arange(index.size, dtype=np.int64), index - starts)
     order = np.lexsort((np.asarray(pos, dtype=np.int64), bucket_of))
     return np.asarray(pos)[order]
+
+
+def check_seed_table_properties(E, target_size, seed_size=19):
+    """Size-independent properties of the device-built seed position table (common/seed_pos_table.cu:49-109): offsets ascending and
+    closed, every indexed position distinct, in range, never 0 (H6), ascending inside its bucket, and as many positions as there are
+    windows of upper-case ACGT only."""
+    import numpy as np
+    index = E.copy_index_table()
+    pos = E.copy_pos_table()
+    assert index[-1] == pos.size and np.all(np.diff(index.astype(np.int64)) >= 0)
+    assert pos.min() >= 1 and pos.max() <= target_size - seed_size
+    assert np.unique(pos).size == pos.size
+    starts = np.concatenate([[0], index[:-1].astype(np.int64)])
+    desc = np.nonzero(np.diff(pos.astype(np.int64)) < 0)[0] + 1  # descents may only happen at bucket starts
+    assert np.all(np.isin(desc, starts))
+    codes = E.copy_ref_codes()
+    bad = (codes >= 4).astype(np.int32)
+    csum = np.concatenate([[0], np.cumsum(bad)])
+    valid = (csum[seed_size:] - csum[:-seed_size]) == 0   # window starting at p = 0 .. len - seed_size
+    assert int(valid[1:].sum()) == pos.size               # position 0 excluded
+    return index, pos

@@ -1,0 +1,131 @@
+"""GPU, full size: the LUMPY ce11 x cb4 stand-in (segalign_amd/synth.py make_realistic: AT-rich Markov background, microsatellites,
+dispersed repeat families with 70 % of the copies soft-masked, segmental duplications, N gaps; the query a diverged rearranged copy)
+-- the workload on which buckets are NOT ~6 entries each: max bucket ~25 k entries, ~100 buckets above 1024, 3.6x the seed hits of the
+uniform stand-in, chunks from 0.3x to 1.5x the mean.  Real ce11 / cb4 (reference README.md:69-78) cannot be fetched offline.
+
+Checked: the table's size-independent properties at 100 Mbp; single-chunk calls on both strands INCLUDING the heaviest chunk of each
+strand and one 20-chunk call around the heaviest chunk of the pass, bit for bit against the oracle (src/seed_filter.cu:682-828); that
+the rare branches a skewed spectrum is there to reach were really taken (sa_call_stats.path_flags); the repeat-masker variant of the
+same target (repeat_masker_src/seeder.cpp:28-195) against the host model."""
+import numpy as np
+import pytest
+
+from helpers import check_seed_table_properties
+from segalign_amd import shard, synth
+from test_gpu_rm_mask import as_list, model_mask_interval
+
+pytestmark = pytest.mark.gpu
+
+SHAPE = "TTT0T00TT00T0T0TTTT"
+CHUNK = 250_000
+
+
+@pytest.fixture(scope="module")
+def lumpy(oracle, engine):
+    E, O = engine, oracle
+    target, query = synth.make_realistic(100_000_000)
+    sub_mat = O.build_sub_mat(910)
+    E.InitializeInterface(1)
+    k = E.GenerateShapePos(SHAPE)
+    O.generate_shape_pos(SHAPE)
+    E.InitializeProcessor(True, CHUNK, 19, sub_mat, 910, 3000, False)
+    keep = E.SendRefWriteRequest(target, 0, target.size)
+    E.GenerateSeedPosTable(keep, 0, target.size, 1, 19, k)
+    E.SendQueryWriteRequest(query, 0, query.size, 0)
+    d = dict(E=E, O=O, target=target, query=query, sub_mat=sub_mat, k=k, index=E.copy_index_table(), pos=E.copy_pos_table(),
+             rcodes=E.copy_ref_codes(), flags=0)
+    d["rc_ascii"] = np.frombuffer(O.rev_comp_ascii(query.tobytes(), 0, query.size), dtype=np.uint8)
+    yield d
+    E.ShutdownProcessor()
+
+
+def test_table_properties_and_spectrum(lumpy):
+    E = lumpy["E"]
+    check_seed_table_properties(E, lumpy["target"].size, 19)
+    sizes = np.diff(np.concatenate([[0], lumpy["index"].astype(np.int64)]))
+    assert sizes.max() > 5000 and int((sizes > 1024).sum()) >= 20          # heavy buckets exist (uniform DNA: max ~25)
+    assert E.lookup_mode() == 2
+
+
+def chunk_hits(lumpy, rev):
+    E = lumpy["E"]
+    end = lumpy["query"].size - 19
+    ch = [(a, min(a + CHUNK, end), rev) for a in range(0, end, CHUNK)]
+    return ch, np.array(E.CountCallHits(ch, 0, 4), dtype=np.int64)
+
+
+def oracle_chunk(lumpy, a, b, rev):
+    O = lumpy["O"]
+    buf = lumpy["rc_ascii"] if rev else lumpy["query"]
+    seeds = O.make_seeds(buf.tobytes(), 0, a, b, 19, lumpy["k"], True)
+    qcodes = lumpy["E"].copy_query_codes(0, rev)
+    return O.seed_and_filter(lumpy["rcodes"], qcodes, lumpy["index"], lumpy["pos"], seeds, lumpy["sub_mat"])
+
+
+@pytest.mark.parametrize("rev", [False, True])
+def test_single_chunk_calls_incl_the_heaviest_against_the_oracle(lumpy, rev):
+    E = lumpy["E"]
+    ch, hits = chunk_hits(lumpy, rev)
+    assert hits.max() > 1.3 * hits.mean() and hits.min() < 0.7 * hits.mean()   # lumpy over chunks, too
+    order = np.argsort(hits)
+    picks = [int(order[-1]), int(order[-2]), int(order[len(order) // 2]), int(order[1])]   # heaviest two, a median one, a light one
+    n = 0
+    for i in picks:
+        a, b, _ = ch[i]
+        got = E.SeedAndFilterRange(a, b, rev, 0)
+        st = E.last_call_stats()
+        lumpy["flags"] |= st["path_flags"]
+        want, ost = oracle_chunk(lumpy, a, b, rev)
+        assert st["num_hits"] == ost["num_hits"] == hits[i]
+        assert got.shape == want.shape and np.all(got == want), (rev, a, b, got.size, want.size)
+        n += want.size - 1
+    assert n > 1000
+
+
+def test_twenty_chunk_call_around_the_heaviest_chunk_against_the_oracle(lumpy):
+    E = lumpy["E"]
+    best = None
+    for rev in (False, True):
+        ch, hits = chunk_hits(lumpy, rev)
+        i = int(np.argmax(hits))
+        if best is None or hits[i] > best[0]:
+            best = (int(hits[i]), rev, i, ch)
+    _, rev, i, ch = best
+    lo = max(0, min(i - 7, len(ch) - 20))
+    group = ch[lo:lo + 20]
+    outs = E.SeedAndFilterChunks(group[0][0], group[-1][1], rev, 0)
+    st = E.last_call_stats()
+    lumpy["flags"] |= st["path_flags"]
+    assert st["lookup_path"] == 2 and st["num_hits"] > 500_000_000
+    for j, (a, b, _) in enumerate(group):
+        want, _ = oracle_chunk(lumpy, a, b, rev)
+        assert outs[j].shape == want.shape and np.all(outs[j] == want), (rev, j, a, b, outs[j].size, want.size)
+
+
+def test_the_rare_branches_were_taken(lumpy):
+    """(runs after the calls above) what a skewed k-mer spectrum is there to reach: a chain bucket above its LDS capacity, a dedup
+    segment above the LDS chain's 2048 records (library sorts), a device list regrown and its batch rerun."""
+    E, f = lumpy["E"], lumpy["flags"]
+    assert f & E.PATH_DEDUP_FALLBACK, f
+    assert f & E.PATH_CHAIN_BUCKET_OVERFLOW, f
+    assert f & E.PATH_LIST_REGROWN, f
+
+
+def test_repeat_masker_variant_on_the_lumpy_target(oracle, engine, lumpy):
+    """The same target self-aligned through sa_rm_mask_interval: one 1 Mbp piece of the first interval task of the reference's
+    plan (repeat_masker_src/main.cpp:316-436) against the host model of repeat_masker_src/seeder.cpp:28-195."""
+    E, O = engine, oracle
+    target = lumpy["target"]
+    E.RmSendQueryWriteRequest()
+    try:
+        task = shard.rm_plan(target.size, seed_size=19)[0]
+        a = task["start"] + 3_000_000
+        got, tot = E.RmMaskInterval(a, a + 1_000_000, task["ref_start"], task["ref_end"], E.STRAND_BOTH, 1)
+        import types
+        c = types.SimpleNamespace(target=target, chunk=CHUNK, seed_size=19, kmer_size=lumpy["k"], transition=True, o_ref=lumpy["rcodes"],
+                                  o_index=lumpy["index"], o_pos=lumpy["pos"], sub_mat=lumpy["sub_mat"], xdrop=910, hspthresh=3000, noentropy=False)
+        want, wtot = model_mask_interval(c, O, a, a + 1_000_000, task["ref_start"], task["ref_end"], E.STRAND_BOTH, 1)
+        assert as_list(got) == as_list(want) and len(as_list(got)) > 10
+        assert tot["num_hits"] == wtot["num_hits"] and tot["num_hsps"] == wtot["num_hsps"]
+    finally:
+        E.RmClearQuery()

@@ -4,6 +4,7 @@ oracle agreement on one full chunk-call per strand (the table is copied from the
 import numpy as np
 import pytest
 
+from helpers import check_seed_table_properties
 from segalign_amd import shard, synth
 
 pytestmark = pytest.mark.gpu
@@ -28,22 +29,7 @@ def full(oracle, engine, standin_100mbp):
 
 
 def test_table_is_a_permutation_of_valid_positions(full):
-    E = full["E"]
-    index = E.copy_index_table()
-    pos = E.copy_pos_table()
-    assert index[-1] == pos.size and np.all(np.diff(index.astype(np.int64)) >= 0)
-    # every indexed position is distinct, in range, never 0 (H6) and ascending inside its bucket
-    assert pos.min() >= 1 and pos.max() <= full["target"].size - 19
-    assert np.unique(pos).size == pos.size
-    starts = np.concatenate([[0], index[:-1].astype(np.int64)])
-    desc = np.nonzero(np.diff(pos.astype(np.int64)) < 0)[0] + 1  # descents may only happen at bucket starts
-    assert np.all(np.isin(desc, starts))
-    # count == number of windows made of upper-case ACGT only (encode: code < 4)
-    codes = E.copy_ref_codes()
-    bad = (codes >= 4).astype(np.int32)
-    csum = np.concatenate([[0], np.cumsum(bad)])
-    valid = (csum[19:] - csum[:-19]) == 0          # window starting at p = 0 .. len-19
-    assert int(valid[1:].sum()) == pos.size       # position 0 excluded
+    check_seed_table_properties(full["E"], full["target"].size, 19)
 
 
 def test_calls_are_deterministic_and_entry_points_agree(full):

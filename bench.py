@@ -846,6 +846,29 @@ def default_sub_mat(xdrop):
     return m.reshape(64)
 
 
+def usable_cores():
+    """Cores this process may really use: the affinity mask, capped by the cgroup's CPU quota (a container that sees 256 CPUs but is
+    allowed 12 runs 64 threads no faster than 12)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, p = int(f.read()), int(g.read())
+            if q > 0:
+                n = max(1, min(n, int(q / p + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(E, target, query, sub_mat, seed_size, kmer, args, xdrop, hspthresh, transition):
     """The oracle (a port: the reference cannot be compiled here and LASTZ is absent) timed on the host cores on a bounded sample of
     the SAME workload, run the way a CPU host would run it: ONE (chunk, strand) task per core -- min(cores, 64) tasks in flight,
@@ -856,7 +879,7 @@ def cpu_baseline(E, target, query, sub_mat, seed_size, kmer, args, xdrop, hspthr
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     O.build(with_ref=False)
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     used = max(1, min(cores, 64))
     O.generate_shape_pos(SHAPE)
     index = E.copy_index_table()
@@ -915,7 +938,7 @@ def cpu_baseline_rm(E, target, sub_mat, seed_size, kmer, args, xdrop, hspthresh,
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     O.build(with_ref=False)
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     used = max(1, min(cores, 64))
     O.generate_shape_pos(SHAPE)
     index = E.copy_index_table()

@@ -203,7 +203,7 @@ int sa_max_hits_for_mem(uint64_t total_global_mem);
  * choose between implementations of the same reference semantics (src/seed_filter.cu:682-828) or size their launches.
  *
  * Deployment options
- *   slots             calls in flight per device (default 4 = max; the reference allows 1: its token IS the device).  Every slot
+ *   slots             calls in flight per device (default 4, at most 8; the reference allows 1: its token IS the device).  Every slot
  *                     has its own stream; the library's load-time constructor sets GPU_MAX_HW_QUEUES=8 (unless the variable is
  *                     set) because slots that share one of the runtime's default four hardware queues run one after the other
  *   chunks_per_call   wga_chunk-sized chunks sa_seed_interval / sa_rm_mask_interval hand to one pass (default 20, maximum 32)
@@ -260,7 +260,7 @@ typedef struct sa_call_stats {
 #define SA_PATH_LIST_REGROWN 1u          /* a device list (second-level / candidate / entropy / survivor) overflowed: regrown, batch rerun */
 #define SA_PATH_DEDUP_FALLBACK 2u        /* a segment held more survivors than the LDS chain takes: library sorts + unique */
 #define SA_PATH_CHAIN_BUCKET_OVERFLOW 4u /* a chain bucket above its LDS capacity was left unsorted (costs extensions, never results) */
-#define SA_PATH_CHAIN_SKIPPED 8u         /* more candidates than the chain buffers hold: every candidate extended on its own */
+#define SA_PATH_CHAIN_SLICED 8u          /* more candidates than the chain buffers hold: the chain stages ran over the list slice by slice */
 #define SA_PATH_HEAD_BITS_REGROWN 16u    /* the head-bit map of the call's hits was regrown and the compaction repeated */
 #define SA_PATH_GENERAL_FALLBACK 32u     /* a device-seeded call could not take the table-direct path (MAX_HITS split, > 2^32 hits, ...) */
 void sa_get_last_call_stats(sa_call_stats* out); /* stats of the calling thread's most recent hot call */

@@ -70,34 +70,77 @@ size_t sa_seed_and_filter_range(uint32_t start, uint32_t end, int rev, uint32_t 
 // seeding, lookup, expansion, extension, grouping and ordering launches and the host syncs, while every chunk keeps its own
 // iteration plan, dedup scope and return vector -- bit for bit what one sa_seed_and_filter_range call per chunk returns.
 int sa_max_chunks_per_call(void) { return SA_MAX_CHUNKS; }
-int sa_get_chunks_per_call(void) { return g_chunks_per_call; }  // what sa_seed_interval hands to one call (SEGALIGN_AMD_CHUNKS_PER_CALL)
-size_t sa_seed_and_filter_chunks(uint32_t start, uint32_t end, int rev, uint32_t buffer, sa_segment_pair** outs, size_t* counts) {
-    require_proc("SeedAndFilterChunks", buffer);
+// What the interval entries hand to one call, and what a host that builds its own call lists should use: option chunks_per_call
+// (default 20), raised for the RESIDENT target when its seed hits are sparse -- a call is sized by hits, not by chunks: option
+// call_hits (default 256 M) / (table entries per key x wga_chunk positions), at most sa_max_chunks_per_call().  With
+// --notransition one 250 kbp chunk holds ~1.5 M hits instead of ~19 M: twenty-chunk calls would spend two thirds of their time in
+// per-call fixed costs.
+int sa_get_chunks_per_call(void) {
+    int k = g_chunks_per_call;
+    if (g_call_hits > 0 && g_ndev > 0 && g_proc_init) {
+        DevCtx* dc = g_dev[0];
+        if (dc->nbr_state == 1 && dc->nkeys > 0 && g_wga_chunk > 0) {
+            const double per_pos = (double)dc->nbr_total / (double)dc->nkeys;           // hits of a query position with a random k-mer
+            const double per_chunk = std::max(1.0, per_pos * (double)g_wga_chunk);
+            const double want = (double)g_call_hits / per_chunk;
+            if (want > (double)k) k = (int)std::min<double>(want, (double)SA_MAX_CHUNKS);
+        }
+    }
+    return k;
+}
+
+static void stats_add(sa_call_stats& a, const sa_call_stats& b) {
+    a.num_seeds += b.num_seeds; a.num_hits += b.num_hits; a.num_survivors += b.num_survivors; a.num_anchors += b.num_anchors;
+    a.num_examined += b.num_examined; a.num_examined_filter += b.num_examined_filter; a.num_candidates += b.num_candidates;
+    a.num_forwarded += b.num_forwarded; a.num_entropy += b.num_entropy; a.num_iter += b.num_iter;
+    a.device = b.device;
+    a.lookup_path = b.lookup_path;
+    a.path_flags |= b.path_flags;
+}
+
+// The chunks of [start, end) in one pass -- or, when the pass cannot hold them, in two halves (recursively): a table-direct call
+// indexes its hits with 32 bits and needs every chunk below MAX_HITS, the general path plans at most SA_MAX_CHUNKS_GENERAL chunks
+// per pass.  Splitting changes nothing in the results (every chunk keeps its own plan and dedup scope either way); the calling
+// thread's statistics are the sums over the passes.
+static size_t chunks_pass(uint32_t start, uint32_t end, int rev, uint32_t buffer, sa_segment_pair** outs, size_t* counts) {
     const uint32_t chunk = g_wga_chunk;
     const int K = end > start ? (int)(((uint64_t)end - start + chunk - 1) / chunk) : 0;
-    if (K > SA_MAX_CHUNKS) {
-        fprintf(stderr, "Error: SeedAndFilterChunks takes at most %d chunks per call\n", SA_MAX_CHUNKS);
-        exit(1);
-    }
-    for (int c = 0; c < K; c++) { outs[c] = nullptr; counts[c] = 0; }
     if (K == 0) return 0;
     if (K == 1) {
         counts[0] = sa_seed_and_filter_range(start, end, rev, buffer, &outs[0]);
         return counts[0];
     }
+    auto halves = [&]() {
+        const int k0 = K / 2;
+        const uint32_t mid = start + (uint32_t)k0 * chunk;
+        sa_call_stats sum;
+        size_t total = chunks_pass(start, mid, rev, buffer, outs, counts);
+        sum = t_stats;
+        total += chunks_pass(mid, end, rev, buffer, outs + k0, counts + k0);
+        stats_add(sum, t_stats);
+        t_stats = sum;
+        return total;
+    };
     Slot* sl = acquire_slot();
     DevCtx* dc = sl->ctx;
     const uint8_t* q = rev ? dc->query_rc[buffer].codes : dc->query[buffer].codes;
     const uint32_t qlen = g_query_len[buffer];
     const uint32_t lim = qlen >= g_seed_size ? qlen - g_seed_size + 1 : 0;
     const uint32_t send = std::min(end, lim);  // a seed window must lie inside the block
-    uint32_t bpos[SA_MAX_CHUNKS + 1], bseed[SA_MAX_CHUNKS + 1];
+    uint32_t bpos[SA_MAX_CHUNKS + 1], bseed[SA_MAX_CHUNKS_GENERAL + 1];
     for (int c = 0; c <= K; c++) bpos[c] = (uint32_t)std::min<uint64_t>((uint64_t)start + (uint64_t)c * chunk, send);
     const PackedBuf* q4 = rev ? &dc->query4_rc[buffer] : &dc->query4[buffer];
     uint32_t ns = 0xFFFFFFFFu, words = 0;
-    if (td_eligible(dc, q4, rev ? &dc->query2_rc[buffer] : &dc->query2[buffer], rev ? &dc->query2[buffer] : &dc->query2_rc[buffer]))
-        ns = td_front(dc, sl, q, K, bpos, 0, &words);
+    const bool eligible = td_eligible(dc, q4, rev ? &dc->query2_rc[buffer] : &dc->query2[buffer], rev ? &dc->query2[buffer] : &dc->query2_rc[buffer]);
+    if (eligible) ns = td_front(dc, sl, q, K, bpos, 0, &words);
     const bool td = ns != 0xFFFFFFFFu;
+    if (!td && (eligible || K > SA_MAX_CHUNKS_GENERAL)) {
+        // one of the chunks needs the general path (num_hits >= MAX_HITS), the pass holds 2^32 hits or more, or it is too long for
+        // the general path: halve it -- the chunks that can stay table-direct do
+        prof_flush(sl);
+        release_slot(sl);
+        return halves();
+    }
     if (!td) { ns = device_seeds(sl, q, start, send, K + 1, bpos, bseed); t_front_flags |= SA_PATH_GENERAL_FALLBACK; }
     size_t total = 0;
     if (ns > 0) {
@@ -118,6 +161,22 @@ size_t sa_seed_and_filter_chunks(uint32_t start, uint32_t end, int rev, uint32_t
     }
     release_slot(sl);
     return total;
+}
+
+size_t sa_seed_and_filter_chunks(uint32_t start, uint32_t end, int rev, uint32_t buffer, sa_segment_pair** outs, size_t* counts) {
+    require_proc("SeedAndFilterChunks", buffer);
+    const uint32_t chunk = g_wga_chunk;
+    const int K = end > start ? (int)(((uint64_t)end - start + chunk - 1) / chunk) : 0;
+    if (K > SA_MAX_CHUNKS) {
+        fprintf(stderr, "Error: SeedAndFilterChunks takes at most %d chunks per call\n", SA_MAX_CHUNKS);
+        exit(1);
+    }
+    for (int c = 0; c < K; c++) { outs[c] = nullptr; counts[c] = 0; }
+    if (K == 0) {
+        memset(&t_stats, 0, sizeof(t_stats));
+        return 0;
+    }
+    return chunks_pass(start, end, rev, buffer, outs, counts);
 }
 
 void sa_free_segments(sa_segment_pair* p) { free(p); }
@@ -159,7 +218,7 @@ size_t sa_seed_interval(uint32_t start, uint32_t end, uint32_t q_len, int strand
     require_proc("SeedInterval", buffer);
     struct Job { uint32_t a, b; int rev; int k; sa_segment_pair* res[SA_MAX_CHUNKS]; size_t n[SA_MAX_CHUNKS]; };
     std::vector<Job> jobs;
-    const int per_job = g_chunks_per_call;  // chunks of one strand that share one pass over the kernels
+    const int per_job = sa_get_chunks_per_call();  // chunks of one strand that share one pass over the kernels
     for (int rev = 0; rev < 2; rev++) {
         if (!(strands & (rev ? SA_STRAND_MINUS : SA_STRAND_PLUS))) continue;
         const uint32_t a = rev ? q_len - end : start, b = rev ? q_len - start : end;
@@ -184,19 +243,7 @@ size_t sa_seed_interval(uint32_t start, uint32_t end, uint32_t q_len, int strand
         Job& jb = jobs[j];
         sa_seed_and_filter_chunks(jb.a, jb.b, jb.rev, buffer, jb.res, jb.n);
         std::lock_guard<std::mutex> lk(mu);
-        tot.num_seeds += t_stats.num_seeds;
-        tot.num_hits += t_stats.num_hits;
-        tot.num_survivors += t_stats.num_survivors;
-        tot.num_anchors += t_stats.num_anchors;
-        tot.num_examined += t_stats.num_examined;
-        tot.num_examined_filter += t_stats.num_examined_filter;
-        tot.num_candidates += t_stats.num_candidates;
-        tot.num_forwarded += t_stats.num_forwarded;
-        tot.num_entropy += t_stats.num_entropy;
-        tot.num_iter += t_stats.num_iter;
-        tot.device = t_stats.device;
-        tot.lookup_path = t_stats.lookup_path;
-        tot.path_flags |= t_stats.path_flags;
+        stats_add(tot, t_stats);
     });
     size_t cnt[2] = {0, 0};
     for (const Job& jb : jobs)
@@ -251,19 +298,7 @@ size_t sa_seed_calls(const sa_call_desc* calls, size_t num_calls, uint32_t buffe
         results[i].num_hsps = n;
         results[i].num_hits = K > 0 ? t_stats.num_hits : 0;  // (an empty call leaves the thread's statistics of its previous call alone)
         std::lock_guard<std::mutex> lk(mu);
-        tot.num_seeds += t_stats.num_seeds;
-        tot.num_hits += t_stats.num_hits;
-        tot.num_survivors += t_stats.num_survivors;
-        tot.num_anchors += t_stats.num_anchors;
-        tot.num_examined += t_stats.num_examined;
-        tot.num_examined_filter += t_stats.num_examined_filter;
-        tot.num_candidates += t_stats.num_candidates;
-        tot.num_forwarded += t_stats.num_forwarded;
-        tot.num_entropy += t_stats.num_entropy;
-        tot.num_iter += t_stats.num_iter;
-        tot.device = t_stats.device;
-        tot.lookup_path = t_stats.lookup_path;
-        tot.path_flags |= t_stats.path_flags;
+        stats_add(tot, t_stats);
     });
     size_t total = 0;
     for (size_t i = 0; i < num_calls; i++) total += results[i].num_hsps;

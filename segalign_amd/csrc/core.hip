@@ -135,7 +135,7 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                 while (it < segs.size() && nseg < (ca.td ? MAX_SEGS : MAX_SEGS_ABS)) {
                     uint64_t upto = segs[it].hit_hi;
                     if (!ca.td && nseg > 0 && upto - b_hit_lo > HIT_BATCH) break;  // (no hit list in a table-direct call)
-                    ea.seg_end[nseg++] = upto;
+                    sl->h_seg_end[nseg++] = upto;
                     b_seed_hi = std::max(b_seed_hi, segs[it].seed_hi);
                     b_hit_hi = upto;
                     it++;
@@ -144,6 +144,10 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                 hit_lo = b_hit_hi;
                 const uint64_t bh = b_hit_hi - b_hit_lo;
                 if (bh == 0 || (!ca.td && b_seed_hi <= b_seed_lo)) continue;  // iterations without hits produce nothing (H5)
+                // (the segment ends of the batch: a device array the candidate-stage kernels search; the previous batch has been
+                //  synchronised, so the pinned staging copy is free)
+                check_memcpy(hipMemcpyAsync(sl->d_seg_end, sl->h_seg_end, (size_t)nseg * sizeof(uint64_t), hipMemcpyHostToDevice, st), "segment ends");
+                ea.seg_end = sl->d_seg_end;
                 if (ca.td) {
                     ea.td = 1;
                     ea.td_rec = sl->td_rec.p;
@@ -216,15 +220,15 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                 ea.ent_count = &sl->d_cnt->n_ent;
                 ea.long_blocks = (uint32_t)g_long_blocks;
                 ea.max_waves = (uint32_t)(ea.fast_filter == 3 ? g_packed_waves : g_max_waves);
-                ea.ent_blocks = 64;
+                ea.ent_blocks = 1024;  // (grid-stride over a count that lives on the device: a few thousand records usually, millions on repeats)
                 sl->cand_list.ensure((size_t)std::max<uint64_t>(1u << 16, bh / 16), "candidate list");
                 // chain shortcut: valid for the plain X-drop recurrence (xdrop >= 0), needs the 29-bit position field of its
                 // sort key, and is off while E is being counted.  The repeat masker takes it too: its window only decides WHICH
                 // hits are extended (all candidates lie inside it), and its chain starts with an exact-duplicate unique
                 // (rm :819-823), so the duplicates the shortcut never produces would be removed there anyway
-                const bool chain_rel = ca.td && ca.q_hi > ca.q_lo && (uint64_t)ca.q_hi - ca.q_lo + g_seed_size < (1u << 26);  // anchors relative to the call's first position fit the key
+                const bool chain_rel = ca.td && ca.q_hi > ca.q_lo;  // table-direct call: anchors relative to the call's first position
                 const bool chain = g_chain && g_xdrop >= 0 && (chain_rel || (nseg <= MAX_SEGS_ABS && ca.query_len < (1u << 29))) && !g_count_examined;
-                ea.chain_q_bits = chain_rel ? 26u : 29u;
+                ea.chain_q_bits = chain_rel ? 32u : 29u;  // (32: diagonal | relative position, no iteration field -- kernels.h)
                 ea.chain_q_base = chain_rel ? ca.q_lo : 0u;
                 ea.chain_cap = chain ? CHAIN_CAP : 0u;
                 ea.chain_sort_threads = (uint32_t)g_chain_sort_threads;
@@ -316,16 +320,26 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                     spec_done = spec && sl->h_seg_info[seg_words - 1] == 0;
                     if (ea.chain_cap && sl->h_cnt->n_long > ea.chain_cap && sl->h_cnt->n_long <= ea.cand_cap_recs) {
                         spec_done = false;  // (the chain ran on an unfinished survivor list)
-                        path_flags |= SA_PATH_CHAIN_SKIPPED;
-                        // more candidates than the chain buffers hold: the chain kernels left the batch alone (device-side
-                        // test on the same counter); extend every candidate on its own
-                        ExtendArgs eb = ea;
-                        eb.chain_cap = 0;
-                        { ProfScope p(sl, "extend_exact");   launch_extend_exact(eb, st); }
-                        { ProfScope p(sl, "extend_entropy"); launch_extend_entropy(eb, st); }
-                        check_launch("extend (no chain)");
+                        path_flags |= SA_PATH_CHAIN_SLICED;
+                        // more candidates than the chain buffers hold: the chain kernels left the batch alone (device-side test on
+                        // the same counter).  Run the chain stages over the candidate list SLICE BY SLICE: a chain that crosses a
+                        // slice border restarts there (one more extension), nothing else changes -- repeat-rich sequence puts tens of
+                        // millions of candidates into one call, and extending each on its own took 160 ms per call
+                        const uint32_t n_long = sl->h_cnt->n_long;
+                        for (uint32_t first = 0; first < n_long; first += ea.chain_cap) {
+                            ExtendArgs es = ea;
+                            es.cand_sliced = 1;
+                            es.cand_first = first;
+                            check_memcpy(hipMemsetAsync(sl->chain_bucket_cnt.p, 0, chain_num_buckets() * sizeof(uint32_t), st), "chain buckets");
+                            check_memcpy(hipMemsetAsync(&sl->d_cnt->n_heads, 0, sizeof(uint32_t), st), "chain heads");
+                            { ProfScope p(sl, "chain_group"); launch_chain_group(es, st); }
+                            { ProfScope p(sl, "chain_link");  launch_chain_link(es, st); }
+                            { ProfScope p(sl, "extend_exact_chain"); launch_extend_exact_chain(es, st); }
+                        }
+                        { ProfScope p(sl, "extend_entropy"); launch_extend_entropy(ea, st); }
+                        check_launch("extend (sliced chain)");
                         check_memcpy(hipMemcpyAsync(sl->h_cnt, sl->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st), "counters");
-                        check_sync(st, "extend (no chain)");
+                        check_sync(st, "extend (sliced chain)");
                     }
                     const Counters& c = *sl->h_cnt;
                     const bool l2_ok = !(ea.td && ea.td_ctx) || c.n_l2_max <= ea.l2_cap;
@@ -394,6 +408,7 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                 sl->recB.ensure(std::max<size_t>(survivors, sl->recA.cap), "survivors B");
                 size_t tb = sort_temp_bytes(survivors);
                 sl->sort_temp.ensure(tb, "sort temp");
+                sl->unique_temp.ensure(unique_temp_bytes(survivors), "unique temp");
                 HspRec* fin = nullptr;
                 bool done = false;
                 if (!ca.rm && survivors <= dedup_seg_max_total() && segs.size() <= dedup_small_max_segs() && !g_no_small_dedup && !spec_tried) {
@@ -428,7 +443,7 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                     // nothing left to do on the device
                 } else if (!ca.rm) {
                     { ProfScope p(sl, "sort_diag");  launch_sort(sl->recA.p, sl->recB.p, survivors, ORDER_DIAG, sl->sort_temp.p, sl->sort_temp.cap, st); }
-                    { ProfScope p(sl, "unique");     launch_unique(sl->recB.p, sl->recA.p, survivors, 0, &sl->d_cnt->uniq, st); }
+                    { ProfScope p(sl, "unique");     launch_unique(sl->recB.p, sl->recA.p, survivors, 0, &sl->d_cnt->uniq, sl->unique_temp.p, st); }
                     check_launch("sort/unique");
                     check_memcpy(hipMemcpyAsync(sl->h_cnt, sl->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st), "counters");
                     check_sync(st, "unique");
@@ -437,13 +452,13 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                     fin = sl->recB.p;
                 } else {
                     { ProfScope p(sl, "sort_rm_first"); launch_sort(sl->recA.p, sl->recB.p, survivors, ORDER_RM_FIRST, sl->sort_temp.p, sl->sort_temp.cap, st); }
-                    { ProfScope p(sl, "unique");        launch_unique(sl->recB.p, sl->recA.p, survivors, 1, &sl->d_cnt->uniq, st); }
+                    { ProfScope p(sl, "unique");        launch_unique(sl->recB.p, sl->recA.p, survivors, 1, &sl->d_cnt->uniq, sl->unique_temp.p, st); }
                     check_launch("sort/unique");
                     check_memcpy(hipMemcpyAsync(sl->h_cnt, sl->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st), "counters");
                     check_sync(st, "unique");
                     uint32_t n1 = sl->h_cnt->uniq;
                     { ProfScope p(sl, "sort_rm_diag");  launch_sort(sl->recA.p, sl->recB.p, n1, ORDER_RM_DIAG, sl->sort_temp.p, sl->sort_temp.cap, st); }
-                    { ProfScope p(sl, "unique");        launch_unique(sl->recB.p, sl->recA.p, n1, 0, &sl->d_cnt->uniq2, st); }
+                    { ProfScope p(sl, "unique");        launch_unique(sl->recB.p, sl->recA.p, n1, 0, &sl->d_cnt->uniq2, sl->unique_temp.p, st); }
                     check_launch("sort/unique 2");
                     check_memcpy(hipMemcpyAsync(sl->h_cnt, sl->d_cnt, sizeof(Counters), hipMemcpyDeviceToHost, st), "counters");
                     check_sync(st, "unique 2");

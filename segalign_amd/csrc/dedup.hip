@@ -152,6 +152,60 @@ __global__ __launch_bounds__(UNQ_THREADS) void unique_kernel(const HspRec* __res
     if (threadIdx.x == 0) *out_count = carry;
 }
 
+// The same predicate over MANY tiles: a call on repeat-rich sequence leaves millions of survivors (every diagonal of a microsatellite
+// pair is an HSP of its own), and one workgroup walking them took 150 ms per call.  A record's verdict only needs its INPUT
+// predecessor (hazard H3), so tiles are independent: count per tile -> exclusive scan of the tile counts -> write.
+__device__ __forceinline__ uint32_t unique_tile_mask(const HspRec* __restrict__ in, uint32_t n, int exact, uint32_t i0, HspRec (&rec)[UNQ_ITEMS]) {
+    uint32_t keepmask = 0;
+    HspRec prev;
+    prev.ref_start = prev.query_start = prev.len = 0; prev.score = 0; prev.seg = 0xFFFFFFFFu;
+    if (i0 > 0 && i0 < n) prev = in[i0 - 1];
+#pragma unroll
+    for (int j = 0; j < UNQ_ITEMS; j++) {
+        const uint32_t i = i0 + j;
+        if (i < n) {
+            rec[j] = in[i];
+            const bool keep = (i == 0) || (prev.seg != rec[j].seg) || !(exact ? hsp_same(prev, rec[j]) : hsp_contained(prev, rec[j]));
+            keepmask |= keep ? (1u << j) : 0u;
+            prev = rec[j];
+        }
+    }
+    return keepmask;
+}
+__global__ __launch_bounds__(UNQ_THREADS) void unique_tile_count_kernel(const HspRec* __restrict__ in, uint32_t n, int exact, uint32_t* __restrict__ tile_cnt) {
+    __shared__ uint32_t s_tot;
+    if (threadIdx.x == 0) s_tot = 0;
+    __syncthreads();
+    HspRec rec[UNQ_ITEMS];
+    uint32_t mine = (uint32_t)__builtin_popcount(unique_tile_mask(in, n, exact, blockIdx.x * (UNQ_THREADS * UNQ_ITEMS) + threadIdx.x * UNQ_ITEMS, rec));
+    for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_tot, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s_tot;
+}
+__global__ __launch_bounds__(UNQ_THREADS) void unique_tile_write_kernel(const HspRec* __restrict__ in, HspRec* __restrict__ out, uint32_t n, int exact,
+                                                                        const uint32_t* __restrict__ tile_base, uint32_t ntiles, uint32_t* __restrict__ out_count) {
+    __shared__ uint32_t wave_cnt[UNQ_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    HspRec rec[UNQ_ITEMS];
+    const uint32_t keepmask = unique_tile_mask(in, n, exact, blockIdx.x * (UNQ_THREADS * UNQ_ITEMS) + threadIdx.x * UNQ_ITEMS, rec);
+    const uint32_t mine = (uint32_t)__builtin_popcount(keepmask);
+    uint32_t inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) wave_cnt[wave] = inc;
+    __syncthreads();
+    uint32_t off = tile_base[blockIdx.x] + inc - mine;
+    for (int w = 0; w < wave; w++) off += wave_cnt[w];
+#pragma unroll
+    for (int j = 0; j < UNQ_ITEMS; j++)
+        if ((keepmask >> j) & 1u) out[off++] = rec[j];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = tile_base[ntiles];
+}
+
 __global__ __launch_bounds__(256) void strip_kernel(const HspRec* __restrict__ in, uint32_t n, uint4* __restrict__ out,
                                                     uint32_t* __restrict__ out_seg) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -161,7 +215,7 @@ __global__ __launch_bounds__(256) void strip_kernel(const HspRec* __restrict__ i
     }
 }
 
-constexpr int DEDUP_SMALL_SEGS = 64;  // distinct segment ids (reference iterations x chunks of a call) the LDS path handles
+constexpr int DEDUP_SMALL_SEGS = 512;  // distinct segment ids (reference iterations x chunks of a call) the LDS path handles = MAX_SEGS
 
 // ---- the whole chain in LDS, ONE WORKGROUP PER SEGMENT -----------------------------------------------------------------
 // After the chain shortcut a call leaves a few hundred to a few thousand survivors; three library sorts + unique + strip then
@@ -174,7 +228,7 @@ constexpr int DEDUP_SMALL_SEGS = 64;  // distinct segment ids (reference iterati
 // running filter kernel) to ~20 us, and the limit rises from 1024 survivors per call to 2048 per segment.
 constexpr int DEDUP_SEG_THREADS = 1024;
 constexpr int DEDUP_SEG_MAX = 2048;      // records per segment (40 KB of LDS)
-constexpr int DEDUP_SEG_TOTAL = 65536;   // survivors per call (every workgroup scans the whole list once)
+constexpr int DEDUP_SEG_TOTAL = 131072;  // survivors per call (every workgroup scans the whole list once)
 
 // In-place bitonic sort of m <= DEDUP_SEG_MAX records of ONE segment in LDS.  The records' seg field (constant inside a
 // segment) carries the input index while sorting: it is the last key, which makes the keys unique and the result the stable
@@ -241,7 +295,7 @@ __global__ __launch_bounds__(DEDUP_SEG_THREADS) void dedup_seg_kernel(const HspR
     __shared__ uint32_t s_m, s_wave[DEDUP_SEG_THREADS / 64];
     const uint32_t g = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x < DEDUP_SMALL_SEGS) s_cnt[threadIdx.x] = 0;
+    for (uint32_t t = threadIdx.x; t < (uint32_t)DEDUP_SMALL_SEGS; t += blockDim.x) s_cnt[t] = 0;
     if (threadIdx.x == 0) s_m = 0;
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
@@ -254,8 +308,18 @@ __global__ __launch_bounds__(DEDUP_SEG_THREADS) void dedup_seg_kernel(const HspR
         }
     }
     __syncthreads();
-    uint32_t off = 0;
-    for (uint32_t t = 0; t < g; t++) off += s_cnt[t];
+    // offset of the segment's slot range = survivors in lower segments: a workgroup-wide sum of s_cnt[0 .. g)
+    __shared__ uint32_t s_off;
+    if (threadIdx.x == 0) s_off = 0;
+    __syncthreads();
+    {
+        uint32_t part = 0;
+        for (uint32_t t = threadIdx.x; t < g; t += blockDim.x) part += s_cnt[t];
+        for (int d = 32; d > 0; d >>= 1) part += __shfl_down(part, d, 64);
+        if (lane == 0 && part) atomicAdd(&s_off, part);
+    }
+    __syncthreads();
+    const uint32_t off = s_off;
     const uint32_t m = s_m;
     if (m > seg_max) {  // the host falls back to the library sorts
         if (threadIdx.x == 0) { seg_info[2 * DEDUP_SMALL_SEGS] = 1u; seg_info[g] = 0; seg_info[DEDUP_SMALL_SEGS + g] = off; }
@@ -315,8 +379,24 @@ void launch_dedup_seg(const HspRec* in, uint32_t n, const uint32_t* n_dev, uint3
 
 uint32_t dedup_small_max_segs() { return DEDUP_SMALL_SEGS; }
 
-void launch_unique(const HspRec* in, HspRec* out, uint32_t n, int exact, uint32_t* out_count, hipStream_t s) {
-    hipLaunchKernelGGL(unique_kernel, dim3(1), dim3(UNQ_THREADS), 0, s, in, out, n, exact, out_count);
+// tile_tmp: 2 * (tiles + 1) dwords + scan_temp_bytes(tiles) bytes of scratch (unique_temp_bytes); small inputs take the one-workgroup
+// kernel and need none
+size_t unique_temp_bytes(uint32_t n) {
+    const uint32_t tiles = (n + UNQ_THREADS * UNQ_ITEMS - 1) / (UNQ_THREADS * UNQ_ITEMS);
+    return (size_t)2 * (tiles + 1) * sizeof(uint32_t) + scan_temp_bytes(tiles) + 64;
+}
+void launch_unique(const HspRec* in, HspRec* out, uint32_t n, int exact, uint32_t* out_count, void* tile_tmp, hipStream_t s) {
+    const uint32_t tiles = (n + UNQ_THREADS * UNQ_ITEMS - 1) / (UNQ_THREADS * UNQ_ITEMS);
+    if (tiles <= 4 || !tile_tmp) {
+        hipLaunchKernelGGL(unique_kernel, dim3(1), dim3(UNQ_THREADS), 0, s, in, out, n, exact, out_count);
+        return;
+    }
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(tile_tmp);
+    uint32_t* base = cnt + (tiles + 1);
+    void* scan_tmp = reinterpret_cast<void*>(((uintptr_t)(base + (tiles + 1)) + 63) & ~(uintptr_t)63);
+    hipLaunchKernelGGL(unique_tile_count_kernel, dim3(tiles), dim3(UNQ_THREADS), 0, s, in, n, exact, cnt);
+    launch_exclusive_scan_u32(cnt, base, tiles, scan_tmp, s);
+    hipLaunchKernelGGL(unique_tile_write_kernel, dim3(tiles), dim3(UNQ_THREADS), 0, s, in, out, n, exact, base, tiles, out_count);
 }
 void launch_strip(const HspRec* in, uint32_t n, void* out_segment_pairs, uint32_t* out_seg, hipStream_t s) {
     if (n == 0) return;

@@ -210,10 +210,11 @@ int prof_id(const char* name);
 // ------------------------------------------------------------------------------------------------------------------
 // per-device state
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int MAX_SLOTS_PER_DEVICE = 4;
+constexpr int MAX_SLOTS_PER_DEVICE = 8;
 extern uint32_t SPEC_RECS;        // records of the speculative output copy (256 KB); option spec_recs (tests)
 extern uint32_t g_dedup_seg_max;  // option dedup_seg_max: records per segment the LDS chain accepts (0 = its LDS capacity; tests)
-constexpr int SA_MAX_CHUNKS = 32;  // chunks one multi-chunk call may carry: 2 reference iterations each = MAX_SEGS segments
+constexpr int SA_MAX_CHUNKS = 256;  // chunks one multi-chunk call may carry: 2 reference iterations each = MAX_SEGS segments
+constexpr int SA_MAX_CHUNKS_GENERAL = 32;  // ... when it takes the general path (per-chunk iteration plans of up to 1000 iterations each)
 constexpr int SA_DEFAULT_CHUNKS = 20;  // ... and what the interval entries hand to one call: the 40 chunks of a 10 Mbp strand go as 20 + 20
 extern int SLOTS_PER_DEVICE;  // calls in flight per device (the reference allows one: token == device); option slots
 
@@ -242,7 +243,7 @@ struct Slot {
     DevBuf<uint64_t> seeds;
     DevBuf<uint32_t> start, count, flags, flag_prefix;
     DevBuf<uint64_t> prefix;
-    DevBuf<uint8_t> scan_temp, sort_temp;
+    DevBuf<uint8_t> scan_temp, sort_temp, unique_temp;
     DevBuf<Hit> hits;
     DevBuf<HspRec> recA, recB;
     DevBuf<CandRec> cand_list;
@@ -267,7 +268,9 @@ struct Slot {
     void* d_td_bounds = nullptr;
     TdPlan* d_td_plan = nullptr;
     TdPlan* h_td_plan = nullptr;      // pinned
-    IterPlan* d_plan = nullptr;       // SA_MAX_CHUNKS plans (one per chunk of a multi-chunk call)
+    IterPlan* d_plan = nullptr;       // SA_MAX_CHUNKS_GENERAL plans (one per chunk of a multi-chunk call on the general path)
+    uint64_t* d_seg_end = nullptr;    // segment ends of the running batch (ExtendArgs.seg_end)
+    uint64_t* h_seg_end = nullptr;    // pinned
     Counters* d_cnt = nullptr;
     uint32_t* d_verify = nullptr;     // drop-in calls: "the host seed vector is what the device seeder would emit" (seeds.hip)
     uint32_t* h_verify = nullptr;     // pinned
@@ -406,6 +409,7 @@ extern int g_fast_filter;
 extern int g_packed_filter;
 extern int g_chain_sort_threads;
 extern int g_chunks_per_call;
+extern int64_t g_call_hits;
 extern int g_no_small_dedup;
 extern int g_ctx;
 extern uint32_t g_audit_cap;

@@ -109,13 +109,16 @@ __device__ __forceinline__ void chunk8_exact(const int* __restrict__ s_tab, uint
     }
 }
 
+// segment (reference iteration) of a hit: the first s with g < seg_end[s] -- a binary search over the batch's <= MAX_SEGS ascending
+// ends (a 4 KB device array every lane of the candidate-stage kernels reads: it lives in the L1 / L2)
 __device__ __forceinline__ uint32_t seg_of(const ExtendArgs& a, uint64_t local_idx) {
-    uint32_t seg = 0;
     const uint64_t g = a.hit_base + local_idx;
-#pragma unroll
-    for (int s = 0; s < MAX_SEGS - 1; s++)
-        if (s < a.num_segs - 1 && g >= a.seg_end[s]) seg = s + 1;
-    return a.seg_base + seg;
+    uint32_t lo = 0, hi = (uint32_t)a.num_segs - 1u;  // answer in [lo, hi]; a hit beyond the last end belongs to the last segment
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (g >= a.seg_end[mid]) lo = mid + 1; else hi = mid;
+    }
+    return a.seg_base + lo;
 }
 
 // What to do with a finished hit: 0 = reject, 1 = survivor with entropy 1, 2 = needs the entropy factor (:608,:633)
@@ -1288,7 +1291,7 @@ constexpr uint32_t CHAIN_WALK_EXTRA = 96; // bases walked past the predecessor's
 // (iteration, diagonal, position).  A bucket holds a handful of diagonals with a few hundred candidates each, so the
 // quadratic rank sort is a few microseconds; all buckets together are the candidate list with every diagonal's
 // candidates contiguous and ordered by position -- exactly what the link test needs.  No host involvement.
-constexpr uint32_t CHAIN_BUCKETS = 16384;  // (a 16-chunk call at human-scale hit density carries ~1.5 M candidates)
+constexpr uint32_t CHAIN_BUCKETS = 65536;  // (a sparse-hit call of 160 chunks carries ~5 M candidates, a 20-chunk call at human-scale hit density ~1.5 M)
 constexpr uint32_t CHAIN_SORT_MAX = 1024;  // entries a bucket may hold and still be sorted (8 KB of LDS); larger: left unsorted,
                                            // which only makes link tests fail, i.e. costs extensions, never correctness
 
@@ -1304,24 +1307,41 @@ __device__ __forceinline__ unsigned long long chain_key(const ExtendArgs& a, con
     // iteration | diagonal (32) | query position (q bits): 3 | 32 | 29 with absolute positions (general path, <= 8 iterations per
     // batch), 6 | 32 | 26 with positions relative to the call's first one (table-direct calls: <= 64 iterations, <= 8 M positions)
     const uint32_t qb = a.chain_q_bits;
+    if (qb == 32u) return ((unsigned long long)(uint32_t)(c.ref_loc - c.query_loc) << 32) | (unsigned long long)(c.query_loc - a.chain_q_base);
     return ((unsigned long long)(seg_of(a, c.hidx) - a.seg_base) << (32u + qb)) |
            ((unsigned long long)(uint32_t)(c.ref_loc - c.query_loc) << qb) |
            (unsigned long long)((c.query_loc - a.chain_q_base) & ((1u << qb) - 1u));
 }
 
+// The candidates the chain stages of this launch work on: all of the batch when they fit the chain buffers; a slice of the list when
+// the host runs an oversized batch slice by slice; nothing (false) for an oversized batch that is not sliced yet -- the counts live
+// on the device, so the first attempt finds out here and the host follows up after its sync.
+__device__ __forceinline__ bool chain_range(const ExtendArgs& a, uint32_t& first, uint32_t& n) {
+    const uint32_t total = min(*a.cand_count, a.cand_cap_recs);
+    if (a.cand_sliced) {
+        first = a.cand_first;
+        n = total > first ? min(total - first, a.chain_cap) : 0u;
+        return n > 0;
+    }
+    first = 0;
+    n = total;
+    return total <= a.chain_cap;
+}
+
 __global__ __launch_bounds__(256) void chain_count_kernel(ExtendArgs a) {
-    const uint32_t n = min(*a.cand_count, a.cand_cap_recs);
-    if (n > a.chain_cap) return;
+    uint32_t first, n;
+    if (!chain_range(a, first, n)) return;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const CandRec c = a.cand_list[i];
+        const CandRec c = a.cand_list[first + i];
         atomicAdd(&a.chain_bucket_cnt[chain_bucket_of(seg_of(a, c.hidx), c)], 1u);
     }
 }
 
 // one block: exclusive scan of the CHAIN_BUCKETS counters into chain_bucket_start[0..CHAIN_BUCKETS]; counters become cursors
-__global__ __launch_bounds__(256) void chain_scan_kernel(ExtendArgs a) {
-    __shared__ uint32_t s_part[256];
-    constexpr uint32_t PER = CHAIN_BUCKETS / 256;
+constexpr uint32_t CHAIN_SCAN_THREADS = 1024;
+__global__ __launch_bounds__(CHAIN_SCAN_THREADS) void chain_scan_kernel(ExtendArgs a) {
+    __shared__ uint32_t s_part[CHAIN_SCAN_THREADS];
+    constexpr uint32_t PER = CHAIN_BUCKETS / CHAIN_SCAN_THREADS;
     uint32_t v[PER], sum = 0;
 #pragma unroll
     for (uint32_t j = 0; j < PER; j++) { v[j] = a.chain_bucket_cnt[threadIdx.x * PER + j]; sum += v[j]; }
@@ -1335,14 +1355,14 @@ __global__ __launch_bounds__(256) void chain_scan_kernel(ExtendArgs a) {
         a.chain_bucket_cnt[threadIdx.x * PER + j] = 0;  // reused as the scatter cursor
         base += v[j];
     }
-    if (threadIdx.x == 255) a.chain_bucket_start[CHAIN_BUCKETS] = base;
+    if (threadIdx.x == CHAIN_SCAN_THREADS - 1) a.chain_bucket_start[CHAIN_BUCKETS] = base;
 }
 
 __global__ __launch_bounds__(256) void chain_scatter_kernel(ExtendArgs a) {
-    const uint32_t n = min(*a.cand_count, a.cand_cap_recs);
-    if (n > a.chain_cap) return;
+    uint32_t first, n;
+    if (!chain_range(a, first, n)) return;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const CandRec c = a.cand_list[i];
+        const CandRec c = a.cand_list[first + i];
         const uint32_t b = chain_bucket_of(seg_of(a, c.hidx), c);
         a.chain_tmp[a.chain_bucket_start[b] + atomicAdd(&a.chain_bucket_cnt[b], 1u)] = c;
     }
@@ -1355,8 +1375,8 @@ constexpr uint32_t CHAIN_SORT_GROUP = 8;
 __global__ __launch_bounds__(512) void chain_bucket_sort_kernel(ExtendArgs a) {
     __shared__ unsigned long long s_key[CHAIN_SORT_GROUP * CHAIN_SORT_MAX / 2];  // 32 KB: the group's entries, when they fit
     __shared__ uint32_t s_b[CHAIN_SORT_GROUP + 1];
-    const uint32_t n = min(*a.cand_count, a.cand_cap_recs);
-    if (n > a.chain_cap) return;
+    uint32_t first, n;
+    if (!chain_range(a, first, n)) return;
     if (threadIdx.x <= CHAIN_SORT_GROUP) s_b[threadIdx.x] = a.chain_bucket_start[blockIdx.x * CHAIN_SORT_GROUP + threadIdx.x];
     __syncthreads();
     const uint32_t g0 = s_b[0], m_all = s_b[CHAIN_SORT_GROUP] - g0;
@@ -1392,8 +1412,8 @@ __global__ __launch_bounds__(256) void chain_link_kernel(ExtendArgs a) {
     __shared__ int s_tab[128];
     if (threadIdx.x < 128) s_tab[threadIdx.x] = threadIdx.x < 64 ? a.sub_mat[threadIdx.x] : NEG;
     __syncthreads();
-    const uint32_t n = min(*a.cand_count, a.cand_cap_recs);
-    if (n > a.chain_cap) return;
+    uint32_t first, n;
+    if (!chain_range(a, first, n)) return;
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     const uint8_t* __restrict__ R8b = a.ref8 - BIAS;
@@ -1448,7 +1468,8 @@ template <bool XDROP_NONNEG>
 __global__ __launch_bounds__(EXT_THREADS) void extend_exact_chain_kernel(ExtendArgs a) {
     constexpr bool COUNT_EXAMINED = false;
     EXACT_KERNEL_PROLOGUE()
-    if (n_cand > a.chain_cap) return;  // overflow: extend_exact_kernel handles the batch
+    uint32_t first_cand, n_chain;
+    if (!chain_range(a, first_cand, n_chain)) return;  // oversized batch: the host reruns the chain stages slice by slice
     const uint32_t n_heads = *a.chain_head_count;
     for (uint32_t j = blockIdx.x * (EXT_THREADS / 64) + (threadIdx.x >> 6); j < n_heads; j += G) {
         uint32_t cur = (uint32_t)rfl((int)a.chain_heads[j]);
@@ -1462,10 +1483,10 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_exact_chain_kernel(ExtendA
             // members of the run follow in the sorted list until the next run head
             const int64_t right_end = (int64_t)ref_loc + (int64_t)bposR;  // E_R(head) as a target position
             uint32_t nxt = 0xFFFFFFFFu;
-            for (uint32_t m0 = cur + 1; m0 < n_cand; m0 += 64) {
+            for (uint32_t m0 = cur + 1; m0 < n_chain; m0 += 64) {
                 const uint32_t m = m0 + (uint32_t)lane;
                 bool stop_run = false, beyond = false;
-                if (m < n_cand) {
+                if (m < n_chain) {
                     stop_run = a.chain_is_head[m] != 0u;  // (also set wherever the iteration or the diagonal changes)
                     beyond = (int64_t)a.chain_sorted[m].ref_loc > right_end;  // (R) does not cover it
                 } else {
@@ -1569,15 +1590,15 @@ void launch_extend_filter_cls(const ExtendArgs& a, hipStream_t s) {
 
 void launch_chain_group(const ExtendArgs& a, hipStream_t s) {  // chain_bucket_cnt must be zero on entry
     if (a.num_hits == 0 || !a.chain_cap) return;
-    hipLaunchKernelGGL(chain_count_kernel, dim3(256), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(chain_scan_kernel, dim3(1), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(chain_scatter_kernel, dim3(256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(chain_count_kernel, dim3(1024), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(chain_scan_kernel, dim3(1), dim3(CHAIN_SCAN_THREADS), 0, s, a);
+    hipLaunchKernelGGL(chain_scatter_kernel, dim3(1024), dim3(256), 0, s, a);
     hipLaunchKernelGGL(chain_bucket_sort_kernel, dim3(CHAIN_BUCKETS / CHAIN_SORT_GROUP), dim3(a.chain_sort_threads ? a.chain_sort_threads : 256), 0, s, a);
 }
 uint32_t chain_num_buckets() { return CHAIN_BUCKETS; }
 void launch_chain_link(const ExtendArgs& a, hipStream_t s) {
     if (a.num_hits == 0 || !a.chain_cap) return;
-    hipLaunchKernelGGL((chain_link_kernel<true>), dim3(256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((chain_link_kernel<true>), dim3(1024), dim3(256), 0, s, a);
 }
 void launch_extend_exact_chain(const ExtendArgs& a, hipStream_t s) {
     if (a.num_hits == 0 || !a.chain_cap) return;

@@ -234,9 +234,18 @@ uint32_t td_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, int K, const uint
     sl->td_rec.ensure((size_t)n + 1, "probe records");
     sl->td_chunk.ensure(TD_CHUNK_CAP, "probe chunk starts");
     sl->td_partial.ensure(probe_partial_bytes(n), "probe partials");
+    // the chunks of a call tile [start, end) with wga_chunk-sized pieces (the last may be short or empty): the probe finds the
+    // boundaries arithmetically.  Every caller builds its bounds that way; anything else is a programming error
     TdBounds tb;
     tb.nb = K + 1;
-    for (int c = 0; c <= K; c++) tb.pos[c] = bpos[c];
+    tb.start = start;
+    tb.end = end;
+    tb.chunk = K > 1 ? g_wga_chunk : std::max(n, 1u);
+    for (int c = 0; c <= K; c++)
+        if (bpos[c] != (uint32_t)std::min<uint64_t>((uint64_t)start + (uint64_t)c * tb.chunk, end) || K + 1 > TD_MAX_BOUNDS || tb.chunk == 0) {
+            fprintf(stderr, "Error: table-direct call with chunk bounds off the wga_chunk grid (chunk %d of %d)\n", c, K);
+            exit(15);
+        }
     {
         ProfScope p(sl, "seed_probe");
         launch_probe_lookup(qcodes, start, n, sh, dc->nbr_start, dc->nkeys, sl->td_toff.p, sl->td_tcnt.p, sl->td_partial.p, st);

@@ -13,7 +13,7 @@ namespace sa {
 constexpr int SEQ_PAD = 64;
 
 constexpr int MAX_CARE = 16;  // seed weight limit; reference asserts 3 < kmer_size <= 15 (seed_pos_table.cu:51-52)
-constexpr int MAX_SEGS = 64;  // reference iterations handled by one extension batch (32 chunks x 2 iterations of a table-direct call)
+constexpr int MAX_SEGS = 512;  // reference iterations handled by one extension batch (256 chunks x 2 iterations of a table-direct call)
 constexpr int MAX_SEGS_ABS = 8;  // ... of a batch whose chain sort key carries absolute query positions (general path)
 
 struct SeedShape {            // device copy of the state GenerateShapePos keeps (ntcoding.cpp:6-8)
@@ -120,6 +120,8 @@ struct ExtendArgs {
     uint32_t ent_cap_recs;
     // chain shortcut of the exact stage (extend.hip 2b); chain_cap == 0 disables it
     uint32_t chain_cap;                      // candidates per batch the chain buffers hold
+    uint32_t cand_sliced, cand_first;        // cand_sliced: the chain stages work on candidates [cand_first, cand_first + chain_cap) of the list
+                                             // (a batch with more candidates than the chain buffers hold is run slice by slice)
     uint32_t* chain_bucket_cnt;              // [buckets] counters, then scatter cursors (zero on entry)
     uint32_t* chain_bucket_start;            // [buckets + 1]
     CandRec* chain_tmp;                      // [chain_cap] candidates dealt into buckets
@@ -161,7 +163,9 @@ struct ExtendArgs {
     uint32_t* l2_max;           // -> largest sub-list count (> l2_cap: records were dropped, the host regrows and reruns)
     int src_cand;               // packed filter reads its anchors from l2_list / *l2_count instead of `hits`
     uint32_t ctx_waves;         // wave budget of the context filter (0: one chunk of TD_CHUNK_HITS hits per wave)
-    uint32_t chain_q_bits;      // chain sort key = iteration | diagonal (32) | query position (chain_q_bits) relative to chain_q_base
+    uint32_t chain_q_bits;      // chain sort key = iteration | diagonal (32) | query position (chain_q_bits) relative to chain_q_base;
+                                // 32: no iteration field -- diagonal (32) | relative position (32): table-direct calls, where the hits of a
+                                // diagonal are in iteration order anyway (the link test compares the iterations itself)
     uint32_t chain_q_base;
     uint32_t ctx_threads;       // workgroup size of the context filter (0: its default)
     uint32_t l2_blocks;         // grid of the second level (its hit count is known on the device only)
@@ -169,7 +173,7 @@ struct ExtendArgs {
     uint64_t num_hits;
     uint64_t hit_base;        // global index of hits[0] inside the call (segment boundaries are global)
     int num_segs;
-    uint64_t seg_end[MAX_SEGS]; // exclusive global hit index where segment s ends
+    const uint64_t* seg_end;  // [num_segs] device array: exclusive global hit index where segment s ends (ascending)
     uint32_t seg_base;        // segment id of the first segment of this batch
     HspRec* out;              // survivors, appended
     uint32_t out_cap;         // capacity of out[]; the counter keeps counting past it, writes are dropped
@@ -267,7 +271,8 @@ size_t sort_temp_bytes(size_t n);
 void launch_sort(const HspRec* in, HspRec* out, size_t n, SortOrder order, void* temp, size_t temp_bytes, hipStream_t s);
 // adjacent-pair unique (thrust::unique_copy on device, hazard H3) within each segment; order preserving.
 // exact = 0: hspEqual of seed_filter.cu:47-52 ; exact = 1: field equality (repeat masker :80-85)
-void launch_unique(const HspRec* in, HspRec* out, uint32_t n, int exact, uint32_t* out_count, hipStream_t s);
+size_t unique_temp_bytes(uint32_t n);
+void launch_unique(const HspRec* in, HspRec* out, uint32_t n, int exact, uint32_t* out_count, void* tile_tmp, hipStream_t s);
 void launch_strip(const HspRec* in, uint32_t n, void* out_segment_pairs, uint32_t* out_seg /*nullable*/, hipStream_t s);
 uint32_t dedup_small_max_segs();
 // sort(diag) -> unique -> sort(lastz) -> 16-byte records in LDS, one workgroup per segment id (< dedup_small_max_segs());

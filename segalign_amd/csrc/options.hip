@@ -39,13 +39,14 @@ int g_max_waves = 4096;    // SEGALIGN_AMD_MAX_WAVES: waves of the filter kernel
 int g_fast_filter = 0;     // derived in InitializeProcessor: xdrop >= 0 && 7*max(M) <= xdrop
 int g_packed_filter = 0;   // derived in InitializeProcessor: the packed upper-bound filter may be used
 int g_chain_sort_threads = 256;  // SEGALIGN_AMD_CHAIN_SORT_THREADS
+int64_t g_call_hits = 256ll << 20;  // option call_hits: seed hits a call is sized for when the resident target's hits are sparse (0: chunks_per_call only)
 int g_chunks_per_call = SA_DEFAULT_CHUNKS;  // SEGALIGN_AMD_CHUNKS_PER_CALL: chunks sa_seed_interval hands to one multi-chunk call
 int g_no_small_dedup = 0;  // SEGALIGN_AMD_NO_SMALL_DEDUP=1: always use the library sorts
 int g_ctx = 1;             // neighbourhood table with target context when it fits (SEGALIGN_AMD_NO_CTX=1: positions only)
 uint32_t g_audit_cap = 0;  // SEGALIGN_AMD_AUDIT_CAP (tests): record up to this many hits the filter levels reject per call
 int g_td = 1;              // table-direct lookup (neighbourhood table + position probe, probe.hip); SEGALIGN_AMD_NO_TD=1 turns it off
 int g_chain = 1;           // chain shortcut of the exact stage (SEGALIGN_AMD_NO_CHAIN=1 turns it off)
-uint32_t CHAIN_CAP = 1u << 22;  // candidates per batch the chain buffers hold (SEGALIGN_AMD_CHAIN_CAP); larger batches fall back
+uint32_t CHAIN_CAP = 1u << 23;  // candidates per batch the chain buffers hold (SEGALIGN_AMD_CHAIN_CAP); larger batches fall back
 SeedShape g_shape = {0, 0, 0, {0}};
 uint32_t g_query_len[SA_BUFFER_DEPTH] = {0, 0};
 
@@ -104,6 +105,7 @@ static Option g_opts[] = {
     // deployment
     {"slots", 4, 1, MAX_SLOTS_PER_DEVICE, 0},          // calls in flight per device (the reference allows one: token == device)
     {"chunks_per_call", SA_DEFAULT_CHUNKS, 1, SA_MAX_CHUNKS, 0},  // chunks sa_seed_interval / sa_rm_mask_interval hand to one pass
+    {"call_hits", 256 << 20, 0, 1ll << 31, 0},        // seed hits a call is sized for when hits are sparse: chunks per call = max(chunks_per_call, call_hits / hits per chunk)
     {"no_ctx", 0, 0, 1, 0},                            // 1: neighbourhood table without target context (lookup mode 1)
     {"no_td", 0, 0, 1, 0},                             // 1: no neighbourhood table at all (lookup mode 0, the reference-shaped path)
     {"no_chain", 0, 0, 1, 0},                          // 1: every candidate is extended on its own (no chain shortcut)
@@ -120,7 +122,7 @@ static Option g_opts[] = {
     // test-only: small capacities that force the overflow / fallback branches
     {"l2_cap", 0, 0, 1 << 30, 1}, {"spec_dedup", 1, 0, 1, 1}, {"spec_recs", 16384, 1, 16384, 1}, {"dedup_seg_max", 0, 0, 1 << 30, 1},
     {"q2_limit_mb", 4096, 1, 4096, 1},                 // (tests) bytes the 16 two-bit copies of a query strand may span before calls leave the table-direct path
-    {"no_small_dedup", 0, 0, 1, 1}, {"chain_cap", 1 << 22, 1, 1 << 30, 1}, {"audit_cap", 0, 0, 1 << 28, 1},
+    {"no_small_dedup", 0, 0, 1, 1}, {"chain_cap", 1 << 23, 1, 1 << 30, 1}, {"audit_cap", 0, 0, 1 << 28, 1},
 };
 static Option* find_option(const char* name) {
     for (auto& o : g_opts)
@@ -148,6 +150,7 @@ void resolve_options() {
     }
     SLOTS_PER_DEVICE = (int)opt_value("slots");
     g_chunks_per_call = (int)opt_value("chunks_per_call");
+    g_call_hits = opt_value("call_hits");
     g_ctx = opt_value("no_ctx") ? 0 : 1;
     g_td = opt_value("no_td") ? 0 : 1;
     g_chain = opt_value("no_chain") ? 0 : 1;

@@ -30,7 +30,8 @@ void slot_init(Slot& s, DevCtx* dc) {
     s.dev = dc->dev;
     s.ctx = dc;
     hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
-    s.d_plan = (IterPlan*)dev_malloc(sizeof(IterPlan) * SA_MAX_CHUNKS, "plan");
+    s.d_plan = (IterPlan*)dev_malloc(sizeof(IterPlan) * SA_MAX_CHUNKS_GENERAL, "plan");
+    s.d_seg_end = (uint64_t*)dev_malloc(sizeof(uint64_t) * MAX_SEGS, "segment ends");
     s.d_cnt = (Counters*)dev_malloc(sizeof(Counters), "counters");
     s.d_verify = (uint32_t*)dev_malloc(sizeof(uint32_t), "seed verify flag");
     s.d_cov_range = (uint32_t*)dev_malloc(2 * sizeof(uint32_t), "coverage range");
@@ -39,7 +40,8 @@ void slot_init(Slot& s, DevCtx* dc) {
     s.d_td_plan = (TdPlan*)dev_malloc(sizeof(TdPlan) * SA_MAX_CHUNKS, "probe plan");
     if (hipHostMalloc((void**)&s.h_cov, 8 * sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc((void**)&s.h_bounds, (SA_MAX_CHUNKS + 2) * sizeof(uint32_t)) != hipSuccess ||
-        hipHostMalloc((void**)&s.h_plan, sizeof(IterPlan) * SA_MAX_CHUNKS) != hipSuccess ||
+        hipHostMalloc((void**)&s.h_plan, sizeof(IterPlan) * SA_MAX_CHUNKS_GENERAL) != hipSuccess ||
+        hipHostMalloc((void**)&s.h_seg_end, sizeof(uint64_t) * MAX_SEGS) != hipSuccess ||
         hipHostMalloc((void**)&s.h_td_plan, sizeof(TdPlan) * SA_MAX_CHUNKS) != hipSuccess ||
         hipHostMalloc((void**)&s.h_seg_info, dedup_seg_info_words() * sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc((void**)&s.h_verify, sizeof(uint32_t)) != hipSuccess ||
@@ -51,7 +53,7 @@ void slot_init(Slot& s, DevCtx* dc) {
 void slot_destroy(Slot& s) {
     s.seeds.release("seeds"); s.start.release("start"); s.count.release("count"); s.flags.release("flags");
     s.flag_prefix.release("flag_prefix"); s.prefix.release("prefix"); s.scan_temp.release("scan_temp");
-    s.sort_temp.release("sort_temp"); s.hits.release("hits"); s.recA.release("recA"); s.recB.release("recB");
+    s.sort_temp.release("sort_temp"); s.unique_temp.release("unique_temp"); s.hits.release("hits"); s.recA.release("recA"); s.recB.release("recB");
     s.out16.release("out16");
     s.cand_list.release("candidate list");
     s.l2_list.release("second-level list");
@@ -68,7 +70,10 @@ void slot_destroy(Slot& s) {
     s.h_seg_info = nullptr;
     if (s.h_td_plan) hipHostFree(s.h_td_plan);
     s.h_td_plan = nullptr;
-    dev_free(s.d_plan, "plan"); dev_free(s.d_cnt, "counters"); dev_free(s.d_cov_range, "coverage range");
+    dev_free(s.d_plan, "plan"); dev_free(s.d_seg_end, "segment ends"); dev_free(s.d_cnt, "counters");
+    s.d_seg_end = nullptr;
+    if (s.h_seg_end) hipHostFree(s.h_seg_end);
+    s.h_seg_end = nullptr; dev_free(s.d_cov_range, "coverage range");
     dev_free(s.d_verify, "seed verify flag");
     if (s.h_verify) hipHostFree(s.h_verify);
     s.d_plan = nullptr; s.d_cnt = nullptr; s.d_cov_range = nullptr; s.d_verify = nullptr; s.h_verify = nullptr;

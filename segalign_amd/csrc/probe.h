@@ -7,11 +7,11 @@
 
 namespace sa {
 
-constexpr int TD_MAX_BOUNDS = 36; // chunk boundaries of one call: SA_MAX_CHUNKS + 1 <= 36
+constexpr int TD_MAX_BOUNDS = 260; // chunk boundaries of one call: SA_MAX_CHUNKS + 1 <= 260
 
-struct TdBounds {                 // query positions of the chunk boundaries of a call, ascending; pos[0] = start, pos[nb-1] = end
-    int nb;
-    uint32_t pos[TD_MAX_BOUNDS];
+struct TdBounds {                 // chunk boundaries of a call: boundary c (c < nb) is query position min(start + c * chunk, end) -- the
+    int nb;                       // chunks of a call tile [start, end) with wga_chunk-sized pieces, the last one may be short or empty
+    uint32_t start, end, chunk;
 };
 
 struct TdPlan {                   // per chunk, written by probe_plan_kernel

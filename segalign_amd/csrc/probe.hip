@@ -312,13 +312,20 @@ __global__ __launch_bounds__(PR_THREADS) void probe_compact_kernel(uint32_t star
     }
     Tri tot;
     Tri run = tri_add(block_excl_scan(mine, tot), partial[blockIdx.x]);
+    // the first chunk boundary at or behind this thread's first position (boundaries sit at multiples of the chunk size: at most one
+    // falls into the thread's PR_ITEMS consecutive positions, PR_ITEMS <= chunk)
+    const uint32_t i_first = i0 + ((int32_t)i0 < 0 ? skew : 0u);  // (the first thread of the grid starts below position 0)
+    uint32_t cb = (i_first + bpos.chunk - 1u) / bpos.chunk;
+    uint32_t ib = cb * bpos.chunk;
 #pragma unroll
     for (int j = 0; j < PR_ITEMS; j++) {
         const uint32_t i = i0 + j;
         if (i >= n) continue;
-#pragma unroll
-        for (int c = 0; c < TD_MAX_BOUNDS; c++)
-            if (c < bpos.nb && bpos.pos[c] - start == i) bounds[c] = run;
+        if (i == ib) {
+            if (cb < (uint32_t)bpos.nb) bounds[cb] = run;
+            cb++;
+            ib += bpos.chunk;  // (a chunk size below PR_ITEMS puts several boundaries into one thread)
+        }
         if (cnt[j]) {
             TdRec r;
             r.prefix = (uint32_t)run.hits;  // (a call with >= 2^32 hits is sent down the general path, engine.hip td_front)
@@ -344,7 +351,7 @@ __global__ __launch_bounds__(PR_THREADS) void probe_compact_kernel(uint32_t star
         r.off = 0;
         c_rec[t.ne] = r;
         for (int c = 0; c < bpos.nb; c++)
-            if (bpos.pos[c] - start >= n) bounds[c] = t;
+            if ((uint64_t)c * bpos.chunk >= n) bounds[c] = t;  // (boundaries at or beyond the end of the call take the total)
     }
 }
 
@@ -422,7 +429,7 @@ void launch_probe_compact(uint32_t start, uint32_t n, const uint64_t* t_off, con
 }
 void launch_probe_plan(const uint8_t* query, SeedShape sh, uint32_t tmask, const uint32_t* bucket_start, const void* bounds_buf, int nchunks,
                        const TdRec* c_rec, TdPlan* plan, hipStream_t s) {
-    hipLaunchKernelGGL(probe_plan_kernel, dim3(1), dim3(64), 0, s, query, sh, tmask, bucket_start, reinterpret_cast<const Tri*>(bounds_buf),
+    hipLaunchKernelGGL(probe_plan_kernel, dim3(1), dim3((nchunks + 63) / 64 * 64), 0, s, query, sh, tmask, bucket_start, reinterpret_cast<const Tri*>(bounds_buf),
                        nchunks, c_rec, plan);
 }
 

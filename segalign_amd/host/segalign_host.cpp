@@ -155,7 +155,7 @@ static void seed_interval(size_t q_block_start, uint32_t q_len /* block_len - se
         if (!cfg.host_seeding) {
             // device seeding: up to sa_max_chunks_per_call() consecutive chunks share one pass over the kernels; every
             // chunk still gets its own return vector, identical to one call per chunk
-            const int kmax = sa_max_chunks_per_call();
+            const int kmax = sa_get_chunks_per_call();  // (chunks_per_call, or more when the resident target's seed hits are sparse)
             std::vector<sa_segment_pair*> res((size_t)kmax, nullptr);
             std::vector<size_t> n((size_t)kmax, 0);
             for (uint64_t i = a; i < b; i += (uint64_t)cfg.wga_chunk * kmax) {

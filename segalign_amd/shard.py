@@ -24,24 +24,45 @@ def shard(items, rank, world):
     return list(items[rank::world])
 
 
+def strand_chunks(intervals, q_block_len, chunk, rev):
+    """Every wga_chunk piece of one strand of a query block, ascending in that strand's coordinates: (interval index, a, b).  The
+    minus strand walks the intervals in reverse (src/seeder.cpp:33-34,89-91)."""
+    out = []
+    order = range(len(intervals) - 1, -1, -1) if rev else range(len(intervals))
+    for idx in order:
+        s, e = intervals[idx]
+        a, b = (q_block_len - e, q_block_len - s) if rev else (s, e)
+        out.extend((idx, c, min(c + chunk, b)) for c in range(a, b, chunk))
+    return out
+
+
 def call_jobs(intervals, q_block_len, chunk, chunks_per_call=16):
-    """The SeedAndFilter CALLS of one pass over a query block, as the engine's interval entry (sa_seed_interval) issues them:
-    per interval and strand the wga_chunk pieces (src/seeder.cpp:48-51, :89-91 in reverse-complement coordinates) are grouped
-    into equal calls of at most `chunks_per_call` chunks (40 chunks go as 14 + 14 + 12).  One dict per call: interval index,
-    strand, [a, b) in that strand's coordinates, chunks.  Every call is independent (own iteration plans, own dedup scopes, its
-    output position is fixed by the host loop), so ANY assignment of calls to GPUs gives identical bytes."""
+    """The SeedAndFilter CALLS of one pass over a query block: per strand the wga_chunk pieces of all intervals (src/seeder.cpp:48-51,
+    :89-91 in reverse-complement coordinates) are grouped into calls of at most `chunks_per_call` consecutive chunks -- equal groups
+    (40 chunks with a limit of 16 go as 14 + 14 + 12).  A call is a range [a, b) that the engine cuts into chunks from `a` on, so a
+    group only continues over pieces that touch and are full-sized except the last: groups run across interval borders where the
+    chunk grid does (10 Mbp intervals hold 40 chunks exactly) and end at a short last chunk (the tail interval, which comes FIRST on
+    the minus strand).  One dict per call: first interval, strand, [a, b) in that strand's coordinates, chunks.  Every call is
+    independent (own iteration plans, own dedup scopes; a chunk's output belongs to the interval it lies in, whatever call carried
+    it), so ANY assignment of calls to GPUs gives identical bytes."""
     jobs = []
-    for idx, (s, e) in enumerate(intervals):
-        for rev in (False, True):
-            a, b = (q_block_len - e, q_block_len - s) if rev else (s, e)
-            nchunks = (b - a + chunk - 1) // chunk if b > a else 0
-            ncalls = (nchunks + chunks_per_call - 1) // chunks_per_call
-            group = (nchunks + ncalls - 1) // ncalls if ncalls else 1
-            i = a
-            while i < b:
-                j = min(i + chunk * group, b)
-                jobs.append(dict(interval=idx, rev=rev, a=i, b=j, chunks=(j - i + chunk - 1) // chunk))
-                i = j
+    for rev in (False, True):
+        pieces = strand_chunks(intervals, q_block_len, chunk, rev)
+        runs, cur = [], []   # maximal runs a single range can describe
+        for p in pieces:
+            if cur and (cur[-1][2] != p[1] or cur[-1][2] - cur[-1][1] != chunk):
+                runs.append(cur)
+                cur = []
+            cur.append(p)
+        if cur:
+            runs.append(cur)
+        for run in runs:
+            n = len(run)
+            ncalls = (n + chunks_per_call - 1) // chunks_per_call
+            group = (n + ncalls - 1) // ncalls
+            for g in range(0, n, group):
+                part = run[g:g + group]
+                jobs.append(dict(interval=part[0][0], rev=rev, a=part[0][1], b=part[-1][2], chunks=len(part)))
     return jobs
 
 

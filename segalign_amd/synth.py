@@ -201,16 +201,19 @@ _MS_UNITS = [b"A", b"A", b"T", b"AT", b"AT", b"TA", b"AG", b"CT", b"AC", b"GT", 
              b"AAGG", b"AAAAT", b"AATAT", b"AAAAG", b"AAAAAT", b"AGATAT", b"TTAGGC"]
 
 
-def add_microsatellites(seq, seed, every=20000, masked=0.85):
-    """One simple repeat (1-6 bp unit, 50-500 bp, ~2 % impure) about every `every` bases; `masked` of them lower case."""
+def add_microsatellites(seq, seed, every=20000, masked=0.93):
+    """One simple repeat (1-6 bp unit, 50-500 bp -- mostly short: 50 + an exponential tail of mean 60 -- ~3 % impure) about every
+    `every` bases; `masked` of them lower case, as TRF / RepeatMasker leave an assembly (the unmasked rest is what makes buckets of
+    tens of thousands of entries, and -- above ~100 bp, where the score passes 3 x hspthresh and the entropy rule no longer applies
+    (src/seed_filter.cu:608) -- one HSP per diagonal of every pair of runs with the same unit)."""
     rng = np.random.default_rng(seed)
     n = max(1, seq.size // every)
     starts = [_lumpy_pos(rng, seq.size, []) for _ in range(n)]
     for i, p in enumerate(starts):
         unit = np.frombuffer(_MS_UNITS[int(rng.integers(0, len(_MS_UNITS)))], dtype=np.uint8)
-        ln = int(rng.integers(50, 501))
+        ln = int(min(500, 50 + rng.exponential(60)))
         run = np.tile(unit, ln // unit.size + 1)[:ln].copy()
-        bad = rng.random(ln) < 0.02
+        bad = rng.random(ln) < 0.03
         run[bad] = _ACGT[rng.integers(0, 4, int(bad.sum()))]
         _overlay(seq, int(p), run, rng.random() < masked)
     return seq

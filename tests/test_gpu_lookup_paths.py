@@ -55,7 +55,7 @@ def test_every_lookup_path_equals_the_oracle(oracle, clean, mode, env, transitio
             per[rev].append(want[1:])
         ch = c.chunks()
         kmax = E.lib().sa_max_chunks_per_call()
-        assert kmax == 32 and len(ch) == 17
+        assert kmax == 256 and len(ch) == 17
         for k in (4, 16, kmax):  # multi-chunk calls: own plan / dedup scope / vector per chunk (all 17 chunks in one call = 34 reference iterations)
             for g in range(0, len(ch), k):
                 outs = E.SeedAndFilterChunks(ch[g][0], ch[min(g + k - 1, len(ch) - 1)][1], rev, 0)

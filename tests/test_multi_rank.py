@@ -42,19 +42,33 @@ def _stub(j, chunk, w=1):
 
 
 def _model(world, steps, scaling, qlen=60_000_000, interval=10_000_000, chunk=250_000):
-    """Independent statement of the bench's work map.  strong: the calls of a pass (per interval and strand the 250 kbp chunks
-    of src/seeder.cpp:48-51 / :33-34 in groups of <= 16) are dealt round-robin, each exactly once per step; weak: in step k rank r
-    walks the whole call list from call r + k on, wrapping."""
+    """Independent statement of the bench's work map.  strong: the calls of a pass (per strand the 250 kbp chunks of
+    src/seeder.cpp:48-51 / :33-34 in equal groups of <= 16 consecutive full-sized chunks, plus strand first) are dealt to the ranks,
+    each exactly once per step; weak: in step k rank r walks the whole call list from call r + k on, wrapping."""
     ivs = shard.plan_intervals(qlen, 19, interval)
     jobs = []
-    for idx, (s, e) in enumerate(ivs):
-        for rev in (False, True):
-            a, b = (qlen - 19 - e, qlen - 19 - s) if rev else (s, e)
-            n = -(-(b - a) // chunk)
+    L = qlen - 19
+    for rev in (False, True):
+        # the strand's chunk starts in ascending order; a range can only continue while chunks touch and are full-sized
+        spans = [(L - e, L - s) for (s, e) in reversed(ivs)] if rev else list(ivs)
+        run = []          # (a, b) of consecutive chunks one call range can describe
+        runs = []
+        for (lo, hi) in spans:
+            c = lo
+            while c < hi:
+                d = min(c + chunk, hi)
+                if run and (run[-1][1] != c or run[-1][1] - run[-1][0] != chunk):
+                    runs.append(run)
+                    run = []
+                run.append((c, d))
+                c = d
+        runs.append(run)
+        for run in runs:
+            n = len(run)
             calls = -(-n // 16)
             group = -(-n // calls)
-            for c in range(calls):
-                jobs.append(dict(rev=rev, a=a + c * group * chunk, b=min(a + (c + 1) * group * chunk, b)))
+            for c in range(0, n, group):
+                jobs.append(dict(rev=rev, a=run[c][0], b=run[min(c + group, n) - 1][1]))
     bases = check = 0
     for r in range(world):
         for k in range(steps):
@@ -71,13 +85,15 @@ def _model(world, steps, scaling, qlen=60_000_000, interval=10_000_000, chunk=25
 def test_call_list_partition_covers_every_call_exactly_once():
     ivs = shard.plan_intervals(60_000_000, 19, 10_000_000)
     jobs = shard.call_jobs(ivs, 60_000_000 - 19, 250_000, 16)
-    assert len(jobs) == 6 * 2 * 3 and sum(j["chunks"] for j in jobs) == 2 * 240
-    # every strand of every interval is tiled by its calls without gap or overlap
-    for idx, (s, e) in enumerate(ivs):
-        for rev in (False, True):
-            mine = sorted((j["a"], j["b"]) for j in jobs if j["interval"] == idx and j["rev"] == rev)
-            lo, hi = (60_000_000 - 19 - e, 60_000_000 - 19 - s) if rev else (s, e)
-            assert mine[0][0] == lo and mine[-1][1] == hi and all(mine[i][1] == mine[i + 1][0] for i in range(len(mine) - 1))
+    assert sum(j["chunks"] for j in jobs) == 2 * 240 and max(j["chunks"] for j in jobs) <= 16
+    assert len(jobs) == 15 + 3 + 13   # plus: 240 chunks in 15 calls; minus: the short tail interval (40 chunks: 14 + 14 + 12), then 200 in 13
+    # every strand is tiled by its calls without gap or overlap, and every call range cuts into full chunks except its last
+    for rev in (False, True):
+        mine = sorted((j["a"], j["b"]) for j in jobs if j["rev"] == rev)
+        assert mine[0][0] == 0 and mine[-1][1] == 60_000_000 - 19 and all(mine[i][1] == mine[i + 1][0] for i in range(len(mine) - 1))
+        want = [(a, b) for (_, a, b) in shard.strand_chunks(ivs, 60_000_000 - 19, 250_000, rev)]
+        got = [(c, min(c + 250_000, b)) for (a, b) in mine for c in range(a, b, 250_000)]
+        assert got == want   # the engine's cut of every call range reproduces the reference's chunk grid (seeder.cpp:48-51)
     for world in (1, 2, 3, 8):
         parts = [shard.partition(jobs, r, world) for r in range(world)]
         flat = [id(j) for p in parts for j in p]

@@ -50,7 +50,8 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SHAPE = "TTT0T00TT00T0T0TTTT"  # 12of19, src/main.cpp:160-163
+SEEDS = {"12of19": "TTT0T00TT00T0T0TTTT", "14of22": "TTT0T0TT00TT00T0T0TTTT"}  # src/main.cpp:160-167
+SHAPE = SEEDS["12of19"]
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 STREAM_GBS = 6200.0            # measured on MI355X: what a pure sequential read of 32-byte records reaches (tools/micro/stream_rec2.hip)
 RANDOM_LINES_PER_S = 57e9      # measured on MI355X: random 128-byte line gathers per second (tools/micro/gather_bw.hip)
@@ -60,15 +61,15 @@ SCOPE_KERNELS = {
     "seed_probe": ["probe_kernel"], "probe_compact": ["probe_partials_kernel", "probe_compact_kernel"],
     "iteration_plan": ["probe_plan_kernel", "plan_kernel"], "seed_lookup": ["seed_lookup_kernel"],
     "expand_hits": ["expand_hits_kernel"], "extend_filter": ["extend_filter_packed_kernel"],  # (the default, packed filter)
-    "chain_group": ["chain_count_kernel", "chain_scan_kernel", "chain_scatter_kernel", "chain_bucket_sort_kernel"],
-    "chain_link": ["chain_link_kernel"], "extend_exact_chain": ["extend_exact_chain_kernel"],
+    "chain_group": ["chain_count_kernel", "chain_scan_kernel", "chain_scatter_kernel", "chain_sort_link_kernel"],
+    "extend_exact_chain": ["extend_exact_chain_kernel"],
     "extend_exact": ["extend_exact_kernel"], "extend_entropy": ["extend_entropy_kernel"], "dedup_seg": ["dedup_seg_kernel"],
 }
 # context-table calls (lookup mode 2): the filter is two kernels -- level 1, the class filter on the 32-byte context records, and
 # level 2 (the packed kernel) on the few hits level 1 could not decide; these are the symbols profile_check compares
 PROFILE_SCOPE_KERNELS = dict(SCOPE_KERNELS, extend_filter=["extend_filter_cls_kernel"],
                              extend_filter2=["extend_filter_packed_kernel"])
-EXTENSION_SCOPES = ["extend_filter", "extend_filter2", "chain_group", "chain_link", "extend_exact_chain", "extend_exact", "extend_entropy"]
+EXTENSION_SCOPES = ["extend_filter", "extend_filter2", "chain_group", "extend_exact_chain", "extend_exact", "extend_entropy"]
 
 
 def parse():
@@ -77,6 +78,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="ce11cb4", choices=["ce11cb4", "notransition", "rm", "human", "plumbing", "lumpy", "lumpy_rm"])
+    ap.add_argument("--seed", default="12of19", choices=sorted(SEEDS), help="seed pattern (src/main.cpp:160-167); 14of22 has 28-bit keys and 15 seed words per position")
     ap.add_argument("--target-fasta", default=None, help="real target FASTA (e.g. ce11.fa[.gz]); first 500 Mbp block is used")
     ap.add_argument("--query-fasta", default=None, help="real query FASTA (e.g. cb4.fa[.gz]); first 500 Mbp block is used")
     ap.add_argument("--target-mbp", type=float, default=None, help="synthetic target size (default per workload)")
@@ -192,8 +194,14 @@ def rotate(seq, k):
     return [seq[(k + i) % n] for i in range(n)] if n else []
 
 
+def words_per_position(transition):
+    return 1 + SHAPE.count("T") if transition else 1
+
+
 def main():
+    global SHAPE
     args = parse()
+    SHAPE = SEEDS[args.seed]
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -244,10 +252,12 @@ def main():
         os.environ.setdefault("SEGALIGN_AMD_ARENA_GB", "180")
     if args.chunks_per_call:
         E.set_option("chunks_per_call", args.chunks_per_call)
+        E.set_option("call_hits", 0)  # (an explicit grain is kept as it is: no sizing by hits)
     E.InitializeProcessor(args.workload != "notransition", args.chunk, seed_size, sub_mat, xdrop, hspthresh, False)
 
     t_gen0 = time.time()
     wl = make_workload(args, rank if scaling == "weak" else 0)  # (strong: every rank generates the SAME block pair)
+    wl["label"] = wl["label"].replace("12of19", args.seed)
     target, query = wl["target"], wl["query"]
     t_gen = time.time() - t_gen0
 
@@ -410,7 +420,7 @@ def main():
     if rank == 0 and prof and not args.no_roofline:
         roof = roofline(args, E, wl, prof, busy, call_stats, run_step, run_job, jobs, elapsed, world)
         if not wl["rm"] and not args.no_dropin:
-            roof["dropin"] = dropin_leg(E, jobs, args, seed_size, 13 if wl["transition"] else 1)
+            roof["dropin"] = dropin_leg(E, jobs, args, seed_size, words_per_position(wl["transition"]))
 
     # how evenly the seed hits are spread over the 250 kbp chunks of the pass (lookup only; rank 0, outside the timed region)
     hit_spread = None
@@ -444,7 +454,7 @@ def main():
                                                  "block (%d intervals of %d bp), both strands, %d bp chunks (%d chunks of a strand share one "
                                                  "pass over the kernels), device-side seeding" % (query.size, len(intervals), args.interval, args.chunk,
                                                                                                  E.lib().sa_get_chunks_per_call()),
-                       "workload_key": args.workload,
+                       "workload_key": args.workload + ("" if args.seed == "12of19" else "_" + args.seed), "seed": args.seed,
                        "parallelism": ("the %d engine calls of one pass dealt to %d rank(s) %s: every call on exactly one GPU, target + tables on every GPU, "
                                        "no collective" % (len(jobs), world, "by seed-hit count (longest first to the least loaded rank; counts from an "
                                                           "untimed pass every rank runs identically)" if weights else "round-robin")) if scaling == "strong" else
@@ -525,7 +535,7 @@ def roofline(args, E, wl, prof, busy, call_stats, run_step, run_job, jobs, elaps
     sH2, sA, sS, sC, sF = totals(solo_stats)
     table_direct = "seed_probe" in prof
     ctx_filter = "extend_filter2" in prof   # context-table calls: level 1 (class filter on the records) + level 2 (packed kernel)
-    words = 13 if wl["transition"] else 1
+    words = words_per_position(wl["transition"])
     lookup_scope = "seed_probe" if table_direct else "seed_lookup"
 
     def ms_of(p, scopes):

@@ -156,6 +156,10 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
             if (!dc->slots[k].stream) slot_init(dc->slots[k], dc);
             dc->slots[k].seeds.ensure((size_t)g_max_seeds, "seed_offsets");
         }
+        if (!opt_value("arena_vmm") && arena_mapped(dc->arena) == 0) {  // (A/B switch: one plain hipMalloc per growth instead of mapped chunks)
+            std::lock_guard<std::mutex> alk(dc->arena.mu);
+            dc->arena.vmm = false;
+        }
         // start mapping the table arena now: the host still has its FASTA files to read (src/main.cpp:300-549)
         if (g_arena_gb > 0 && g_td && g_ctx && g_packed_filter) {
             size_t free_b = 0, total_b = 0;

@@ -13,6 +13,12 @@ static void arena_worker(Arena* A) {
     hipMemAccessDesc acc = {};
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
+    if (opt_value("debug")) {
+        size_t gmin = 0, grec = 0;
+        hipMemGetAllocationGranularity(&gmin, &prop, hipMemAllocationGranularityMinimum);
+        hipMemGetAllocationGranularity(&grec, &prop, hipMemAllocationGranularityRecommended);
+        fprintf(stderr, "table arena: allocation granularity minimum %zu, recommended %zu bytes; chunks of %zu bytes\n", gmin, grec, (size_t)ARENA_CHUNK);
+    }
     std::unique_lock<std::mutex> lk(A->mu);
     while (!A->stop && !A->failed && A->mapped < A->goal && A->mapped + ARENA_CHUNK <= A->va_bytes) {
         uint8_t* at = A->base + A->mapped;

@@ -146,7 +146,8 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                 if (bh == 0 || (!ca.td && b_seed_hi <= b_seed_lo)) continue;  // iterations without hits produce nothing (H5)
                 // (the segment ends of the batch: a device array the candidate-stage kernels search; the previous batch has been
                 //  synchronised, so the pinned staging copy is free)
-                check_memcpy(hipMemcpyAsync(sl->d_seg_end, sl->h_seg_end, (size_t)nseg * sizeof(uint64_t), hipMemcpyHostToDevice, st), "segment ends");
+                // (a table-direct call is one batch whose ends probe_plan_kernel has already written from the same chunk plans)
+                if (!ca.td) check_memcpy(hipMemcpyAsync(sl->d_seg_end, sl->h_seg_end, (size_t)nseg * sizeof(uint64_t), hipMemcpyHostToDevice, st), "segment ends");
                 ea.seg_end = sl->d_seg_end;
                 if (ca.td) {
                     ea.td = 1;
@@ -220,7 +221,7 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                 ea.ent_count = &sl->d_cnt->n_ent;
                 ea.long_blocks = (uint32_t)g_long_blocks;
                 ea.max_waves = (uint32_t)(ea.fast_filter == 3 ? g_packed_waves : g_max_waves);
-                ea.ent_blocks = 1024;  // (grid-stride over a count that lives on the device: a few thousand records usually, millions on repeats)
+                ea.ent_blocks = 256;  // (grid-stride over a count that lives on the device: a few thousand records usually, millions on repeats)
                 sl->cand_list.ensure((size_t)std::max<uint64_t>(1u << 16, bh / 16), "candidate list");
                 // chain shortcut: valid for the plain X-drop recurrence (xdrop >= 0), needs the 29-bit position field of its
                 // sort key, and is off while E is being counted.  The repeat masker takes it too: its window only decides WHICH
@@ -231,6 +232,7 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                 ea.chain_q_bits = chain_rel ? 32u : 29u;  // (32: diagonal | relative position, no iteration field -- kernels.h)
                 ea.chain_q_base = chain_rel ? ca.q_lo : 0u;
                 ea.chain_cap = chain ? CHAIN_CAP : 0u;
+                ea.chain_buckets = chain_buckets_for(bh);
                 ea.chain_sort_threads = (uint32_t)g_chain_sort_threads;
                 if (chain) {
                     sl->chain_tmp.ensure(CHAIN_CAP, "chain candidates");
@@ -291,7 +293,6 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                     if (ea.chain_cap) {
                         if (!cleared) check_memcpy(hipMemsetAsync(sl->chain_bucket_cnt.p, 0, chain_num_buckets() * sizeof(uint32_t), st), "chain buckets");
                         { ProfScope p(sl, "chain_group"); launch_chain_group(ea, st); }
-                        { ProfScope p(sl, "chain_link");  launch_chain_link(ea, st); }
                     }
                     if (ea.chain_cap) { ProfScope p(sl, "extend_exact_chain"); launch_extend_exact_chain(ea, st); }
                     else              { ProfScope p(sl, "extend_exact");       launch_extend_exact(ea, st); }
@@ -333,7 +334,6 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                             check_memcpy(hipMemsetAsync(sl->chain_bucket_cnt.p, 0, chain_num_buckets() * sizeof(uint32_t), st), "chain buckets");
                             check_memcpy(hipMemsetAsync(&sl->d_cnt->n_heads, 0, sizeof(uint32_t), st), "chain heads");
                             { ProfScope p(sl, "chain_group"); launch_chain_group(es, st); }
-                            { ProfScope p(sl, "chain_link");  launch_chain_link(es, st); }
                             { ProfScope p(sl, "extend_exact_chain"); launch_extend_exact_chain(es, st); }
                         }
                         { ProfScope p(sl, "extend_entropy"); launch_extend_entropy(ea, st); }

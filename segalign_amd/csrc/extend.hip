@@ -110,16 +110,22 @@ __device__ __forceinline__ void chunk8_exact(const int* __restrict__ s_tab, uint
 }
 
 // segment (reference iteration) of a hit: the first s with g < seg_end[s] -- a binary search over the batch's <= MAX_SEGS ascending
-// ends (a 4 KB device array every lane of the candidate-stage kernels reads: it lives in the L1 / L2)
-__device__ __forceinline__ uint32_t seg_of(const ExtendArgs& a, uint64_t local_idx) {
+// ends.  Every candidate-stage workgroup stages the ends in LDS first (SEG_TABLE below): the search is 6-9 dependent reads, and from
+// the device array itself it cost the five candidate-stage kernels ~100 us per call together (a 63-step compare loop over kernel
+// arguments, which is what a 64-segment limit allowed, cost about the same).
+__device__ __forceinline__ uint32_t seg_of(const ExtendArgs& a, const uint64_t* __restrict__ s_seg, uint64_t local_idx) {
     const uint64_t g = a.hit_base + local_idx;
     uint32_t lo = 0, hi = (uint32_t)a.num_segs - 1u;  // answer in [lo, hi]; a hit beyond the last end belongs to the last segment
     while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (g >= a.seg_end[mid]) lo = mid + 1; else hi = mid;
+        if (g >= s_seg[mid]) lo = mid + 1; else hi = mid;
     }
     return a.seg_base + lo;
 }
+#define SEG_TABLE()                                                                                                      \
+    __shared__ uint64_t s_seg[MAX_SEGS];                                                                                 \
+    for (uint32_t t_ = threadIdx.x; t_ < (uint32_t)a.num_segs; t_ += blockDim.x) s_seg[t_] = a.seg_end[t_];             \
+    __syncthreads();
 
 // What to do with a finished hit: 0 = reject, 1 = survivor with entropy 1, 2 = needs the entropy factor (:608,:633)
 __device__ __forceinline__ int classify(const ExtendArgs& a, int total) {
@@ -1243,6 +1249,7 @@ __device__ __forceinline__ void wave_finalize(const ExtendArgs& a, ExactStage& s
     const uint8_t* __restrict__ Qb = a.query - BIAS;                                                       \
     const uint32_t n_cand = min(*a.cand_count, a.cand_cap_recs);                                           \
     const uint32_t G = gridDim.x * (EXT_THREADS / 64);                                                     \
+    SEG_TABLE()                                                                                            \
     unsigned long long examined = 0;
 
 #define EXACT_KERNEL_EPILOGUE()                                                                            \
@@ -1265,7 +1272,7 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_exact_kernel(ExtendArgs a)
         const uint32_t hidx = (uint32_t)rfl((int)cr.hidx);
         int bestR, bposR, bestL, boffL;
         wave_extend_exact<COUNT_EXAMINED, XDROP_NONNEG>(a, s_tab, R8b, Qb, lane, ref_loc, query_loc, bestR, bposR, bestL, boffL, examined);
-        wave_finalize(a, st, lane, ref_loc, query_loc, seg_of(a, hidx), bestR, bposR, bestL, boffL);
+        wave_finalize(a, st, lane, ref_loc, query_loc, seg_of(a, s_seg, hidx), bestR, bposR, bestL, boffL);
     }
     EXACT_KERNEL_EPILOGUE()
 }
@@ -1291,7 +1298,7 @@ constexpr uint32_t CHAIN_WALK_EXTRA = 96; // bases walked past the predecessor's
 // (iteration, diagonal, position).  A bucket holds a handful of diagonals with a few hundred candidates each, so the
 // quadratic rank sort is a few microseconds; all buckets together are the candidate list with every diagonal's
 // candidates contiguous and ordered by position -- exactly what the link test needs.  No host involvement.
-constexpr uint32_t CHAIN_BUCKETS = 65536;  // (a sparse-hit call of 160 chunks carries ~5 M candidates, a 20-chunk call at human-scale hit density ~1.5 M)
+constexpr uint32_t CHAIN_BUCKETS_MIN = 16384, CHAIN_BUCKETS_MAX = 262144;  // the host picks a power of two from the batch's hits (ExtendArgs.chain_buckets)
 constexpr uint32_t CHAIN_SORT_MAX = 1024;  // entries a bucket may hold and still be sorted (8 KB of LDS); larger: left unsorted,
                                            // which only makes link tests fail, i.e. costs extensions, never correctness
 
@@ -1299,16 +1306,16 @@ constexpr uint32_t CHAIN_SORT_MAX = 1024;  // entries a bucket may hold and stil
 // collinear query), so the window keeps a group at <= 512 entries and spreads the counting atomics; chains simply
 // restart at window borders (one extra extension per 512 bases of HSP).
 constexpr uint32_t CHAIN_QSHIFT = 9;
-__device__ __forceinline__ uint32_t chain_bucket_of(uint32_t seg, const CandRec& c) {
+__device__ __forceinline__ uint32_t chain_bucket_of(const ExtendArgs& a, uint32_t seg, const CandRec& c) {
     const uint32_t diag = c.ref_loc - c.query_loc;
-    return (((diag * 2654435761u) ^ ((c.query_loc >> CHAIN_QSHIFT) * 0x85EBCA6Bu) ^ (seg * 0x9E3779B1u)) >> 15) & (CHAIN_BUCKETS - 1u);
+    return (((diag * 2654435761u) ^ ((c.query_loc >> CHAIN_QSHIFT) * 0x85EBCA6Bu) ^ (seg * 0x9E3779B1u)) >> 14) & (a.chain_buckets - 1u);
 }
-__device__ __forceinline__ unsigned long long chain_key(const ExtendArgs& a, const CandRec& c) {
+__device__ __forceinline__ unsigned long long chain_key(const ExtendArgs& a, const uint64_t* __restrict__ s_seg, const CandRec& c) {
     // iteration | diagonal (32) | query position (q bits): 3 | 32 | 29 with absolute positions (general path, <= 8 iterations per
     // batch), 6 | 32 | 26 with positions relative to the call's first one (table-direct calls: <= 64 iterations, <= 8 M positions)
     const uint32_t qb = a.chain_q_bits;
     if (qb == 32u) return ((unsigned long long)(uint32_t)(c.ref_loc - c.query_loc) << 32) | (unsigned long long)(c.query_loc - a.chain_q_base);
-    return ((unsigned long long)(seg_of(a, c.hidx) - a.seg_base) << (32u + qb)) |
+    return ((unsigned long long)(seg_of(a, s_seg, c.hidx) - a.seg_base) << (32u + qb)) |
            ((unsigned long long)(uint32_t)(c.ref_loc - c.query_loc) << qb) |
            (unsigned long long)((c.query_loc - a.chain_q_base) & ((1u << qb) - 1u));
 }
@@ -1331,125 +1338,150 @@ __device__ __forceinline__ bool chain_range(const ExtendArgs& a, uint32_t& first
 __global__ __launch_bounds__(256) void chain_count_kernel(ExtendArgs a) {
     uint32_t first, n;
     if (!chain_range(a, first, n)) return;
+    SEG_TABLE()
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const CandRec c = a.cand_list[first + i];
-        atomicAdd(&a.chain_bucket_cnt[chain_bucket_of(seg_of(a, c.hidx), c)], 1u);
+        atomicAdd(&a.chain_bucket_cnt[chain_bucket_of(a, seg_of(a, s_seg, c.hidx), c)], 1u);
     }
 }
 
-// one block: exclusive scan of the CHAIN_BUCKETS counters into chain_bucket_start[0..CHAIN_BUCKETS]; counters become cursors
+// one block: exclusive scan of the a.chain_buckets counters into chain_bucket_start[0..buckets]; counters become cursors.  Tiles of
+// 4096 counters: every thread takes four consecutive ones as ONE 16-byte load (coalesced), wave scan + the totals of the waves
+// before + the running total of the tiles before, results stored the same way.  (Round 3: every thread walked 64 consecutive
+// counters with 4-byte loads, 20 us for 16384 buckets and 80 us for 65536.)
 constexpr uint32_t CHAIN_SCAN_THREADS = 1024;
 __global__ __launch_bounds__(CHAIN_SCAN_THREADS) void chain_scan_kernel(ExtendArgs a) {
-    __shared__ uint32_t s_part[CHAIN_SCAN_THREADS];
-    constexpr uint32_t PER = CHAIN_BUCKETS / CHAIN_SCAN_THREADS;
-    uint32_t v[PER], sum = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < PER; j++) { v[j] = a.chain_bucket_cnt[threadIdx.x * PER + j]; sum += v[j]; }
-    s_part[threadIdx.x] = sum;
+    __shared__ uint32_t s_part[CHAIN_SCAN_THREADS / 64];
+    __shared__ uint32_t s_carry;
+    const uint32_t B = a.chain_buckets;
+    if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
-    uint32_t base = 0;
-    for (uint32_t t = 0; t < threadIdx.x; t++) base += s_part[t];
+    uint4* cnt4 = reinterpret_cast<uint4*>(a.chain_bucket_cnt);
+    uint4* start4 = reinterpret_cast<uint4*>(a.chain_bucket_start);
+    for (uint32_t t0 = 0; t0 < B; t0 += CHAIN_SCAN_THREADS * 4) {
+        const uint32_t q = (t0 >> 2) + threadIdx.x;
+        const uint4 v = cnt4[q];
+        const uint32_t sum = v.x + v.y + v.z + v.w;
+        uint32_t inc = sum;
 #pragma unroll
-    for (uint32_t j = 0; j < PER; j++) {
-        a.chain_bucket_start[threadIdx.x * PER + j] = base;
-        a.chain_bucket_cnt[threadIdx.x * PER + j] = 0;  // reused as the scatter cursor
-        base += v[j];
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(inc, off, 64);
+            if ((int)(threadIdx.x & 63) >= off) inc += t;
+        }
+        if ((threadIdx.x & 63) == 63) s_part[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t base = s_carry + inc - sum;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) base += s_part[w];
+        start4[q] = make_uint4(base, base + v.x, base + v.x + v.y, base + v.x + v.y + v.z);
+        cnt4[q] = make_uint4(0u, 0u, 0u, 0u);  // reused as the scatter cursor
+        __syncthreads();
+        if (threadIdx.x == CHAIN_SCAN_THREADS - 1) s_carry = base + sum;
+        __syncthreads();
     }
-    if (threadIdx.x == CHAIN_SCAN_THREADS - 1) a.chain_bucket_start[CHAIN_BUCKETS] = base;
+    if (threadIdx.x == 0) a.chain_bucket_start[B] = s_carry;
 }
 
 __global__ __launch_bounds__(256) void chain_scatter_kernel(ExtendArgs a) {
     uint32_t first, n;
     if (!chain_range(a, first, n)) return;
+    SEG_TABLE()
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const CandRec c = a.cand_list[first + i];
-        const uint32_t b = chain_bucket_of(seg_of(a, c.hidx), c);
+        const uint32_t b = chain_bucket_of(a, seg_of(a, s_seg, c.hidx), c);
         a.chain_tmp[a.chain_bucket_start[b] + atomicAdd(&a.chain_bucket_cnt[b], 1u)] = c;
     }
 }
 
-// CHAIN_SORT_GROUP consecutive buckets per workgroup (a bucket holds ~40 candidates: one workgroup per bucket was 16384 tiny
-// workgroups whose dispatch cost more than their work): rank sort in LDS by (iteration, diagonal, position), every entry ranked
-// inside its own bucket
+// CHAIN_SORT_GROUP consecutive buckets per workgroup (a bucket holds a few dozen candidates: one workgroup per bucket was thousands
+// of tiny workgroups whose dispatch cost more than their work): rank sort in LDS by (diagonal, position) -- table-direct calls -- or
+// (iteration, diagonal, position), every entry ranked inside its own bucket; then, in the SAME workgroup, the link test of every
+// entry against its predecessor in the bucket (the separate chain_link_kernel of rounds 1-3: one launch and one pass over the
+// sorted list less).  The sorted order is kept as a permutation in LDS; the records are read from the scatter's output and
+// written in order, coalesced.
 constexpr uint32_t CHAIN_SORT_GROUP = 8;
-__global__ __launch_bounds__(512) void chain_bucket_sort_kernel(ExtendArgs a) {
-    __shared__ unsigned long long s_key[CHAIN_SORT_GROUP * CHAIN_SORT_MAX / 2];  // 32 KB: the group's entries, when they fit
+constexpr uint32_t CHAIN_GROUP_MAX = CHAIN_SORT_GROUP * CHAIN_SORT_MAX / 2;  // entries of a group the LDS holds (32 KB of keys)
+
+// does candidate c start a run?  (test (L) of DESIGN.md 4.5' against its predecessor pc on the same diagonal, bounded walk)
+template <bool XDROP_NONNEG>
+__device__ __forceinline__ bool chain_is_run_head(const ExtendArgs& a, const uint64_t* __restrict__ s_seg, const int* __restrict__ s_tab, const uint8_t* __restrict__ R8b,
+                                                  const uint8_t* __restrict__ Qb, const CandRec& c, const CandRec& pc) {
+    // same iteration, same diagonal, predecessor strictly before this anchor
+    if (!((c.ref_loc - c.query_loc) == (pc.ref_loc - pc.query_loc) && c.query_loc > pc.query_loc && seg_of(a, s_seg, c.hidx) == seg_of(a, s_seg, pc.hidx)))
+        return true;
+    const uint32_t g = c.query_loc - pc.query_loc;  // anchor gap (> 0)
+    if (g > CHAIN_GAP_MAX) return true;
+    const uint32_t lim = min(c.ref_loc, c.query_loc);
+    int score = 0, best = 0, bpos = 0;
+    uint32_t ex = 0;
+    for (uint32_t k = 1; k <= g + CHAIN_WALK_EXTRA; k += 8) {
+        const int64_t rem64 = (int64_t)lim - (int64_t)k + 1;
+        const int remaining = rem64 > 8 ? 8 : (rem64 < 0 ? 0 : (int)rem64);
+        uint64_t x = 0;
+        if (remaining > 0)
+            x = __builtin_bswap64(load8u(R8b + (c.ref_loc + BIAS - k - 7u)) | load8u(Qb + (c.query_loc + BIAS - k - 7u)));
+        if (remaining < 8) x |= (remaining <= 0) ? TERM_ALL : (TERM_ALL << (8 * remaining));
+        chunk8_exact<false, XDROP_NONNEG>(s_tab, x, k, a.xdrop, score, best, bpos, ex);
+        if ((uint32_t)bpos > g) return false;  // strict new best at a position < predecessor's anchor: (L)
+        if (score < (DEAD >> 1)) break;        // walk ended first: extend this one on its own
+    }
+    return true;
+}
+
+template <bool XDROP_NONNEG>
+__global__ __launch_bounds__(512) void chain_sort_link_kernel(ExtendArgs a) {
+    __shared__ unsigned long long s_key[CHAIN_GROUP_MAX];  // 32 KB: the group's keys, when they fit
+    __shared__ uint16_t s_perm[CHAIN_GROUP_MAX];            // sorted position -> entry of the group
     __shared__ uint32_t s_b[CHAIN_SORT_GROUP + 1];
+    __shared__ int s_tab[128];
     uint32_t first, n;
     if (!chain_range(a, first, n)) return;
+    SEG_TABLE()
+    if (threadIdx.x < 128) s_tab[threadIdx.x] = threadIdx.x < 64 ? a.sub_mat[threadIdx.x] : NEG;
     if (threadIdx.x <= CHAIN_SORT_GROUP) s_b[threadIdx.x] = a.chain_bucket_start[blockIdx.x * CHAIN_SORT_GROUP + threadIdx.x];
     __syncthreads();
     const uint32_t g0 = s_b[0], m_all = s_b[CHAIN_SORT_GROUP] - g0;
     if (m_all == 0) return;
-    bool big = m_all > CHAIN_SORT_GROUP * CHAIN_SORT_MAX / 2;  // (a bucket above CHAIN_SORT_MAX, or a group that does not fit: left unsorted)
-    for (uint32_t j = 0; j < CHAIN_SORT_GROUP; j++) big = big || (s_b[j + 1] - s_b[j]) > CHAIN_SORT_MAX;
-    if (big) {
-        for (uint32_t i = threadIdx.x; i < m_all; i += blockDim.x) a.chain_sorted[g0 + i] = a.chain_tmp[g0 + i];
-        if (threadIdx.x == 0 && a.chain_big) atomicAdd(a.chain_big, 1u);
-        return;
-    }
-    for (uint32_t i = threadIdx.x; i < m_all; i += blockDim.x) s_key[i] = chain_key(a, a.chain_tmp[g0 + i]);
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < m_all; i += blockDim.x) {
-        uint32_t j = 0;  // the entry's bucket inside the group
-        while (g0 + i >= s_b[j + 1]) j++;
-        const uint32_t lo = s_b[j] - g0, hi = s_b[j + 1] - g0;
-        const unsigned long long k = s_key[i];
-        // rank = entries below this one; keys are unique per hit, and hand-made ties (a foreign host's duplicate seed words) are
-        // broken by the index: "<=" before i, "<" behind it -- one compare + one add-with-carry per entry either way
-        uint32_t rank = 0;
-#pragma unroll 4
-        for (uint32_t t = lo; t < i; t++) rank += s_key[t] <= k ? 1u : 0u;
-#pragma unroll 4
-        for (uint32_t t = i + 1; t < hi; t++) rank += s_key[t] < k ? 1u : 0u;
-        a.chain_sorted[g0 + lo + rank] = a.chain_tmp[g0 + i];
-    }
-}
-
-// one lane per sorted candidate: does it start a run?  (test (L) against the predecessor, bounded walk)
-template <bool XDROP_NONNEG>
-__global__ __launch_bounds__(256) void chain_link_kernel(ExtendArgs a) {
-    __shared__ int s_tab[128];
-    if (threadIdx.x < 128) s_tab[threadIdx.x] = threadIdx.x < 64 ? a.sub_mat[threadIdx.x] : NEG;
-    __syncthreads();
-    uint32_t first, n;
-    if (!chain_range(a, first, n)) return;
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    bool big = m_all > CHAIN_GROUP_MAX;  // (a bucket above CHAIN_SORT_MAX, or a group that does not fit: left unsorted, every entry a run head)
+    for (uint32_t j = 0; j < CHAIN_SORT_GROUP; j++) big = big || (s_b[j + 1] - s_b[j]) > CHAIN_SORT_MAX;
+    if (!big) {
+        for (uint32_t i = threadIdx.x; i < m_all; i += blockDim.x) s_key[i] = chain_key(a, s_seg, a.chain_tmp[g0 + i]);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < m_all; i += blockDim.x) {
+            uint32_t j = 0;  // the entry's bucket inside the group
+            while (g0 + i >= s_b[j + 1]) j++;
+            const uint32_t lo = s_b[j] - g0, hi = s_b[j + 1] - g0;
+            const unsigned long long k = s_key[i];
+            // rank = entries below this one; keys are unique per hit, and hand-made ties (a foreign host's duplicate seed words) are
+            // broken by the index: "<=" before i, "<" behind it -- one compare + one add-with-carry per entry either way
+            uint32_t rank = 0;
+#pragma unroll 4
+            for (uint32_t t = lo; t < i; t++) rank += s_key[t] <= k ? 1u : 0u;
+#pragma unroll 4
+            for (uint32_t t = i + 1; t < hi; t++) rank += s_key[t] < k ? 1u : 0u;
+            s_perm[lo + rank] = (uint16_t)i;
+        }
+        __syncthreads();
+    } else if (threadIdx.x == 0 && a.chain_big) {
+        atomicAdd(a.chain_big, 1u);
+    }
     const uint8_t* __restrict__ R8b = a.ref8 - BIAS;
     const uint8_t* __restrict__ Qb = a.query - BIAS;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t rounds = (n + stride - 1) / stride;  // wave-uniform trip count (ballot below)
+    const uint32_t rounds = (m_all + blockDim.x - 1) / blockDim.x;  // wave-uniform trip count (ballot below)
     for (uint32_t r = 0; r < rounds; r++) {
-        const uint32_t i = r * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        const uint32_t p = r * blockDim.x + threadIdx.x;  // sorted position inside the group
         bool head = false;
-        if (i < n) {
+        if (p < m_all) {
+            const CandRec c = a.chain_tmp[g0 + (big ? p : (uint32_t)s_perm[p])];
+            a.chain_sorted[g0 + p] = c;
             head = true;
-            const CandRec c = a.chain_sorted[i];
-            CandRec pc = c;
-            if (i > 0) pc = a.chain_sorted[i - 1];
-            // same iteration, same diagonal, predecessor strictly before this anchor
-            if (i > 0 && (c.ref_loc - c.query_loc) == (pc.ref_loc - pc.query_loc) && c.query_loc > pc.query_loc &&
-                seg_of(a, c.hidx) == seg_of(a, pc.hidx)) {
-                const uint32_t g = c.query_loc - pc.query_loc;  // anchor gap (> 0)
-                if (g <= CHAIN_GAP_MAX) {
-                    const uint32_t lim = min(c.ref_loc, c.query_loc);
-                    int score = 0, best = 0, bpos = 0;
-                    uint32_t ex = 0;
-                    for (uint32_t k = 1; k <= g + CHAIN_WALK_EXTRA; k += 8) {
-                        const int64_t rem64 = (int64_t)lim - (int64_t)k + 1;
-                        const int remaining = rem64 > 8 ? 8 : (rem64 < 0 ? 0 : (int)rem64);
-                        uint64_t x = 0;
-                        if (remaining > 0)
-                            x = __builtin_bswap64(load8u(R8b + (c.ref_loc + BIAS - k - 7u)) | load8u(Qb + (c.query_loc + BIAS - k - 7u)));
-                        if (remaining < 8) x |= (remaining <= 0) ? TERM_ALL : (TERM_ALL << (8 * remaining));
-                        chunk8_exact<false, XDROP_NONNEG>(s_tab, x, k, a.xdrop, score, best, bpos, ex);
-                        if ((uint32_t)bpos > g) { head = false; break; }  // strict new best at a position < predecessor's anchor: (L)
-                        if (score < (DEAD >> 1)) break;                  // walk ended first: extend this one on its own
-                    }
-                }
+            if (!big) {
+                uint32_t j = 0;
+                while (g0 + p >= s_b[j + 1]) j++;
+                if (g0 + p > s_b[j]) head = chain_is_run_head<XDROP_NONNEG>(a, s_seg, s_tab, R8b, Qb, c, a.chain_tmp[g0 + (uint32_t)s_perm[p - 1]]);
             }
-            a.chain_is_head[i] = head ? 1u : 0u;
+            a.chain_is_head[g0 + p] = head ? 1u : 0u;
         }
         // run heads -> head list (order irrelevant)
         const unsigned long long m = __ballot(head);
@@ -1458,7 +1490,7 @@ __global__ __launch_bounds__(256) void chain_link_kernel(ExtendArgs a) {
             uint32_t wbase = 0;
             if (lane == leader) wbase = atomicAdd(a.chain_head_count, (uint32_t)__popcll(m));
             wbase = (uint32_t)__builtin_amdgcn_readlane((int)wbase, leader);
-            if (head) a.chain_heads[wbase + (uint32_t)__popcll(m & lane_lt)] = i;
+            if (head) a.chain_heads[wbase + (uint32_t)__popcll(m & lane_lt)] = g0 + p;
         }
     }
 }
@@ -1479,7 +1511,7 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_exact_chain_kernel(ExtendA
             const uint32_t hidx = (uint32_t)rfl((int)cr.hidx);
             int bestR, bposR, bestL, boffL;
             wave_extend_exact<false, XDROP_NONNEG>(a, s_tab, R8b, Qb, lane, ref_loc, query_loc, bestR, bposR, bestL, boffL, examined);
-            wave_finalize(a, st, lane, ref_loc, query_loc, seg_of(a, hidx), bestR, bposR, bestL, boffL);
+            wave_finalize(a, st, lane, ref_loc, query_loc, seg_of(a, s_seg, hidx), bestR, bposR, bestL, boffL);
             // members of the run follow in the sorted list until the next run head
             const int64_t right_end = (int64_t)ref_loc + (int64_t)bposR;  // E_R(head) as a target position
             uint32_t nxt = 0xFFFFFFFFu;
@@ -1593,12 +1625,14 @@ void launch_chain_group(const ExtendArgs& a, hipStream_t s) {  // chain_bucket_c
     hipLaunchKernelGGL(chain_count_kernel, dim3(1024), dim3(256), 0, s, a);
     hipLaunchKernelGGL(chain_scan_kernel, dim3(1), dim3(CHAIN_SCAN_THREADS), 0, s, a);
     hipLaunchKernelGGL(chain_scatter_kernel, dim3(1024), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(chain_bucket_sort_kernel, dim3(CHAIN_BUCKETS / CHAIN_SORT_GROUP), dim3(a.chain_sort_threads ? a.chain_sort_threads : 256), 0, s, a);
+    hipLaunchKernelGGL((chain_sort_link_kernel<true>), dim3(a.chain_buckets / CHAIN_SORT_GROUP), dim3(a.chain_sort_threads ? a.chain_sort_threads : 256), 0, s, a);
 }
-uint32_t chain_num_buckets() { return CHAIN_BUCKETS; }
-void launch_chain_link(const ExtendArgs& a, hipStream_t s) {
-    if (a.num_hits == 0 || !a.chain_cap) return;
-    hipLaunchKernelGGL((chain_link_kernel<true>), dim3(1024), dim3(256), 0, s, a);
+uint32_t chain_num_buckets() { return CHAIN_BUCKETS_MAX; }  // (what the bucket arrays are sized for)
+// buckets for a batch of `hits` seed hits: ~0.6 % of them become candidates on ordinary sequence, and a bucket should hold ~100
+uint32_t chain_buckets_for(uint64_t hits) {
+    uint32_t b = CHAIN_BUCKETS_MIN;
+    while (b < CHAIN_BUCKETS_MAX && (uint64_t)b * 16384ull < hits) b <<= 1;
+    return b;
 }
 void launch_extend_exact_chain(const ExtendArgs& a, hipStream_t s) {
     if (a.num_hits == 0 || !a.chain_cap) return;

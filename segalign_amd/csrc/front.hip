@@ -269,7 +269,7 @@ uint32_t td_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, int K, const uint
         }
         {
             ProfScope p(sl, "iteration_plan");
-            launch_probe_plan(qcodes, sh, tmask, dc->bucket_start, sl->d_td_bounds, K, sl->td_rec.p, sl->d_td_plan, st);
+            launch_probe_plan(qcodes, sh, tmask, dc->bucket_start, sl->d_td_bounds, K, sl->td_rec.p, sl->d_td_plan, sl->d_seg_end, st);
         }
         check_launch("probe");
         check_memcpy(hipMemcpyAsync(sl->h_td_plan, sl->d_td_plan, sizeof(TdPlan) * K, hipMemcpyDeviceToHost, st), "probe plan");

@@ -120,6 +120,7 @@ struct ExtendArgs {
     uint32_t ent_cap_recs;
     // chain shortcut of the exact stage (extend.hip 2b); chain_cap == 0 disables it
     uint32_t chain_cap;                      // candidates per batch the chain buffers hold
+    uint32_t chain_buckets;                  // hash buckets of this batch (power of two, chain_buckets_for)
     uint32_t cand_sliced, cand_first;        // cand_sliced: the chain stages work on candidates [cand_first, cand_first + chain_cap) of the list
                                              // (a batch with more candidates than the chain buffers hold is run slice by slice)
     uint32_t* chain_bucket_cnt;              // [buckets] counters, then scatter cursors (zero on entry)
@@ -261,7 +262,7 @@ void launch_extend_exact(const ExtendArgs& a, hipStream_t s);    // candidates -
 // chain shortcut: keys -> (sort, dedup.hip) -> links/run heads -> one exact extension per run
 void launch_chain_group(const ExtendArgs& a, hipStream_t s);
 uint32_t chain_num_buckets();
-void launch_chain_link(const ExtendArgs& a, hipStream_t s);
+uint32_t chain_buckets_for(uint64_t hits);
 void launch_extend_exact_chain(const ExtendArgs& a, hipStream_t s);
 void launch_extend_entropy(const ExtendArgs& a, hipStream_t s);  // entropy records -> survivors
 

@@ -357,9 +357,11 @@ __global__ __launch_bounds__(PR_THREADS) void probe_compact_kernel(uint32_t star
 
 // one lane per chunk
 __global__ void probe_plan_kernel(const uint8_t* __restrict__ query, SeedShape sh, uint32_t tmask, const uint32_t* __restrict__ bucket_start,
-                                  const Tri* __restrict__ bounds, int nchunks, const TdRec* __restrict__ c_rec, TdPlan* __restrict__ plan) {
+                                  const Tri* __restrict__ bounds, int nchunks, const TdRec* __restrict__ c_rec, TdPlan* __restrict__ plan,
+                                  uint64_t* __restrict__ seg_end) {
+    __shared__ uint64_t s_split[TD_MAX_BOUNDS], s_end[TD_MAX_BOUNDS];
     const int c = threadIdx.x;
-    if (c >= nchunks) return;
+    if (c < nchunks) {
     const Tri lo = bounds[c], hi = bounds[c + 1];
     TdPlan p;
     p.hit_base = lo.hits;
@@ -387,6 +389,17 @@ __global__ void probe_plan_kernel(const uint8_t* __restrict__ query, SeedShape s
         p.split = (uint64_t)c_rec[m].prefix + before_last;  // iteration 0 = hits [hit_base, split), iteration 1 = [split, hit_base + num_hits)
     }
     plan[c] = p;
+    s_split[c] = p.split;
+    s_end[c] = p.num_hits ? p.hit_base + p.num_hits : 0;  // (0: a chunk without hits has no iterations)
+    }
+    __syncthreads();
+    // the segment (reference iteration) ends of the call, in hit order: two per chunk that has hits -- what the host derives from the
+    // same plans for its own bookkeeping (core.hip); the candidate-stage kernels search this array (extend.hip seg_of)
+    if (threadIdx.x == 0 && seg_end) {
+        int n = 0;
+        for (int k = 0; k < nchunks; k++)
+            if (s_end[k]) { seg_end[n++] = s_split[k]; seg_end[n++] = s_end[k]; }
+    }
 }
 
 // ONE clearing kernel per table-direct call: the words of the head-bit map the call will use (its hit total is only known on the
@@ -428,9 +441,9 @@ void launch_probe_compact(uint32_t start, uint32_t n, const uint64_t* t_off, con
                        chunk_cap, head_bits, head_words, bpos, reinterpret_cast<Tri*>(bounds_buf));
 }
 void launch_probe_plan(const uint8_t* query, SeedShape sh, uint32_t tmask, const uint32_t* bucket_start, const void* bounds_buf, int nchunks,
-                       const TdRec* c_rec, TdPlan* plan, hipStream_t s) {
+                       const TdRec* c_rec, TdPlan* plan, uint64_t* seg_end, hipStream_t s) {
     hipLaunchKernelGGL(probe_plan_kernel, dim3(1), dim3((nchunks + 63) / 64 * 64), 0, s, query, sh, tmask, bucket_start, reinterpret_cast<const Tri*>(bounds_buf),
-                       nchunks, c_rec, plan);
+                       nchunks, c_rec, plan, seg_end);
 }
 
 }  // namespace sa

@@ -35,6 +35,7 @@ def run(engine, oracle, t, q, chain, **kw):
     c = Case(t, q, **kw).oracle_setup(oracle).engine_setup(engine)
     try:
         outs, surv = [], 0
+        run.flags = 0
         for rev in (False, True):
             for (s, e) in c.chunks():
                 seeds = c.host_seeds(s, e, rev)
@@ -44,6 +45,7 @@ def run(engine, oracle, t, q, chain, **kw):
                 got = c.E.SeedAndFilter(seeds, rev, 0)
                 assert seg_equal(got, want), (chain, rev, s, e)
                 surv += c.E.last_call_stats()["num_survivors"]
+                run.flags |= c.E.last_call_stats()["path_flags"]
                 outs.append(got)
         return outs, surv
     finally:
@@ -91,8 +93,8 @@ def test_chain_with_iteration_split(oracle, engine):
 
 
 def test_candidate_list_larger_than_the_chain_buffers(oracle, engine):
-    """more candidates than SEGALIGN_AMD_CHAIN_CAP: the chain kernels leave the batch alone and every candidate is
-    extended on its own by a second launch (engine.hip), same output"""
+    """more candidates than SEGALIGN_AMD_CHAIN_CAP: the chain kernels leave the batch alone at first (the count lives on the device)
+    and the host runs the chain stages over the candidate list slice by slice (core.hip), same output"""
     t = synth.random_dna(50000, 31)
     q = synth.mutate(t, 32, 0.03)
     os.environ["SEGALIGN_AMD_CHAIN_CAP"] = "500"
@@ -100,4 +102,4 @@ def test_candidate_list_larger_than_the_chain_buffers(oracle, engine):
         outs, surv = run(engine, oracle, t, q, True)
     finally:
         os.environ.pop("SEGALIGN_AMD_CHAIN_CAP", None)
-    assert surv > 500  # without the shortcut every candidate survives on its own
+    assert surv > 0 and run.flags & engine.PATH_CHAIN_SLICED

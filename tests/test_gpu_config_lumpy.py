@@ -43,7 +43,7 @@ def test_table_properties_and_spectrum(lumpy):
     E = lumpy["E"]
     check_seed_table_properties(E, lumpy["target"].size, 19)
     sizes = np.diff(np.concatenate([[0], lumpy["index"].astype(np.int64)]))
-    assert sizes.max() > 5000 and int((sizes > 1024).sum()) >= 20          # heavy buckets exist (uniform DNA: max ~25)
+    assert sizes.max() > 2000 and int((sizes > 1024).sum()) >= 10          # heavy buckets exist (uniform DNA: max ~25)
     assert E.lookup_mode() == 2
 
 
@@ -66,7 +66,7 @@ def oracle_chunk(lumpy, a, b, rev):
 def test_single_chunk_calls_incl_the_heaviest_against_the_oracle(lumpy, rev):
     E = lumpy["E"]
     ch, hits = chunk_hits(lumpy, rev)
-    assert hits.max() > 1.3 * hits.mean() and hits.min() < 0.7 * hits.mean()   # lumpy over chunks, too
+    assert hits.max() > 1.15 * hits.mean() and hits.min() < 0.5 * hits.mean()   # uneven over chunks, too (N gaps, repeat clusters)
     order = np.argsort(hits)
     picks = [int(order[-1]), int(order[-2]), int(order[len(order) // 2]), int(order[1])]   # heaviest two, a median one, a light one
     n = 0
@@ -103,12 +103,16 @@ def test_twenty_chunk_call_around_the_heaviest_chunk_against_the_oracle(lumpy):
 
 
 def test_the_rare_branches_were_taken(lumpy):
-    """(runs after the calls above) what a skewed k-mer spectrum is there to reach: a chain bucket above its LDS capacity, a dedup
-    segment above the LDS chain's 2048 records (library sorts), a device list regrown and its batch rerun."""
+    """(runs after the calls above) what a skewed k-mer spectrum reaches at workload size, by sa_call_stats.path_flags: a dedup segment
+    above the LDS chain's 2048 records (library sorts + the tiled unique) and a head-bit map regrown for a call denser than 128 hits
+    per position.  Two more branches exist for denser input still -- unmasked microsatellites in bulk put tens of millions of
+    candidates into one call: the chain stages then run slice by slice (SA_PATH_CHAIN_SLICED) and the survivor / candidate lists are
+    regrown (SA_PATH_LIST_REGROWN); a first cut of this generator did exactly that -- and for a chain bucket above its
+    LDS capacity; those are reached by tests/test_gpu_chain.py and tests/test_gpu_edge_cases.py with forced capacities."""
     E, f = lumpy["E"], lumpy["flags"]
     assert f & E.PATH_DEDUP_FALLBACK, f
-    assert f & E.PATH_CHAIN_BUCKET_OVERFLOW, f
-    assert f & E.PATH_LIST_REGROWN, f
+    assert f & E.PATH_HEAD_BITS_REGROWN, f
+    assert not (f & E.PATH_GENERAL_FALLBACK), f
 
 
 def test_repeat_masker_variant_on_the_lumpy_target(oracle, engine, lumpy):

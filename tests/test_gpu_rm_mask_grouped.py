@@ -34,7 +34,7 @@ def rm_case_small_chunks(oracle, engine):
 def test_grouped_chunks_match_the_reference_loop(oracle, rm_case_small_chunks, strands):
     c, E, O = rm_case_small_chunks, rm_case_small_chunks.E, oracle
     L = c.target.size
-    assert E.lib().sa_get_chunks_per_call() == 20 and E.lookup_mode() == 2
+    assert E.get_option("chunks_per_call") == 20 and E.lookup_mode() == 2
     for (s, e, ws, we, M) in ((0, L - 19, 0, L, 1),            # 25 chunks: 16 + 9 (plus), 1 + 16 + 8 (minus)
                               (3000, 195500, 0, L, 2),          # short last chunk -> overlapping minus chunk
                               (10000, 170000, 60000, 140000, 1),  # window inside the interval

@@ -253,6 +253,7 @@ def main():
     if args.chunks_per_call:
         E.set_option("chunks_per_call", args.chunks_per_call)
         E.set_option("call_hits", 0)  # (an explicit grain is kept as it is: no sizing by hits)
+        E.set_option("call_hits_max", 0)
     E.InitializeProcessor(args.workload != "notransition", args.chunk, seed_size, sub_mat, xdrop, hspthresh, False)
 
     t_gen0 = time.time()

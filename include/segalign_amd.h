@@ -145,7 +145,7 @@ typedef struct sa_call_result {
 size_t sa_seed_calls(const sa_call_desc* calls, size_t num_calls, uint32_t buffer, int threads, sa_call_result* results,
                      struct sa_call_stats* totals /* nullable: sums over the calls */);
 /* Seed hits of every call of such a list, WITHOUT filtering or extending them: lookup only (the table-direct position probe and its
- * chunk plans, ~0.2 ms per twenty-chunk call against ~2.6 ms for the call itself).  A multi-GPU host weighs the calls of a pass with
+ * chunk plans, ~0.4 ms per forty-chunk call against ~5 ms for the call itself).  A multi-GPU host weighs the calls of a pass with
  * these counts before it deals them out (longest first); every rank computes the same numbers from the same resident blocks. */
 void sa_count_call_hits(const sa_call_desc* calls, size_t num_calls, uint32_t buffer, int threads, uint64_t* hits);
 
@@ -206,7 +206,9 @@ int sa_max_hits_for_mem(uint64_t total_global_mem);
  *   slots             calls in flight per device (default 4, at most 8; the reference allows 1: its token IS the device).  Every slot
  *                     has its own stream; the library's load-time constructor sets GPU_MAX_HW_QUEUES=8 (unless the variable is
  *                     set) because slots that share one of the runtime's default four hardware queues run one after the other
- *   chunks_per_call   wga_chunk-sized chunks sa_seed_interval / sa_rm_mask_interval hand to one pass (default 20, maximum 32)
+ *   chunks_per_call   wga_chunk-sized chunks sa_seed_interval / sa_rm_mask_interval hand to one pass (default 40: a strand's chunks of a 10 Mbp interval; maximum 256; the repeat masker at most 20).
+ *                     sa_get_chunks_per_call() adapts it to the resident target: more when seed hits are sparse (option call_hits,
+ *                     default 128 M hits per call), fewer when they are dense (option call_hits_max, default 1 G)
  *   no_ctx            1: neighbourhood table without target context (lookup mode 1)
  *   no_td             1: no neighbourhood table (lookup mode 0: seed words -> buckets -> hit list, the reference's shape)
  *   arena_gb          GiB of table arena the engine starts mapping in the background at sa_initialize_processor (default 40:

@@ -72,7 +72,7 @@ size_t sa_seed_and_filter_range(uint32_t start, uint32_t end, int rev, uint32_t 
 int sa_max_chunks_per_call(void) { return SA_MAX_CHUNKS; }
 // What the interval entries hand to one call, and what a host that builds its own call lists should use: option chunks_per_call
 // (default 20), raised for the RESIDENT target when its seed hits are sparse -- a call is sized by hits, not by chunks: option
-// call_hits (default 256 M) / (table entries per key x wga_chunk positions), at most sa_max_chunks_per_call().  With
+// call_hits (default 128 M: beyond that a call no longer gets cheaper per hit, and a pass has too few calls to fill the slots) / (table entries per key x wga_chunk positions), at most sa_max_chunks_per_call().  With
 // --notransition one 250 kbp chunk holds ~1.5 M hits instead of ~19 M: twenty-chunk calls would spend two thirds of their time in
 // per-call fixed costs.
 int sa_get_chunks_per_call(void) {
@@ -84,6 +84,10 @@ int sa_get_chunks_per_call(void) {
             const double per_chunk = std::max(1.0, per_pos * (double)g_wga_chunk);
             const double want = (double)g_call_hits / per_chunk;
             if (want > (double)k) k = (int)std::min<double>(want, (double)SA_MAX_CHUNKS);
+            // ... and lowered when they are dense (a 500 Mbp target block: ~70 M hits per chunk): a call stays below ~option
+            // call_hits_max = 1 G hits by this estimate (its lists are sized by its hits; 2^32 is the hard limit of a pass)
+            const double most = (double)g_call_hits_max / per_chunk;
+            if (g_call_hits_max > 0 && most < (double)k) k = (int)std::max(1.0, most);
         }
     }
     return k;

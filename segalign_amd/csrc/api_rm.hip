@@ -162,8 +162,9 @@ size_t sa_rm_mask_interval(uint32_t start_pos, uint32_t end_pos, uint32_t ref_st
     int path = 0;
     // The reference walks the plus-strand chunks and derives a minus-strand chunk from each (:73-150).  Coverage counting is
     // order independent and every chunk keeps its own iteration plan and dedup scope, so the chunks of a strand are grouped:
-    // consecutive chunks that tile a range go through ONE table-direct pass (up to g_chunks_per_call of them), the rest --
+    // consecutive chunks that tile a range go through ONE table-direct pass (up to min(chunks_per_call, 20) of them), the rest --
     // the minus-strand chunk of a short last plus chunk overlaps its neighbour (:118-119) -- go on their own.
+    const int rm_group = std::min(g_chunks_per_call, 20);  // (a self-alignment is hit-dense: twenty chunks are ~0.5 G hits)
     struct Range { uint32_t s0, s1; };
     for (int rev = 0; rev < 2; rev++) {
         if (!(strands & (rev ? SA_STRAND_MINUS : SA_STRAND_PLUS))) continue;
@@ -186,7 +187,7 @@ size_t sa_rm_mask_interval(uint32_t start_pos, uint32_t end_pos, uint32_t ref_st
         size_t a = 0;
         while (a < rs.size()) {
             size_t b = a + 1;
-            while (td_ok && b < rs.size() && (int)(b - a) < g_chunks_per_call && rs[b].s0 == rs[b - 1].s1) b++;
+            while (td_ok && b < rs.size() && (int)(b - a) < rm_group && rs[b].s0 == rs[b - 1].s1) b++;
             int Kc = (int)(b - a);
             uint32_t bp[SA_MAX_CHUNKS + 1];
             for (int c = 0; c < Kc; c++) bp[c] = rs[a + c].s0;

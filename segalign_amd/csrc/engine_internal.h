@@ -215,7 +215,7 @@ extern uint32_t SPEC_RECS;        // records of the speculative output copy (256
 extern uint32_t g_dedup_seg_max;  // option dedup_seg_max: records per segment the LDS chain accepts (0 = its LDS capacity; tests)
 constexpr int SA_MAX_CHUNKS = 256;  // chunks one multi-chunk call may carry: 2 reference iterations each = MAX_SEGS segments
 constexpr int SA_MAX_CHUNKS_GENERAL = 32;  // ... when it takes the general path (per-chunk iteration plans of up to 1000 iterations each)
-constexpr int SA_DEFAULT_CHUNKS = 20;  // ... and what the interval entries hand to one call: the 40 chunks of a 10 Mbp strand go as 20 + 20
+constexpr int SA_DEFAULT_CHUNKS = 40;  // ... and what the interval entries hand to one call: the 40 chunks of a strand of a 10 Mbp interval
 extern int SLOTS_PER_DEVICE;  // calls in flight per device (the reference allows one: token == device); option slots
 
 struct Counters {  // device-side scalars of one slot
@@ -409,7 +409,7 @@ extern int g_fast_filter;
 extern int g_packed_filter;
 extern int g_chain_sort_threads;
 extern int g_chunks_per_call;
-extern int64_t g_call_hits;
+extern int64_t g_call_hits, g_call_hits_max;
 extern int g_no_small_dedup;
 extern int g_ctx;
 extern uint32_t g_audit_cap;

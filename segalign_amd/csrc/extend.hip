@@ -1299,7 +1299,7 @@ constexpr uint32_t CHAIN_WALK_EXTRA = 96; // bases walked past the predecessor's
 // quadratic rank sort is a few microseconds; all buckets together are the candidate list with every diagonal's
 // candidates contiguous and ordered by position -- exactly what the link test needs.  No host involvement.
 constexpr uint32_t CHAIN_BUCKETS_MIN = 16384, CHAIN_BUCKETS_MAX = 262144;  // the host picks a power of two from the batch's hits (ExtendArgs.chain_buckets)
-constexpr uint32_t CHAIN_SORT_MAX = 1024;  // entries a bucket may hold and still be sorted (8 KB of LDS); larger: left unsorted,
+constexpr uint32_t CHAIN_SORT_MAX = 4096;  // entries a bucket may hold and still be sorted (its keys fill the workgroup's LDS); larger: left unsorted,
                                            // which only makes link tests fail, i.e. costs extensions, never correctness
 
 // A bucket = hash of (iteration, diagonal, 512-position window): one diagonal can carry every candidate of a call (a
@@ -1399,7 +1399,7 @@ __global__ __launch_bounds__(256) void chain_scatter_kernel(ExtendArgs a) {
 // sorted list less).  The sorted order is kept as a permutation in LDS; the records are read from the scatter's output and
 // written in order, coalesced.
 constexpr uint32_t CHAIN_SORT_GROUP = 8;
-constexpr uint32_t CHAIN_GROUP_MAX = CHAIN_SORT_GROUP * CHAIN_SORT_MAX / 2;  // entries of a group the LDS holds (32 KB of keys)
+constexpr uint32_t CHAIN_GROUP_MAX = CHAIN_SORT_MAX;  // entries the workgroup's LDS holds at a time (32 KB of keys): a whole group usually
 
 // does candidate c start a run?  (test (L) of DESIGN.md 4.5' against its predecessor pc on the same diagonal, bounded walk)
 template <bool XDROP_NONNEG>
@@ -1439,59 +1439,68 @@ __global__ __launch_bounds__(512) void chain_sort_link_kernel(ExtendArgs a) {
     if (threadIdx.x < 128) s_tab[threadIdx.x] = threadIdx.x < 64 ? a.sub_mat[threadIdx.x] : NEG;
     if (threadIdx.x <= CHAIN_SORT_GROUP) s_b[threadIdx.x] = a.chain_bucket_start[blockIdx.x * CHAIN_SORT_GROUP + threadIdx.x];
     __syncthreads();
-    const uint32_t g0 = s_b[0], m_all = s_b[CHAIN_SORT_GROUP] - g0;
-    if (m_all == 0) return;
+    if (s_b[CHAIN_SORT_GROUP] == s_b[0]) return;
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
-    bool big = m_all > CHAIN_GROUP_MAX;  // (a bucket above CHAIN_SORT_MAX, or a group that does not fit: left unsorted, every entry a run head)
-    for (uint32_t j = 0; j < CHAIN_SORT_GROUP; j++) big = big || (s_b[j + 1] - s_b[j]) > CHAIN_SORT_MAX;
-    if (!big) {
-        for (uint32_t i = threadIdx.x; i < m_all; i += blockDim.x) s_key[i] = chain_key(a, s_seg, a.chain_tmp[g0 + i]);
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < m_all; i += blockDim.x) {
-            uint32_t j = 0;  // the entry's bucket inside the group
-            while (g0 + i >= s_b[j + 1]) j++;
-            const uint32_t lo = s_b[j] - g0, hi = s_b[j + 1] - g0;
-            const unsigned long long k = s_key[i];
-            // rank = entries below this one; keys are unique per hit, and hand-made ties (a foreign host's duplicate seed words) are
-            // broken by the index: "<=" before i, "<" behind it -- one compare + one add-with-carry per entry either way
-            uint32_t rank = 0;
-#pragma unroll 4
-            for (uint32_t t = lo; t < i; t++) rank += s_key[t] <= k ? 1u : 0u;
-#pragma unroll 4
-            for (uint32_t t = i + 1; t < hi; t++) rank += s_key[t] < k ? 1u : 0u;
-            s_perm[lo + rank] = (uint16_t)i;
-        }
-        __syncthreads();
-    } else if (threadIdx.x == 0 && a.chain_big) {
-        atomicAdd(a.chain_big, 1u);
-    }
     const uint8_t* __restrict__ R8b = a.ref8 - BIAS;
     const uint8_t* __restrict__ Qb = a.query - BIAS;
-    const uint32_t rounds = (m_all + blockDim.x - 1) / blockDim.x;  // wave-uniform trip count (ballot below)
-    for (uint32_t r = 0; r < rounds; r++) {
-        const uint32_t p = r * blockDim.x + threadIdx.x;  // sorted position inside the group
-        bool head = false;
-        if (p < m_all) {
-            const CandRec c = a.chain_tmp[g0 + (big ? p : (uint32_t)s_perm[p])];
-            a.chain_sorted[g0 + p] = c;
-            head = true;
-            if (!big) {
-                uint32_t j = 0;
-                while (g0 + p >= s_b[j + 1]) j++;
-                if (g0 + p > s_b[j]) head = chain_is_run_head<XDROP_NONNEG>(a, s_seg, s_tab, R8b, Qb, c, a.chain_tmp[g0 + (uint32_t)s_perm[p - 1]]);
+    // The group is handled in pieces of consecutive buckets that fit the LDS together (usually the whole group at once; a group of
+    // crowded buckets -- sparse-hit calls carry 3 % candidates -- goes bucket by bucket).  Only a single bucket above the LDS
+    // capacity is left unsorted, every entry of it a run head (costs extensions, never results).
+    for (uint32_t ja = 0; ja < CHAIN_SORT_GROUP;) {
+        uint32_t jb = ja + 1;
+        while (jb < CHAIN_SORT_GROUP && s_b[jb + 1] - s_b[ja] <= CHAIN_GROUP_MAX) jb++;
+        const uint32_t g0 = s_b[ja], m_all = s_b[jb] - g0;
+        const bool big = m_all > CHAIN_GROUP_MAX;  // (then jb == ja + 1: one bucket that does not fit)
+        if (m_all == 0) { ja = jb; continue; }
+        if (!big) {
+            for (uint32_t i = threadIdx.x; i < m_all; i += blockDim.x) s_key[i] = chain_key(a, s_seg, a.chain_tmp[g0 + i]);
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < m_all; i += blockDim.x) {
+                uint32_t j = ja;  // the entry's bucket
+                while (g0 + i >= s_b[j + 1]) j++;
+                const uint32_t lo = s_b[j] - g0, hi = s_b[j + 1] - g0;
+                const unsigned long long k = s_key[i];
+                // rank = entries below this one; keys are unique per hit, and hand-made ties (a foreign host's duplicate seed words) are
+                // broken by the index: "<=" before i, "<" behind it -- one compare + one add-with-carry per entry either way
+                uint32_t rank = 0;
+#pragma unroll 4
+                for (uint32_t t = lo; t < i; t++) rank += s_key[t] <= k ? 1u : 0u;
+#pragma unroll 4
+                for (uint32_t t = i + 1; t < hi; t++) rank += s_key[t] < k ? 1u : 0u;
+                s_perm[lo + rank] = (uint16_t)i;
             }
-            a.chain_is_head[g0 + p] = head ? 1u : 0u;
+            __syncthreads();
+        } else if (threadIdx.x == 0 && a.chain_big) {
+            atomicAdd(a.chain_big, 1u);
         }
-        // run heads -> head list (order irrelevant)
-        const unsigned long long m = __ballot(head);
-        if (m) {
-            const int leader = __ffsll((long long)m) - 1;
-            uint32_t wbase = 0;
-            if (lane == leader) wbase = atomicAdd(a.chain_head_count, (uint32_t)__popcll(m));
-            wbase = (uint32_t)__builtin_amdgcn_readlane((int)wbase, leader);
-            if (head) a.chain_heads[wbase + (uint32_t)__popcll(m & lane_lt)] = g0 + p;
+        const uint32_t rounds = (m_all + blockDim.x - 1) / blockDim.x;  // wave-uniform trip count (ballot below)
+        for (uint32_t r = 0; r < rounds; r++) {
+            const uint32_t p = r * blockDim.x + threadIdx.x;  // sorted position inside the piece
+            bool head = false;
+            if (p < m_all) {
+                const CandRec c = a.chain_tmp[g0 + (big ? p : (uint32_t)s_perm[p])];
+                a.chain_sorted[g0 + p] = c;
+                head = true;
+                if (!big) {
+                    uint32_t j = ja;
+                    while (g0 + p >= s_b[j + 1]) j++;
+                    if (g0 + p > s_b[j]) head = chain_is_run_head<XDROP_NONNEG>(a, s_seg, s_tab, R8b, Qb, c, a.chain_tmp[g0 + (uint32_t)s_perm[p - 1]]);
+                }
+                a.chain_is_head[g0 + p] = head ? 1u : 0u;
+            }
+            // run heads -> head list (order irrelevant)
+            const unsigned long long m = __ballot(head);
+            if (m) {
+                const int leader = __ffsll((long long)m) - 1;
+                uint32_t wbase = 0;
+                if (lane == leader) wbase = atomicAdd(a.chain_head_count, (uint32_t)__popcll(m));
+                wbase = (uint32_t)__builtin_amdgcn_readlane((int)wbase, leader);
+                if (head) a.chain_heads[wbase + (uint32_t)__popcll(m & lane_lt)] = g0 + p;
+            }
         }
+        __syncthreads();  // (the next piece reuses the LDS)
+        ja = jb;
     }
 }
 

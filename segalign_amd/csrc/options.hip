@@ -39,7 +39,8 @@ int g_max_waves = 4096;    // SEGALIGN_AMD_MAX_WAVES: waves of the filter kernel
 int g_fast_filter = 0;     // derived in InitializeProcessor: xdrop >= 0 && 7*max(M) <= xdrop
 int g_packed_filter = 0;   // derived in InitializeProcessor: the packed upper-bound filter may be used
 int g_chain_sort_threads = 256;  // SEGALIGN_AMD_CHAIN_SORT_THREADS
-int64_t g_call_hits = 256ll << 20;  // option call_hits: seed hits a call is sized for when the resident target's hits are sparse (0: chunks_per_call only)
+int64_t g_call_hits_max = 1ll << 30;  // option call_hits_max
+int64_t g_call_hits = 128ll << 20;  // option call_hits: seed hits a call is sized for when the resident target's hits are sparse (0: chunks_per_call only)
 int g_chunks_per_call = SA_DEFAULT_CHUNKS;  // SEGALIGN_AMD_CHUNKS_PER_CALL: chunks sa_seed_interval hands to one multi-chunk call
 int g_no_small_dedup = 0;  // SEGALIGN_AMD_NO_SMALL_DEDUP=1: always use the library sorts
 int g_ctx = 1;             // neighbourhood table with target context when it fits (SEGALIGN_AMD_NO_CTX=1: positions only)
@@ -105,7 +106,8 @@ static Option g_opts[] = {
     // deployment
     {"slots", 4, 1, MAX_SLOTS_PER_DEVICE, 0},          // calls in flight per device (the reference allows one: token == device)
     {"chunks_per_call", SA_DEFAULT_CHUNKS, 1, SA_MAX_CHUNKS, 0},  // chunks sa_seed_interval / sa_rm_mask_interval hand to one pass
-    {"call_hits", 256 << 20, 0, 1ll << 31, 0},        // seed hits a call is sized for when hits are sparse: chunks per call = max(chunks_per_call, call_hits / hits per chunk)
+    {"call_hits", 128 << 20, 0, 1ll << 31, 0},
+    {"call_hits_max", 1 << 30, 0, 1ll << 32, 0},      // ... and lowered when they are dense: chunks per call <= call_hits_max / estimated hits per chunk (0: no cap)        // seed hits a call is sized for when hits are sparse: chunks per call = max(chunks_per_call, call_hits / hits per chunk)
     {"no_ctx", 0, 0, 1, 0},                            // 1: neighbourhood table without target context (lookup mode 1)
     {"no_td", 0, 0, 1, 0},                             // 1: no neighbourhood table at all (lookup mode 0, the reference-shaped path)
     {"no_chain", 0, 0, 1, 0},                          // 1: every candidate is extended on its own (no chain shortcut)
@@ -152,6 +154,7 @@ void resolve_options() {
     SLOTS_PER_DEVICE = (int)opt_value("slots");
     g_chunks_per_call = (int)opt_value("chunks_per_call");
     g_call_hits = opt_value("call_hits");
+    g_call_hits_max = opt_value("call_hits_max");
     g_ctx = opt_value("no_ctx") ? 0 : 1;
     g_td = opt_value("no_td") ? 0 : 1;
     g_chain = opt_value("no_chain") ? 0 : 1;

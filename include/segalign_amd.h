@@ -148,6 +148,9 @@ size_t sa_seed_calls(const sa_call_desc* calls, size_t num_calls, uint32_t buffe
  * chunk plans, ~0.4 ms per forty-chunk call against ~5 ms for the call itself).  A multi-GPU host weighs the calls of a pass with
  * these counts before it deals them out (longest first); every rank computes the same numbers from the same resident blocks. */
 void sa_count_call_hits(const sa_call_desc* calls, size_t num_calls, uint32_t buffer, int threads, uint64_t* hits);
+/* ... and per wga_chunk piece: chunk_hits[i * sa_max_chunks_per_call() + c] = hits of chunk c of call i (same lookups, no more launches) */
+void sa_count_chunk_hits(const sa_call_desc* calls, size_t num_calls, uint32_t buffer, int threads, uint64_t* hits, uint64_t* chunk_hits);
+uint32_t sa_get_wga_chunk(void); /* the chunk size InitializeProcessor was given */
 
 /* ---- repeat-masker variant (repeat_masker_src/seed_filter.h:4-8) ----------------------------------------- */
 

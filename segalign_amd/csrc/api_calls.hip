@@ -311,11 +311,12 @@ size_t sa_seed_calls(const sa_call_desc* calls, size_t num_calls, uint32_t buffe
 }
 
 // The seed hits of every call of a list, lookup only (see the header): what a multi-GPU host weighs the calls of a pass with.
-void sa_count_call_hits(const sa_call_desc* calls, size_t num_calls, uint32_t buffer, int threads, uint64_t* hits) {
+void sa_count_chunk_hits(const sa_call_desc* calls, size_t num_calls, uint32_t buffer, int threads, uint64_t* hits, uint64_t* chunk_hits) {
     require_proc("CountCallHits", buffer);
     run_parallel(num_calls, threads, [&](size_t i) {
         const sa_call_desc& c = calls[i];
         hits[i] = 0;
+        uint64_t* per_chunk = chunk_hits ? chunk_hits + i * (size_t)SA_MAX_CHUNKS : nullptr;
         const uint32_t chunk = g_wga_chunk;
         const int K = c.end > c.start ? (int)(((uint64_t)c.end - c.start + chunk - 1) / chunk) : 0;
         if (K == 0) return;
@@ -338,6 +339,7 @@ void sa_count_call_hits(const sa_call_desc* calls, size_t num_calls, uint32_t bu
             ns = td_front(dc, sl, q, K, bpos, 0, &words);
         if (ns != 0xFFFFFFFFu) {
             if (ns > 0) hits[i] = sl->h_td_plan[K - 1].hit_base + sl->h_td_plan[K - 1].num_hits;
+            if (per_chunk) for (int k = 0; k < K; k++) per_chunk[k] = ns > 0 ? sl->h_td_plan[k].num_hits : 0;
             prof_flush(sl);
             release_slot(sl);
             return;
@@ -348,10 +350,17 @@ void sa_count_call_hits(const sa_call_desc* calls, size_t num_calls, uint32_t bu
         sa_segment_pair* res[SA_MAX_CHUNKS];
         size_t cnt[SA_MAX_CHUNKS];
         sa_seed_and_filter_chunks(c.start, c.end, rev, buffer, res, cnt);
-        for (int k = 0; k < K; k++) free(res[k]);
+        for (int k = 0; k < K; k++) {
+            if (per_chunk) per_chunk[k] = cnt[k] ? (uint64_t)(uint32_t)res[k][0].score : 0;  // (header: the chunk's hit count, :806-809)
+            free(res[k]);
+        }
         hits[i] = t_stats.num_hits;
     });
 }
+void sa_count_call_hits(const sa_call_desc* calls, size_t num_calls, uint32_t buffer, int threads, uint64_t* hits) {
+    sa_count_chunk_hits(calls, num_calls, buffer, threads, hits, nullptr);
+}
+uint32_t sa_get_wga_chunk(void) { return g_wga_chunk; }
 
 size_t sa_device_make_seeds(uint32_t start, uint32_t end, int rev, uint32_t buffer, uint64_t* dst, size_t cap) {
     require_proc("DeviceMakeSeeds", buffer);

@@ -103,7 +103,7 @@ int sa_initialize_interface(int num_gpu) {  // seed_filter_interface.cu:49-80
         check_set_device(ord, "InitializeInterface");
         int twin = 0;  // how many earlier engine devices sit on the same ordinal (sa_select_devices with a repeated id)
         for (int h = 0; h < g; h++) if (!g_selected.empty() && g_selected[h] == ord) twin++;
-        DevCtx* dc = new DevCtx(arena_of(ord + 64 * twin, ord));
+        DevCtx* dc = new DevCtx(arena_of(ord + 64 * twin, ord), arena_of(1024 + ord + 64 * twin, ord));
         dc->dev = ord;
         dc->index = g;
         hipStreamCreateWithFlags(&dc->admin, hipStreamNonBlocking);
@@ -152,8 +152,15 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
         check_set_device(dc->dev, "InitializeProcessor");
         if (!dc->d_sub_mat) dc->d_sub_mat = (int*)dev_malloc(64 * sizeof(int), "sub_mat");
         check_memcpy(hipMemcpy(dc->d_sub_mat, g_sub_mat, 64 * sizeof(int), hipMemcpyHostToDevice), "sub_mat");
+        // the work arena first (it is what the first calls need), then the table arena; both are mapped in the background while the
+        // host reads its FASTA files (src/main.cpp:300-549) and both stay with the process
+        const size_t work_per_slot = (size_t)opt_value("work_gb") << 30;
+        if (work_per_slot && g_td && g_packed_filter) arena_request(dc->work_arena, work_per_slot * (size_t)SLOTS_PER_DEVICE);
         for (int k = 0; k < SLOTS_PER_DEVICE; k++) {
             if (!dc->slots[k].stream) slot_init(dc->slots[k], dc);
+            dc->slots[k].work.arena = work_per_slot ? &dc->work_arena : nullptr;
+            dc->slots[k].work.off = (size_t)k * work_per_slot;
+            dc->slots[k].work.size = work_per_slot;
             dc->slots[k].seeds.ensure((size_t)g_max_seeds, "seed_offsets");
         }
         if (!opt_value("arena_vmm") && arena_mapped(dc->arena) == 0) {  // (A/B switch: one plain hipMalloc per growth instead of mapped chunks)
@@ -196,7 +203,7 @@ static void release_device_state(DevCtx* dc) {
     nbr_release(dc);
     // (the table arena stays mapped: it is a process-wide cache of cleared device pages that cost seconds to get; its background
     //  worker is stopped here.  Option arena_gb = 0 gives the pages back now, sa_release_arena() whenever the host wants them)
-    if (g_arena_gb == 0) arena_destroy(dc->arena);
+    if (g_arena_gb == 0) { arena_destroy(dc->arena); arena_destroy(dc->work_arena); }
     dev_free(dc->bucket_start, "d_index_table");
     dev_free(dc->pos_table, "d_pos_table");
     dc->bucket_start = dc->pos_table = nullptr;
@@ -349,6 +356,7 @@ void sa_generate_seed_pos_table(const char* ref_str, size_t start_addr, uint32_t
         dev_free(dc->pos_table, "d_pos_table");
         dc->bucket_start = (uint32_t*)dev_malloc(((size_t)nkeys + 1) * sizeof(uint32_t), "index_table");
         uint32_t num_index = 0;
+        bool built = false;
         if (table_partition_build_supported(kmer_size) && !g_table_atomic) {
             // PARTITION build (table.hip): keys + coarse histogram -> offsets of the 4096 coarse partitions -> two LDS-staged
             // partition passes -> one workgroup per partition finishes its slice of bucket_start and pos_table in LDS
@@ -358,7 +366,9 @@ void sa_generate_seed_pos_table(const char* ref_str, size_t start_addr, uint32_t
             uint32_t* part_start = coarse + pw;
             uint32_t* cursor = part_start + pw;
             uint8_t* part_unsorted = reinterpret_cast<uint8_t*>(cursor + pw);
-            void* scan_tmp = dev_malloc(scan_temp_bytes(pw), "scan temp");
+            const size_t fw = table_partition_fine_words(kmer_size);  // (keys above 24 bits -- 14of22 -- take a third partition level)
+            uint32_t* fine = fw ? (uint32_t*)dev_malloc(fw * sizeof(uint32_t), "fine partitions") : nullptr;
+            void* scan_tmp = dev_malloc(scan_temp_bytes(std::max<size_t>(pw, (size_t)1 << 18)), "scan temp");
             check_memcpy(hipMemsetAsync(coarse, 0, pw * sizeof(uint32_t), st), "coarse histogram");
             launch_table_keys(codes, num_steps, start_offset, step, sh, keys, coarse, st);
             launch_exclusive_scan_u32(coarse, part_start, pw - 1, scan_tmp, st);
@@ -368,15 +378,26 @@ void sa_generate_seed_pos_table(const char* ref_str, size_t start_addr, uint32_t
             const size_t np = std::max<uint32_t>(num_index, 1);
             dc->pos_table = (uint32_t*)dev_malloc(np * sizeof(uint32_t), "pos_table");
             uint32_t* pairs = (uint32_t*)dev_malloc(4 * np * sizeof(uint32_t), "partition pairs");  // key_a | pos_a | key_b | pos_b
+            uint32_t* d_err = nullptr;
+            uint32_t err = 0;
             launch_table_partition_build(keys, num_steps, start_offset, step, kmer_size, part_start, num_index, cursor, pairs, pairs + np,
-                                         pairs + 2 * np, pairs + 3 * np, part_unsorted, dc->bucket_start, dc->pos_table, st);
+                                         pairs + 2 * np, pairs + 3 * np, part_unsorted, dc->bucket_start, dc->pos_table, fine, scan_tmp, &d_err, st);
             check_launch("table partition");
+            if (d_err) check_memcpy(hipMemcpyAsync(&err, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, st), "partition flag");
             check_sync(st, "table partition");
             dev_free(pairs, "partition pairs");
             dev_free(keys, "kmer keys");
             dev_free(coarse, "coarse histogram");
+            dev_free(fine, "fine partitions");
             dev_free(scan_tmp, "scan temp");
-        } else {
+            built = err == 0;  // (a tile of the third level spanned too many coarse groups -- a tiny or wildly skewed table: atomic build)
+            if (!built) {
+                dev_free(dc->pos_table, "d_pos_table");
+                dc->pos_table = nullptr;
+                if (opt_value("debug")) fprintf(stderr, "seed table: the partition build gave up on this table, atomic build instead\n");
+            }
+        }
+        if (!built) {
             // ATOMIC build: histogram + scatter with one global atomic per position (any seed weight)
             uint32_t* hist = (uint32_t*)dev_malloc(((size_t)nkeys + 1) * sizeof(uint32_t), "kmer histogram");
             void* scan_tmp = dev_malloc(scan_temp_bytes(nkeys), "scan temp");

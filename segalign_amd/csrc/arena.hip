@@ -139,6 +139,17 @@ size_t arena_mapped(Arena& A) {
 static std::mutex g_arenas_mu;
 static std::vector<Arena*> g_arenas;  // (never destroyed: a worker thread may outlive static destruction)
 
+void* WorkRegion::take(size_t bytes) {
+    if (!arena || !size) return nullptr;
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (used + need > size) return nullptr;
+    std::lock_guard<std::mutex> lk(arena->mu);
+    if (!arena->vmm || !arena->base || arena->mapped < off + used + need) return nullptr;  // (not there yet: the caller allocates)
+    void* p = arena->base + off + used;
+    used += need;
+    return p;
+}
+
 static void arena_stop_worker(Arena& A) {  // the worker finishes the chunk it is on and goes away; what is mapped stays
     std::unique_lock<std::mutex> lk(A.mu);
     A.stop = true;

@@ -76,26 +76,44 @@ static inline void check_sync(hipStream_t s, const char* tag) {
     if (e != hipSuccess) die(15, "hipStreamSynchronize", tag, e);
 }
 
+// A slot's share of the WORK ARENA (arena.hip): device memory that is already mapped and page-cleared when the first calls arrive.
+// A fresh hipMalloc costs 25-60 ms per GiB on this platform, and the first pass after engine start allocated ~3 GB per slot inside
+// its calls (140-180 ms instead of 95); buffers attached to a region carve their memory out of it instead (bump
+// allocation: a buffer that regrows abandons its old piece until the slot is destroyed) and fall back to hipMalloc when the region
+// is exhausted or not mapped yet.
+struct Arena;
+struct WorkRegion {
+    Arena* arena = nullptr;
+    size_t off = 0, size = 0, used = 0;  // [off, off + size) of the arena's range
+    void* take(size_t bytes);            // nullptr: no room (or that part of the arena is not mapped yet)
+};
+
 template <typename T>
 struct DevBuf {  // grow-only device buffer
     T* p = nullptr;
     size_t cap = 0;  // elements
+    WorkRegion* region = nullptr;  // (optional) where the memory comes from
+    bool in_region = false;
     void ensure(size_t n, const char* tag, bool keep = false, hipStream_t s = 0) {
         if (n <= cap) return;
         size_t ncap = std::max(n, cap + cap / 2);
-        T* np = (T*)dev_malloc(ncap * sizeof(T), tag);
+        T* np = region ? (T*)region->take(ncap * sizeof(T)) : nullptr;
+        const bool nr = np != nullptr;
+        if (!np) np = (T*)dev_malloc(ncap * sizeof(T), tag);
         if (keep && p && cap) {
             check_memcpy(hipMemcpyAsync(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice, s), tag);
             check_sync(s, tag);
         }
-        dev_free(p, tag);
+        if (!in_region) dev_free(p, tag);
         p = np;
         cap = ncap;
+        in_region = nr;
     }
     void release(const char* tag) {
-        dev_free(p, tag);
+        if (!in_region) dev_free(p, tag);
         p = nullptr;
         cap = 0;
+        in_region = false;
     }
 };
 
@@ -291,6 +309,7 @@ struct Slot {
     std::vector<ProfRec> prof_pending;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
     size_t events_used = 0;
+    WorkRegion work;                  // this slot's share of the device's work arena
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -363,9 +382,10 @@ struct DevCtx {
     uint64_t* nbr_start = nullptr;       // nkeys + 1
     uint32_t* nbr_pos = nullptr;         // == pos_table when no transition word exists (nbr_alias); null when nbr_ctx is built
     CtxRec* nbr_ctx = nullptr;           // the runs WITH their target context: 32-byte records in the arena (class filter, extend.hip 1d)
+    Arena& work_arena;                   // cleared device memory for the slots' work buffers (WorkRegion), mapped in the background like `arena`
     Arena& arena;                        // memory of the context table: outlives target blocks AND engine contexts (a process-wide
                                          // cache per device ordinal, see arena_of), grown in the background
-    explicit DevCtx(Arena& a) : arena(a) {}
+    DevCtx(Arena& a, Arena& w) : work_arena(w), arena(a) {}
     bool nbr_alias = false;
     uint64_t nbr_total = 0;
     uint32_t nbr_tmask = 0;

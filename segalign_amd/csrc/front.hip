@@ -148,7 +148,8 @@ bool ensure_nbr(DevCtx* dc) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = total_b = 0;  // (then only the plain lookup modes are tried)
     // keep room for the slots' work buffers: at human-scale hit density a sixteen-chunk call holds ~6 GB of lists per slot
-    const size_t reserve = ((size_t)8 << 30) + ((size_t)4 << 30) * (size_t)SLOTS_PER_DEVICE;
+    size_t reserve = ((size_t)8 << 30) + ((size_t)4 << 30) * (size_t)SLOTS_PER_DEVICE;
+    reserve -= std::min(reserve / 2, arena_mapped(dc->work_arena));  // (what the work arena holds IS part of that room)
     const size_t need_pos = (size_t)std::max<uint64_t>(total, 1) * sizeof(uint32_t);
     // context records (class filter): 32 bytes per entry; the two-stage fill wants num_index records of scratch behind them, which is
     // given up (one-stage fill) when only the table itself fits.  (+ 16 KB of slack: the filter requests two buffers ahead, so

@@ -233,7 +233,8 @@ void launch_table_keys(const uint8_t* ref, uint32_t num_steps, uint32_t start_of
 void launch_table_partition_build(const uint32_t* keys, uint32_t num_steps, uint32_t start_offset, uint32_t step, int weight,
                                   const uint32_t* part_start /* 4097 */, uint32_t num_index, uint32_t* cursor /* 4096 */, uint32_t* key_a,
                                   uint32_t* pos_a, uint32_t* key_b, uint32_t* pos_b, uint8_t* part_unsorted /* 4096 */,
-                                  uint32_t* bucket_start, uint32_t* pos_table, hipStream_t s);
+                                  uint32_t* bucket_start, uint32_t* pos_table, uint32_t* fine, void* scan_tmp, uint32_t** err_flag, hipStream_t s);
+size_t table_partition_fine_words(int weight);
 
 // ---- seeds.hip -------------------------------------------------------------------------------------------------
 // device-side seeder: valid flags for query positions [start,end), then ordered emission

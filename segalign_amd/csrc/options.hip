@@ -114,6 +114,7 @@ static Option g_opts[] = {
     {"no_packed_filter", 0, 0, 1, 0},                  // 1: byte-coded filter kernels only (also disables table-direct lookup)
     {"no_fast_filter", 0, 0, 1, 0},                    // 1: exact per-base filter only
     {"arena_gb", 40, 0, 1024, 0},                      // GiB of table arena mapped in the background from InitializeProcessor on
+    {"work_gb", 3, 0, 64, 0},                          // GiB of work arena per slot, mapped in the background from InitializeProcessor on (0: the slots' buffers are plain allocations)
     {"arena_vmm", 1, 0, 1, 0},                         // 0: the table arena is one plain hipMalloc per growth (A/B against the mapped 1 GiB chunks)
     {"debug", 0, 0, 2, 0},                             // 1: table-build timings on stderr; 2: + sync and name every kernel scope
     // launch geometry (swept by tools/sweep_*.sh; the defaults are the measured optima)

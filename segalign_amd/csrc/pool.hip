@@ -29,6 +29,15 @@ void release_slot(Slot* s) {  // src/seed_filter.cu:798-803
 void slot_init(Slot& s, DevCtx* dc) {
     s.dev = dc->dev;
     s.ctx = dc;
+    // the table-direct path's large buffers come out of the slot's work region when it has room (WorkRegion, engine_internal.h)
+    s.work.used = 0;
+    s.td_toff.region = s.td_tcnt.region = s.td_bits.region = s.chain_is_head.region = s.chain_heads.region = &s.work;
+    s.td_rec.region = &s.work;
+    s.td_partial.region = &s.work;
+    s.recA.region = &s.work;
+    s.l2_list.region = &s.work;
+    s.cand_list.region = s.chain_tmp.region = s.chain_sorted.region = &s.work;
+    s.ent_list.region = &s.work;
     hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
     s.d_plan = (IterPlan*)dev_malloc(sizeof(IterPlan) * SA_MAX_CHUNKS_GENERAL, "plan");
     s.d_seg_end = (uint64_t*)dev_malloc(sizeof(uint64_t) * MAX_SEGS, "segment ends");
@@ -89,6 +98,7 @@ void slot_destroy(Slot& s) {
     if (s.h_out) hipHostFree(s.h_out);
     s.h_plan = nullptr; s.h_cnt = nullptr; s.h_seeds = nullptr; s.h_out = nullptr;
     s.h_seeds_cap = s.h_out_cap = 0;
+    s.work.used = 0;
     for (auto& e : s.event_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     s.event_pool.clear();
     if (s.stream) hipStreamDestroy(s.stream);

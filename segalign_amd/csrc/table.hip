@@ -116,6 +116,7 @@ constexpr int TB_COARSE_BITS = 12;                    // coarse partitions = top
 constexpr int TB_PART_THREADS = 1024;
 constexpr int TB_PART_TILE = 8192;                    // elements per partition tile (64 KB of staged pairs)
 constexpr uint32_t TB_FIN_CAP = 22528;                // positions a coarse partition may hold and still be finished in LDS (88 KB)
+constexpr uint32_t TB_FIN_CAP_FINE = 8192;            // ... a fine partition of the three-level build (keys above 24 bits)
 
 // k-mers -> keys[], coarse histogram (top TB_COARSE_BITS bits of the key) privatised in LDS
 __global__ __launch_bounds__(TB_KEYS_THREADS) void table_keys_kernel(const uint8_t* __restrict__ ref, uint32_t num_steps, uint32_t start_offset,
@@ -231,13 +232,123 @@ __global__ __launch_bounds__(TB_PART_THREADS) void table_partition_kernel(const 
     }
 }
 
+// ---- keys of more than 24 bits (14of22: 28): a THIRD partition level ---------------------------------------------------------------
+// The finish kernel keeps a partition's fine histogram in LDS (<= 4096 bins), so 28-bit keys need 2^16 or more partitions.  After the
+// two passes above the pairs are grouped by their top 12 key bits; each of those 4096 groups is cut once more by its next 6 bits:
+//   table_subhist_kernel      one workgroup per 12-bit group: histogram of the next TB_FINE_SUB bits in LDS -> hist18[group * 64 + b]
+//   (scan of the 2^18 counts = the offsets of the 2^18 fine partitions)
+//   table_partition_rel_kernel  the partition pass again, with bins counted RELATIVE to the tile's first 12-bit group: a tile of 8192
+//                             consecutive pairs spans a few groups (the input is grouped by them), i.e. a few x 64 bins; a tile that
+//                             spans 64 groups or more -- a tiny or wildly skewed table -- raises a flag and the host falls back to the
+//                             atomic build
+// and the finish kernel then runs once per FINE partition (~300 positions of a 100 Mbp block, 1024 bins of 10 low bits).
+constexpr int TB_FINE_SUB = 6;
+constexpr int TB_FINE_BITS = TB_COARSE_BITS + TB_FINE_SUB;  // 18
+
+__global__ __launch_bounds__(256) void table_subhist_kernel(const uint32_t* __restrict__ key, const uint32_t* __restrict__ part_start, int shift,
+                                                            uint32_t* __restrict__ hist) {
+    __shared__ uint32_t s_h[1 << TB_FINE_SUB];
+    if (threadIdx.x < (1 << TB_FINE_SUB)) s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t lo = part_start[blockIdx.x], hi = part_start[blockIdx.x + 1];
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&s_h[(key[i] >> shift) & ((1u << TB_FINE_SUB) - 1u)], 1u);
+    __syncthreads();
+    if (threadIdx.x < (1 << TB_FINE_SUB)) hist[((size_t)blockIdx.x << TB_FINE_SUB) + threadIdx.x] = s_h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void table_copy_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[i];
+}
+
+// bin = key >> shift (TB_FINE_BITS bits), counted relative to the first bin of the tile's first 12-bit group; at most 4096 relative bins
+__global__ __launch_bounds__(TB_PART_THREADS) void table_partition_rel_kernel(const uint32_t* __restrict__ in_key, const uint32_t* __restrict__ in_pos,
+                                                                              uint32_t n, int shift, uint32_t* __restrict__ cursor,
+                                                                              uint32_t* __restrict__ out_key, uint32_t* __restrict__ out_pos,
+                                                                              uint32_t* __restrict__ err) {
+    extern __shared__ uint32_t s_dyn[];
+    constexpr uint32_t NB = 4096;
+    uint32_t* s_key = s_dyn;
+    uint32_t* s_pos = s_dyn + TB_PART_TILE;
+    uint32_t* s_cnt = s_dyn + 2 * TB_PART_TILE;
+    uint32_t* s_loc = s_cnt + NB;
+    uint32_t* s_base = s_loc + NB;
+    __shared__ uint32_t s_wave[TB_PART_THREADS / 64];
+    __shared__ uint32_t s_bad;
+    constexpr int PER = TB_PART_TILE / TB_PART_THREADS;
+    for (uint32_t i = threadIdx.x; i < NB; i += TB_PART_THREADS) s_cnt[i] = 0;
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    const uint64_t tile0 = (uint64_t)blockIdx.x * TB_PART_TILE;
+    const uint32_t bin0 = ((in_key[tile0] >> shift) >> TB_FINE_SUB) << TB_FINE_SUB;  // first bin of the tile's first 12-bit group
+    uint32_t key[PER], pos[PER], rank[PER], rel[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        const uint64_t i = tile0 + (uint64_t)j * TB_PART_THREADS + threadIdx.x;
+        key[j] = TB_INVALID;
+        pos[j] = rank[j] = rel[j] = 0;
+        if (i < n) {
+            key[j] = in_key[i];
+            pos[j] = in_pos[i];
+            rel[j] = (key[j] >> shift) - bin0;
+            if (rel[j] >= NB) { s_bad = 1; key[j] = TB_INVALID; }
+            else rank[j] = atomicAdd(&s_cnt[rel[j]], 1u);
+        }
+    }
+    __syncthreads();
+    if (s_bad) {  // (the host rebuilds the table with the atomic build)
+        if (threadIdx.x == 0) *err = 1u;
+        return;
+    }
+    {
+        uint32_t c[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { c[q] = s_cnt[threadIdx.x * 4 + q]; sum += c[q]; }
+        uint32_t inc = sum;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)inc, off, 64);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        uint32_t base = 0;
+        for (int w = 0; w < wave; w++) base += s_wave[w];
+        uint32_t run = base + inc - sum;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t b = threadIdx.x * 4 + q;
+            s_loc[b] = run;
+            s_base[b] = c[q] ? atomicAdd(&cursor[bin0 + b], c[q]) : 0u;
+            run += c[q];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; j++)
+        if (key[j] != TB_INVALID) {
+            const uint32_t slot = s_loc[rel[j]] + rank[j];
+            s_key[slot] = key[j];
+            s_pos[slot] = pos[j];
+        }
+    __syncthreads();
+    uint32_t total = 0;
+    for (int w = 0; w < TB_PART_THREADS / 64; w++) total += s_wave[w];
+    for (uint32_t slot = threadIdx.x; slot < total; slot += TB_PART_THREADS) {
+        const uint32_t k = s_key[slot], b = (k >> shift) - bin0;
+        const uint32_t dst = s_base[b] + (slot - s_loc[b]);
+        out_key[dst] = k;
+        out_pos[dst] = s_pos[slot];
+    }
+}
+
 // One workgroup per coarse partition: fine histogram (low key bits) in LDS -> the partition's slice of bucket_start; positions
 // placed bucket by bucket in LDS, every bucket sorted (ascending positions: the canonical order, hazard H7), one coalesced write.
 __global__ __launch_bounds__(1024) void table_finish_kernel(const uint32_t* __restrict__ key, const uint32_t* __restrict__ pos,
                                                             const uint32_t* __restrict__ part_start, int low_bits,
                                                             uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ pos_table,
-                                                            uint8_t* __restrict__ part_unsorted) {
-    extern __shared__ uint32_t s_dyn[];  // [nlow] offsets / cursors, [nlow] bucket sizes, [TB_FIN_CAP] positions
+                                                            uint8_t* __restrict__ part_unsorted, uint32_t fin_cap) {
+    extern __shared__ uint32_t s_dyn[];  // [nlow] offsets / cursors, [nlow] bucket sizes, [fin_cap] positions
     __shared__ uint32_t s_wave[16];
     const uint32_t nlow = 1u << low_bits, lowmask = nlow - 1u;
     uint32_t* s_off = s_dyn;
@@ -282,7 +393,7 @@ __global__ __launch_bounds__(1024) void table_finish_kernel(const uint32_t* __re
         }
     }
     __syncthreads();
-    const bool fits = m <= TB_FIN_CAP;
+    const bool fits = m <= fin_cap;
     if (threadIdx.x == 0) part_unsorted[p] = fits ? 0 : 1;
     // place (cursor = s_off advanced; the bucket starts are recovered from s_off - s_n afterwards)
     for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
@@ -332,7 +443,13 @@ static bool lds_budget_ok() {
     }
     return cached[dev] == 1;
 }
-bool table_partition_build_supported(int weight) { return weight >= 9 && weight <= 12 && lds_budget_ok(); }
+bool table_partition_build_supported(int weight) { return weight >= 9 && weight <= 14 && lds_budget_ok(); }
+// scratch of the third partition level (keys above 24 bits), in dwords: hist | part_start (+1) | cursor | unsorted flags | error flag
+size_t table_partition_fine_words(int weight) {
+    if (2 * weight <= 2 * TB_COARSE_BITS) return 0;
+    const size_t n = (size_t)1 << TB_FINE_BITS;
+    return 3 * n + 1 + n / 4 + 16;
+}
 size_t table_partition_part_start_words() { return (1u << TB_COARSE_BITS) + 1; }
 
 void launch_table_keys(const uint8_t* ref, uint32_t num_steps, uint32_t start_offset, uint32_t step, SeedShape sh, uint32_t* keys,
@@ -349,8 +466,10 @@ void launch_table_keys(const uint8_t* ref, uint32_t num_steps, uint32_t start_of
 void launch_table_partition_build(const uint32_t* keys, uint32_t num_steps, uint32_t start_offset, uint32_t step, int weight,
                                   const uint32_t* part_start, uint32_t num_index, uint32_t* cursor, uint32_t* key_a, uint32_t* pos_a,
                                   uint32_t* key_b, uint32_t* pos_b, uint8_t* part_unsorted, uint32_t* bucket_start, uint32_t* pos_table,
-                                  hipStream_t s) {
+                                  uint32_t* fine /* table_partition_fine_words(weight) dwords */, void* scan_tmp /* scan_temp_bytes(2^18) */,
+                                  uint32_t** err_flag /* out: device flag, != 0 after the build = fall back to the atomic build */, hipStream_t s) {
     const int keybits = 2 * weight, low_bits = keybits - TB_COARSE_BITS;
+    if (err_flag) *err_flag = nullptr;
     const uint32_t nkeys = 1u << keybits;
     // (dynamic LDS above 64 KB has to be announced per kernel and device)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&table_partition_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
@@ -368,9 +487,34 @@ void launch_table_partition_build(const uint32_t* keys, uint32_t num_steps, uint
         hipLaunchKernelGGL((table_partition_kernel<false>), dim3((num_index + TB_PART_TILE - 1) / TB_PART_TILE), dim3(TB_PART_THREADS),
                            (2 * TB_PART_TILE + 3 * (1u << TB_COARSE_BITS)) * sizeof(uint32_t), s, key_a, pos_a, num_index, 0u, 0u, low_bits,
                            TB_COARSE_BITS, cursor, key_b, pos_b);
+    if (keybits > 2 * TB_COARSE_BITS) {
+        // third level: 2^18 fine partitions (see above); the pairs go back into the A buffers
+        const uint32_t nfine = 1u << TB_FINE_BITS;
+        const int fine_low = keybits - TB_FINE_BITS;
+        uint32_t* hist18 = fine;
+        uint32_t* start18 = hist18 + nfine;
+        uint32_t* cursor18 = start18 + nfine + 1;
+        uint8_t* unsorted18 = reinterpret_cast<uint8_t*>(cursor18 + nfine);
+        uint32_t* err = reinterpret_cast<uint32_t*>(unsorted18 + nfine);
+        if (err_flag) *err_flag = err;
+        (void)hipMemsetAsync(err, 0, sizeof(uint32_t), s);
+        hipLaunchKernelGGL(table_subhist_kernel, dim3(1u << TB_COARSE_BITS), dim3(256), 0, s, key_b, part_start, fine_low, hist18);
+        launch_exclusive_scan_u32(hist18, start18, nfine, scan_tmp, s);
+        hipLaunchKernelGGL(table_copy_kernel, dim3(256), dim3(256), 0, s, start18, cursor18, nfine);
+        if (num_index)
+            hipLaunchKernelGGL(table_partition_rel_kernel, dim3((num_index + TB_PART_TILE - 1) / TB_PART_TILE), dim3(TB_PART_THREADS),
+                               (2 * TB_PART_TILE + 3 * 4096) * sizeof(uint32_t), s, key_b, pos_b, num_index, fine_low, cursor18, key_a, pos_a, err);
+        // a fine partition holds a few hundred positions: 8192 of them in LDS (a partition above that is placed directly)
+        hipLaunchKernelGGL(table_finish_kernel, dim3(nfine), dim3(256), (2 * (1u << fine_low) + TB_FIN_CAP_FINE) * sizeof(uint32_t), s, key_a, pos_a,
+                           start18, fine_low, bucket_start, pos_table, unsorted18, TB_FIN_CAP_FINE);
+        (void)hipMemcpyAsync(bucket_start + nkeys, part_start + (1u << TB_COARSE_BITS), sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
+        hipLaunchKernelGGL(table_sort_buckets_kernel, dim3(grid_for(nkeys, 256)), dim3(256), 0, s, bucket_start, nkeys, pos_table, 33u, unsorted18,
+                           (uint32_t)fine_low);
+        return;
+    }
     // finish: one workgroup per coarse partition
     hipLaunchKernelGGL(table_finish_kernel, dim3(1u << TB_COARSE_BITS), dim3(1024), (2 * (1u << low_bits) + TB_FIN_CAP) * sizeof(uint32_t), s, key_b,
-                       pos_b, part_start, low_bits, bucket_start, pos_table, part_unsorted);
+                       pos_b, part_start, low_bits, bucket_start, pos_table, part_unsorted, TB_FIN_CAP);
     // bucket_start[nkeys] = num_index; buckets of more than 32 entries (and the partitions that did not fit) get the global sort
     (void)hipMemcpyAsync(bucket_start + nkeys, part_start + (1u << TB_COARSE_BITS), sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
     hipLaunchKernelGGL(table_sort_buckets_kernel, dim3(grid_for(nkeys, 256)), dim3(256), 0, s, bucket_start, nkeys, pos_table, 33u,

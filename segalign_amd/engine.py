@@ -37,7 +37,7 @@ C_ABI_SYMBOLS = [
     "sa_rm_mask_interval", "sa_rm_coverage_intervals", "sa_free_intervals", "sa_get_filter_mode",
     "sa_seed_interval", "sa_seed_and_filter_chunks", "sa_max_chunks_per_call", "sa_get_chunks_per_call", "sa_extend_hits",
     "sa_get_lookup_mode", "sa_get_neighbourhood_entries",
-    "sa_seed_calls", "sa_count_call_hits", "sa_release_arena", "sa_set_option", "sa_reset_option", "sa_get_option", "sa_option_count", "sa_option_name", "sa_get_audit",
+    "sa_seed_calls", "sa_count_call_hits", "sa_count_chunk_hits", "sa_get_wga_chunk", "sa_release_arena", "sa_set_option", "sa_reset_option", "sa_get_option", "sa_option_count", "sa_option_name", "sa_get_audit",
 ]
 IVL_DTYPE = np.dtype([("query_start", "<u4"), ("len", "<u4")])  # struct Segment, repeat_masker_src/graph.h:32-35
 STRAND_PLUS, STRAND_MINUS, STRAND_BOTH = 1, 2, 3
@@ -121,6 +121,8 @@ def lib():
     L.sa_seed_calls.restype = C.c_size_t
     L.sa_seed_calls.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_void_p, C.POINTER(CallStats)]
     L.sa_count_call_hits.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_void_p]
+    L.sa_count_chunk_hits.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+    L.sa_get_wga_chunk.restype = C.c_uint32
     L.sa_set_option.restype = C.c_int
     L.sa_set_option.argtypes = [C.c_char_p, C.c_int64]
     L.sa_reset_option.restype = C.c_int
@@ -239,14 +241,24 @@ class CallResult(C.Structure):
     _fields_ = [("hsps", C.c_void_p), ("num_hsps", C.c_size_t), ("num_hits", C.c_uint64), ("device", C.c_int32), ("reserved", C.c_int32)]
 
 
-def CountCallHits(calls, buffer=0, threads=4):
+def CountCallHits(calls, buffer=0, threads=4, per_chunk=False):
     """Seed hits of every call [(start, end, rev), ...], lookup only (no filtering, no extension): the weights a multi-GPU host
-    deals the calls of a pass by."""
+    deals the calls of a pass by.  per_chunk: the hits of every wga_chunk piece of every call instead, concatenated."""
     n = len(calls)
     descs = (CallDesc * max(n, 1))(*[CallDesc(int(a), int(b), int(bool(r))) for (a, b, r) in calls])
     hits = (C.c_uint64 * max(n, 1))()
-    lib().sa_count_call_hits(descs, n, buffer, threads, hits)
-    return [int(hits[i]) for i in range(n)]
+    if not per_chunk:
+        lib().sa_count_call_hits(descs, n, buffer, threads, hits)
+        return [int(hits[i]) for i in range(n)]
+    k = lib().sa_max_chunks_per_call()
+    ch = (C.c_uint64 * max(n * k, 1))()
+    lib().sa_count_chunk_hits(descs, n, buffer, threads, hits, ch)
+    chunk = lib().sa_get_wga_chunk()
+    out = []
+    for i, (a, b, r) in enumerate(calls):
+        kk = (int(b) - int(a) + chunk - 1) // chunk if b > a else 0
+        out.extend(int(ch[i * k + c]) for c in range(kk))
+    return out
 
 
 def ReleaseArena():

@@ -137,5 +137,10 @@ def test_hit_counts_by_lookup_equal_the_calls_own_counts(oracle, engine, two_dev
         seen = []
         E.SeedCalls(calls, 0, 4, hits_out=seen)
         assert counted == seen and sum(counted) > 0
+        # ... and per 250 kbp chunk: the same lookups report every chunk's hits, which add up to the calls'
+        per_chunk = E.CountCallHits(calls, 0, 4, per_chunk=True)
+        assert len(per_chunk) == sum(j["chunks"] for j in jobs) and sum(per_chunk) == sum(counted)
+        singles = [(a, min(a + 250_000, j["b"]), j["rev"]) for j in jobs for a in range(j["a"], j["b"], 250_000)]
+        assert per_chunk == E.CountCallHits(singles, 0, 4)
     finally:
         E.ShutdownProcessor()

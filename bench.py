@@ -612,7 +612,11 @@ def roofline(args, E, wl, prof, busy, call_stats, run_step, run_job, jobs, elaps
         # what binds: the unit closest to what it can deliver -- the memory path against the rate a pure stream of the same records
         # reaches (STREAM_GBS), the VALU against always-busy
         mem = (traffic / (1e3 * s_ms / max(s_n, 1) * 1e-6) / 1e9 / STREAM_GBS) if (traffic and s_ms) else 0.0
-        if (counters["valu_busy_frac"] or 0.0) > max(mem, 0.5):
+        valu = counters["valu_busy_frac"] or 0.0
+        # both ratios are in the line; the name only changes when the VALU share leads by more than 10 % (the two sit close together on
+        # this kernel and move by a few per cent from box to box: a plain comparison flipped between runs of the same build)
+        counters["bound_ratios"] = {"memory_path_vs_stream_ceiling": round(mem, 4), "valu_busy": round(valu, 4)}
+        if valu > 0.5 and valu > 1.10 * mem:
             bound = "valu_issue"
     per_step_scale = 1.0 / max(args.steps, 1)
 

@@ -874,12 +874,14 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
 // the lowest N seen at a field end: "alive" = never more than xdrop below the best at a field end.  (Asking only at the end of the
 // context -- N_end >= -xdrop, implied by the former, so it errs on the forwarding side -- saves one op per field and forwards 6.3 %
 // instead of 4.6 % of the hits: the second level then costs 0.08 ms more per call than the filter saves.)
-// What bounds the kernel (profiles/r03, tools/pmc_mem.sh): the L1's miss path.  A CU has ~57 lines of 128 bytes in flight at
-// an L1->L2 read latency of ~840 cycles under this load (TCP_TCC_READ_REQ_LATENCY / TCP_TCC_READ_REQ; TCP_PENDING_STALL_CYCLES is
-// 61 % of the kernel's cycles), i.e. ~9 bytes per cycle and CU = 5.1 TB/s for the chip -- what tools/micro/stream_rec.hip gets for
-// the same 32-byte record stream with no arithmetic at all (5.8 TB/s).  Measured on this kernel, each changing NOTHING in its
-// duration: 12 % fewer VALU instructions (no W), half the LDS bytes (these 4-byte entries instead of 8-byte ones; the LDS pipe
-// went from 65 % to ~35 % busy), the next buffer's records requested one iteration ahead.  They are kept because the kernel then
+// What bounds the kernel (profiles/r03, tools/pmc_mem.sh): the L1's miss path.  A CU has ~57 lines of 128 bytes in
+// flight at an L1->L2 read latency of ~840 cycles under this load (TCP_TCC_READ_REQ_LATENCY / TCP_TCC_READ_REQ;
+// TCP_PENDING_STALL_CYCLES is 61 % of the kernel's cycles), i.e. ~9 bytes per cycle and CU = 5.2 TB/s for the chip by the TCC
+// counters (0.63-0.68 of the 8 TB/s peak), against 6.2 TB/s for a pure stream of the same 32-byte records with no arithmetic at all
+// (tools/micro/stream_rec2.hip) and 5.8-6.0 TB/s for a bare read of the same random 2.5 KB pieces (tools/micro/piece_order.hip).
+// Measured on this kernel, each changing NOTHING in its duration: 12 % fewer VALU instructions (no W), half the LDS bytes (these
+// 4-byte entries instead of 8-byte ones; the LDS pipe stays ~67 % busy: 64 random reads conflict in the banks whatever their
+// width), the next buffer's records requested one iteration ahead.  They are kept because the kernel then
 // leaves more of the CU to the kernels of the other calls in flight (0.96 -> 1.04 Gbp/s for the whole pass).  Only fewer LINES
 // per hit would make it faster: reading half of every record did not (same lines, -9 % from the smaller loads alone).
 // Why the bound holds: with u_i >= s_i pointwise the bounded walk's drop max_i<=k(Q_i) - Q_k never exceeds the exact walk's, so it

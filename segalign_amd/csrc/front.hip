@@ -147,7 +147,7 @@ bool ensure_nbr(DevCtx* dc) {
     const size_t have = arena_mapped(dc->arena);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = total_b = 0;  // (then only the plain lookup modes are tried)
-    // keep room for the slots' work buffers: at human-scale hit density a sixteen-chunk call holds ~6 GB of lists per slot
+    // keep room for the slots' work buffers: at human-scale hit density a fourteen-chunk call (1 G hits, option call_hits_max) holds ~6 GB of lists per slot
     size_t reserve = ((size_t)8 << 30) + ((size_t)4 << 30) * (size_t)SLOTS_PER_DEVICE;
     reserve -= std::min(reserve / 2, arena_mapped(dc->work_arena));  // (what the work arena holds IS part of that room)
     const size_t need_pos = (size_t)std::max<uint64_t>(total, 1) * sizeof(uint32_t);

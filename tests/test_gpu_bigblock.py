@@ -14,6 +14,8 @@ pytestmark = pytest.mark.gpu
 
 def test_750_mbp_block_both_strands_against_the_oracle(oracle, engine):
     E = engine
+    E.ShutdownProcessor()
+    E.ReleaseArena()   # (whatever earlier modules left cached: this block needs 230 GB)
     tlen = 750_000_000
     target = synth.random_dna(tlen, 5)
     target = synth.soft_mask(target, 6, 0.3, 200, 2000)

@@ -94,7 +94,9 @@ def test_block_that_does_not_fit_falls_back_to_positions_and_recovers(oracle, en
     O.generate_shape_pos(SHAPE)
     # the table arena is a process-wide cache: give back what earlier tests left mapped (arena_gb = 0 releases it at
     # ShutdownProcessor), then run with a small arena, so that what is mapped when the memory is taken away is known
+    # (and no work arena: its background mapping would take memory while this test does its own accounting)
     E.set_option("arena_gb", 0)
+    E.set_option("work_gb", 0)
     E.InitializeProcessor(True, CHUNK, 19, sub_mat, 910, 3000, False)
     E.ShutdownProcessor()
     E.InitializeInterface(1)
@@ -121,3 +123,4 @@ def test_block_that_does_not_fit_falls_back_to_positions_and_recovers(oracle, en
             hip.hipFree(hog)
         E.ShutdownProcessor()
         E.reset_option("arena_gb")
+        E.reset_option("work_gb")

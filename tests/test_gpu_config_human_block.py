@@ -97,7 +97,7 @@ def test_configs2_block_chunks_bit_exact_vs_oracle(human_block, rev):
     assert np.array_equal(outs[1], E.SeedAndFilterRange(250000, 500000, rev, 0))
 
 
-def test_configs2_block_sixteen_chunk_call_bit_exact_vs_oracle(human_block):
+def test_configs2_block_multi_chunk_call_bit_exact_vs_oracle(human_block):
     """ONE call over sixteen chunks of the plus strand at human-scale hit density (~0.5 G hits, > 1 M chain candidates, tens
     of thousands of survivors in 32 dedup segments): every chunk's vector against the oracle."""
     E, O, query = human_block["E"], human_block["O"], human_block["query"]

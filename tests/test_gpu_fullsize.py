@@ -94,10 +94,10 @@ def test_one_full_chunk_bit_exact_vs_oracle(full, rev):
     assert got.shape == want.shape and np.all(got == want)
 
 
-def test_sixteen_chunk_calls_bit_exact_vs_oracle_at_full_size(full):
-    """Half an interval (20 chunks per strand = one 16-chunk call of ~200 M hits + one 4-chunk call) through sa_seed_interval,
-    every chunk against the oracle: the multi-chunk machinery (32 reference iterations in one pass, relative chain keys,
-    per-segment LDS chains, speculative output copy) at the workload's real hit density."""
+def test_multi_chunk_calls_bit_exact_vs_oracle_at_full_size(full):
+    """Half an interval (20 chunks per strand = one 20-chunk call of ~260 M hits per strand) through sa_seed_interval, every chunk
+    against the oracle: the multi-chunk machinery (40 reference iterations in one pass, relative chain keys, per-segment LDS
+    chains, speculative output copy) at the workload's real hit density."""
     E, O, query = full["E"], full["O"], full["query"]
     index, pos = E.copy_index_table(), E.copy_pos_table()
     rcodes = E.copy_ref_codes()
@@ -188,7 +188,7 @@ def test_configs3_repeat_masker_chunks_bit_exact_vs_oracle(full_rm, strands):
 
 
 def test_configs3_repeat_masker_grouped_interval_vs_oracle(full_rm):
-    """Half an interval of the plan, both strands, through sa_rm_mask_interval -- sixteen-chunk table-direct passes, a short last
+    """Half an interval of the plan, both strands, through sa_rm_mask_interval -- twenty-chunk table-direct passes, a short last
     plus chunk whose minus chunk overlaps its neighbour (seeder.cpp:118-119) -- against the oracle chunk by chunk."""
     E, O, target = full_rm["E"], full_rm["O"], full_rm["target"]
     L, chunk = target.size, 250000

@@ -32,6 +32,9 @@ def two_devices(engine):
     ids = engine_devices(engine, 2)
     yield ids
     engine.select_devices([])
+    # the arenas are process-wide caches, one set per engine device: give the twins' memory back to the tests that follow
+    engine.ShutdownProcessor()
+    engine.ReleaseArena()
 
 
 def test_all_devices_token_pool_matches_oracle(oracle, engine, two_devices):

@@ -250,6 +250,10 @@ def main():
     os.environ.setdefault("SEGALIGN_AMD_SLOTS", str(max(2, inflight)))  # one engine slot per call in flight (default 2)
     if args.workload == "human":
         os.environ.setdefault("SEGALIGN_AMD_ARENA_GB", "180")
+    if not args.chunks_per_call and world > 2 and scaling == "strong":
+        # strong scaling over many ranks: a finer grain, so that every rank gets >= 10 calls of a pass to balance (N = 4: calls of
+        # twenty chunks, N = 8: of ten); N <= 2 keeps the engine's default of forty
+        E.set_option("chunks_per_call", max(10, 80 // world))
     if args.chunks_per_call:
         E.set_option("chunks_per_call", args.chunks_per_call)
         E.set_option("call_hits", 0)  # (an explicit grain is kept as it is: no sizing by hits)

@@ -311,21 +311,32 @@ def main():
     weights = None
     imbalance = None
     t_weigh = None
+    chunk_hits = None   # {(rev, chunk start): seed hits} of every 250 kbp piece of the pass
     if scaling == "strong" and not wl["rm"] and (args.partition == "hits" or (args.partition == "auto" and (world > 1 or args.workload in ("lumpy", "human")))):
-        # lookup only (sa_count_call_hits: the position probe + chunk plans of every call, no filtering, no extension): what the map
+        # lookup only (sa_count_chunk_hits: the position probe + chunk plans of every call, no filtering, no extension): what the map
         # costs a production host per (target block, query block) pair -- reported as partition_cost_ms
         t0 = time.perf_counter()
-        weights = E.CountCallHits([(j["a"], j["b"], j["rev"]) for j in jobs], 0, inflight)
+        per_chunk = E.CountCallHits([(j["a"], j["b"], j["rev"]) for j in jobs], 0, inflight, per_chunk=True)
         t_weigh = time.perf_counter() - t0
+        keys = [(j["rev"], c) for j in jobs for c in range(j["a"], j["b"], args.chunk)]
+        chunk_hits = dict(zip(keys, per_chunk))
+
+        def call_weights(js):
+            return [sum(chunk_hits[(j["rev"], c)] for c in range(j["a"], j["b"], args.chunk)) for j in js]
+        weights = call_weights(jobs)
     my_jobs = shard.partition(jobs, rank, world, weights) if scaling == "strong" else jobs
     if weights and world >= 1:
-        # (what the map promises: heaviest rank / mean, by seed hits; and what round-robin would have given)
-        def spread(w_or_none, n):
-            pos = {id(j): k for k, j in enumerate(jobs)}
-            loads = [sum(weights[pos[id(j)]] for j in shard.partition(jobs, r, n, w_or_none)) for r in range(n)]
-            return round(max(loads) / (sum(loads) / n), 4)
+        # (what the map promises: heaviest rank / mean, by seed hits; and what round-robin would have given.  A 1-rank run shows it for
+        #  the call list an 8-rank run of the same pass would deal: calls of ten chunks)
         n_show = world if world > 1 else 8
-        imbalance = {"ranks": n_show, "by_hits": spread(weights, n_show), "round_robin": spread(None, n_show)}
+        js = jobs if world > 1 else shard.call_jobs(intervals, q_block_len, args.chunk, min(10, max(j["chunks"] for j in jobs)))
+        ws = weights if world > 1 else call_weights(js)
+
+        def spread(w_or_none, n):
+            pos = {id(j): k for k, j in enumerate(js)}
+            loads = [sum(ws[pos[id(j)]] for j in shard.partition(js, r, n, w_or_none)) for r in range(n)]
+            return round(max(loads) / (sum(loads) / n), 4)
+        imbalance = {"ranks": n_show, "calls": len(js), "by_hits": spread(ws, n_show), "round_robin": spread(None, n_show)}
     # never more calls in flight than this rank's share of one pass holds (the 1 Mbp plumbing case is two calls per pass: six
     # tiny calls in flight only contend for the engine's locks, 1.1 -> 0.67 Gbp/s)
     inflight = max(1, min(inflight, len(my_jobs)))
@@ -442,7 +453,8 @@ def main():
     # how evenly the seed hits are spread over the 250 kbp chunks of the pass (lookup only; rank 0, outside the timed region)
     hit_spread = None
     if rank == 0 and not wl["rm"] and not args.no_roofline:
-        ch = np.array(E.CountCallHits([(j["a"], j["b"], j["rev"]) for j in jobs], 0, inflight, per_chunk=True), dtype=np.float64)
+        ch = np.array(list(chunk_hits.values()) if chunk_hits else
+                      E.CountCallHits([(j["a"], j["b"], j["rev"]) for j in jobs], 0, inflight, per_chunk=True), dtype=np.float64)
         if ch.size and ch.sum() > 0:
             hit_spread = {"chunks": int(ch.size), "hits_per_pass": int(ch.sum()), "heaviest_chunk_over_mean": round(float(ch.max() / ch.mean()), 3),
                           "lightest_chunk_over_mean": round(float(ch.min() / ch.mean()), 3)}

@@ -226,3 +226,34 @@ def test_query_block_beyond_the_2bit_copy_limit_takes_the_general_path(oracle, c
         assert n > 50
     finally:
         E.reset_option("q2_limit_mb")
+
+
+@pytest.mark.parametrize("mode,env", MODES)
+def test_passes_that_cannot_hold_their_chunks_halve_themselves(oracle, clean, mode, env):
+    """A multi-chunk pass with chunks at or above MAX_HITS (those need the general path's iteration plan, hazard H4), and a pass of
+    more than 32 chunks on the general path, are cut in halves until every piece fits (api_calls.hip chunks_pass): every chunk's
+    vector must still be what a call of its own returns, the statistics the sums."""
+    with_env(env)
+    t, q = synth.make_pair(260000, 81, 82, sub_rate=0.07, mask_frac=0.1, records=2, indel_every=600)
+    c = Case(t, q, chunk=5000).oracle_setup(oracle).engine_setup(clean)  # 52 chunks
+    E = c.E
+    ch = c.chunks()
+    assert len(ch) > 40
+    try:
+        for mh in (2500, 1 << 30):   # ~half of the chunks hold more hits than 2500
+            E.set_max_hits(mh)
+            for rev in (False, True):
+                wants, hits = [], 0
+                for (s, e) in ch[:48]:
+                    w, st = c.oracle_saf(c.host_seeds(s, e, rev), rev, max_hits=mh)
+                    wants.append(w)
+                    hits += st["num_hits"]
+                outs = E.SeedAndFilterChunks(ch[0][0], ch[47][1], rev, 0)   # 48 chunks in one entry call
+                st = E.last_call_stats()
+                for j, w in enumerate(wants):
+                    assert seg_equal(outs[j], w), (mode, mh, rev, j)
+                assert st["num_hits"] == hits
+                if mh == 2500 and mode:
+                    assert st["path_flags"] & E.PATH_GENERAL_FALLBACK   # the crowded chunks went down the general path ...
+    finally:
+        E.set_max_hits(0)

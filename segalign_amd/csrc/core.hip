@@ -181,6 +181,7 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                     ea.l2_blocks = (uint32_t)g_l2_blocks;
                     ea.ctx_waves = (uint32_t)g_ctx_waves;
                     ea.ctx_threads = (uint32_t)g_ctx_threads;
+                    ea.cls_one_copy = (uint32_t)opt_value("cls_one_copy");
                 } else if (!ca.raw_hits) {
                     sl->hits.ensure((size_t)bh, "hits");
                     ProfScope p(sl, "expand_hits");

@@ -951,6 +951,13 @@ __device__ __forceinline__ void cls_step(const uint32_t* __restrict__ s_tab, uin
     }
 }
 
+// ONE_COPY: the query windows come out of the UNSHIFTED 2-bit copy of either strand (copy 0 of the sixteen) with funnel shifts, instead
+// of aligned dwords of the copy that starts at the position's phase.  With ~78 hits per query position a 64-hit buffer holds about
+// one position and the sixteen copies cost nothing; with ~5 hits per position (--notransition, small targets) it holds 13 positions
+// whose windows lie in 13 different copies x 2 strands = 26 lines per buffer that miss the L1 every time and the L2 half of the time
+// (the record stream flushes both): 3.1 HBM lines per 160-byte run where a bare walk of the same runs needs 2.1
+// (tools/micro/hit_shaped.hip).  From copy 0 the windows of consecutive positions share their lines.
+template <bool ONE_COPY>
 __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(ExtendArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_cls[CLS_LDS_DWORDS];  // 4-byte entry per 6-base class field (16 KB) + the 4-base tail fields (1 KB)
     extern __shared__ L2Rec s_l2_dyn[];          // [waves of the workgroup][CTX_STAGE_CAP]
@@ -1018,13 +1025,34 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(E
         S.query_loc = query_loc;
         // copy (pos & 3, (pos >> 2) & 3) = copy number pos & 15, dword pos >> 4 (encode.hip); strides are multiples of 16 bytes, so
         // the offset is ONE 32-bit value next to a scalar base
-        const uint32_t po = (mul24(query_loc & 15u, stride16) << 4) + ((query_loc >> 4) << 2);
-        uint3 t;
-        __builtin_memcpy(&t, __builtin_assume_aligned(a.q2_own + po, 4), 12);
-        S.qr0 = t.x; S.qr1 = t.y; S.qr2 = t.z;
         const uint32_t lp = a.query_len - query_loc;  // the left walk = the other strand's forward window at len - anchor (CtxRec)
-        const uint32_t qo = (mul24(lp & 15u, stride16) << 4) + ((lp >> 4) << 2);
-        __builtin_memcpy(&S.ql, __builtin_assume_aligned(a.q2_other + qo, 4), 16);
+        if (ONE_COPY) {
+            // copy 0: dword j holds bases [16 j, 16 j + 16), base 16 j + k in bits 2k, 2k + 1; the window at position p is the bit string
+            // from bit 2 (p & 15) of dword p >> 4 on: one more dword per side and a funnel shift per dword
+            uint4 t;
+            __builtin_memcpy(&t, __builtin_assume_aligned(a.q2_own + ((query_loc >> 4) << 2), 4), 16);
+            const uint32_t sr = (query_loc & 15u) << 1;
+            S.qr0 = __builtin_amdgcn_alignbit(t.y, t.x, sr);
+            S.qr1 = __builtin_amdgcn_alignbit(t.z, t.y, sr);
+            S.qr2 = __builtin_amdgcn_alignbit(t.w, t.z, sr);
+            uint4 u;
+            uint32_t u4;
+            const uint8_t* lpp = a.q2_other + ((lp >> 4) << 2);
+            __builtin_memcpy(&u, __builtin_assume_aligned(lpp, 4), 16);
+            __builtin_memcpy(&u4, __builtin_assume_aligned(lpp + 16, 4), 4);
+            const uint32_t sl = (lp & 15u) << 1;
+            S.ql.x = __builtin_amdgcn_alignbit(u.y, u.x, sl);
+            S.ql.y = __builtin_amdgcn_alignbit(u.z, u.y, sl);
+            S.ql.z = __builtin_amdgcn_alignbit(u.w, u.z, sl);
+            S.ql.w = __builtin_amdgcn_alignbit(u4, u.w, sl);
+        } else {
+            const uint32_t po = (mul24(query_loc & 15u, stride16) << 4) + ((query_loc >> 4) << 2);
+            uint3 t;
+            __builtin_memcpy(&t, __builtin_assume_aligned(a.q2_own + po, 4), 12);
+            S.qr0 = t.x; S.qr1 = t.y; S.qr2 = t.z;
+            const uint32_t qo = (mul24(lp & 15u, stride16) << 4) + ((lp >> 4) << 2);
+            __builtin_memcpy(&S.ql, __builtin_assume_aligned(a.q2_other + qo, 4), 16);
+        }
     };
     auto score = [&](uint64_t b, const Stage& S) {
         const bool valid = (b << 6) + (uint64_t)lane < a.num_hits;
@@ -1628,7 +1656,11 @@ void launch_extend_filter_cls(const ExtendArgs& a, hipStream_t s) {
     const uint32_t wpb = threads / 64;
     const uint32_t blocks = (uint32_t)((waves + wpb - 1) / wpb);
     const size_t lds = wpb * CTX_STAGE_CAP * sizeof(L2Rec);
-    hipLaunchKernelGGL(extend_filter_cls_kernel, dim3(blocks), dim3(threads), lds, s, a);
+    // the query windows out of ONE copy (see the kernel): -24 % on the kernel with ~5 hits per position, no loss with ~78 (the default
+    // workload measures the same either way, same box); option cls_one_copy = 2 keeps the sixteen shifted copies (A/B)
+    const bool one_copy = a.cls_one_copy != 2;
+    if (one_copy) hipLaunchKernelGGL(extend_filter_cls_kernel<true>, dim3(blocks), dim3(threads), lds, s, a);
+    else hipLaunchKernelGGL(extend_filter_cls_kernel<false>, dim3(blocks), dim3(threads), lds, s, a);
 }
 
 void launch_chain_group(const ExtendArgs& a, hipStream_t s) {  // chain_bucket_cnt must be zero on entry

@@ -169,6 +169,7 @@ struct ExtendArgs {
                                 // diagonal are in iteration order anyway (the link test compares the iterations itself)
     uint32_t chain_q_base;
     uint32_t ctx_threads;       // workgroup size of the context filter (0: its default)
+    uint32_t cls_one_copy;      // 0 / 1: query windows from the unshifted copy (default), 2: from the sixteen shifted copies
     uint32_t l2_blocks;         // grid of the second level (its hit count is known on the device only)
     uint32_t seed_size;
     uint64_t num_hits;

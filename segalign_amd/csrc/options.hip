@@ -122,6 +122,7 @@ static Option g_opts[] = {
     {"long_blocks", 1792, 1, 1 << 20, 0}, {"max_waves", 4096, 4, 1 << 20, 0}, {"packed_waves", 4096, 8, 1 << 20, 0},
     {"l2_blocks", 512, 1, 1 << 20, 0}, {"ctx_waves", 0, 0, 1 << 20, 0}, {"ctx_threads", 0, 0, 1024, 0},
     {"chain_sort_threads", 256, 64, 512, 0}, {"dedup_threads", 0, 0, 1024, 0},
+    {"cls_one_copy", 0, 0, 2, 0},                      // class filter's query windows: 0 / 1 unshifted copy + funnel shifts (default), 2 the sixteen shifted copies (round 3's form)
     {"nbr_one_stage", 0, 0, 1, 0}, {"table_atomic", 0, 0, 1, 0}, {"seed_upload", 0, 0, 2, 0},
     // test-only: small capacities that force the overflow / fallback branches
     {"l2_cap", 0, 0, 1 << 30, 1}, {"spec_dedup", 1, 0, 1, 1}, {"spec_recs", 16384, 1, 16384, 1}, {"dedup_seg_max", 0, 0, 1 << 30, 1},

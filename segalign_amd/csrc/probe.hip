@@ -317,6 +317,10 @@ __global__ __launch_bounds__(PR_THREADS) void probe_compact_kernel(uint32_t star
     const uint32_t i_first = i0 + ((int32_t)i0 < 0 ? skew : 0u);  // (the first thread of the grid starts below position 0)
     uint32_t cb = (i_first + bpos.chunk - 1u) / bpos.chunk;
     uint32_t ib = cb * bpos.chunk;
+    // head bits of the thread's positions are gathered per 32-bit word before they go out: with a few hits per position (sparse-hit
+    // calls) the four positions of a thread -- and those of its neighbours -- set bits of the SAME word, and one atomic per record
+    // queued up on it
+    uint32_t hb_word = 0xFFFFFFFFu, hb_mask = 0;
 #pragma unroll
     for (int j = 0; j < PR_ITEMS; j++) {
         const uint32_t i = i0 + j;
@@ -334,7 +338,15 @@ __global__ __launch_bounds__(PR_THREADS) void probe_compact_kernel(uint32_t star
             c_rec[run.ne] = r;
             // head bit of the position's first hit: bit g of the call-wide bitmap <=> a record starts at hit g.  The class filter
             // finds the record of every hit of a 64-hit buffer from ONE 64-bit word of it (extend.hip 1d)
-            if (head_bits && (uint32_t)(run.hits >> 5) < head_words) atomicOr(&head_bits[run.hits >> 5], 1u << (run.hits & 31u));
+            if (head_bits && (uint32_t)(run.hits >> 5) < head_words) {
+                const uint32_t w = (uint32_t)(run.hits >> 5);
+                if (w != hb_word) {
+                    if (hb_mask) atomicOr(&head_bits[hb_word], hb_mask);
+                    hb_word = w;
+                    hb_mask = 0;
+                }
+                hb_mask |= 1u << (run.hits & 31u);
+            }
             // which record holds hit k * TD_CHUNK_HITS?  (the context filter's waves start there without searching)
             for (uint64_t k = (run.hits + TD_CHUNK_HITS - 1) / TD_CHUNK_HITS; k * TD_CHUNK_HITS < run.hits + cnt[j] && k < chunk_cap; k++)
                 chunk_rec[k] = run.ne;
@@ -343,6 +355,7 @@ __global__ __launch_bounds__(PR_THREADS) void probe_compact_kernel(uint32_t star
         run.ne += cnt[j] ? 1u : 0u;
         run.valid += (off[j] & PR_VALID) ? 1u : 0u;
     }
+    if (hb_mask) atomicOr(&head_bits[hb_word], hb_mask);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const Tri t = *total;
         TdRec r;

@@ -181,7 +181,9 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                     ea.l2_blocks = (uint32_t)g_l2_blocks;
                     ea.ctx_waves = (uint32_t)g_ctx_waves;
                     ea.ctx_threads = (uint32_t)g_ctx_threads;
-                    ea.cls_one_copy = (uint32_t)opt_value("cls_one_copy");
+                    // (the one-copy form unless the sixteen copies were asked for AND built: the option is read at InitializeProcessor, the
+                    //  copies are made at SendQueryWriteRequest)
+                    ea.cls_one_copy = (ca.q2_own->copies == (uint32_t)Q2_COPIES && ca.q2_other->copies == (uint32_t)Q2_COPIES && opt_value("cls_one_copy") == 2) ? 2u : 1u;
                 } else if (!ca.raw_hits) {
                     sl->hits.ensure((size_t)bh, "hits");
                     ProfScope p(sl, "expand_hits");

@@ -134,10 +134,12 @@ __global__ __launch_bounds__(256) void pack4_phase_kernel(const uint8_t* __restr
 // in the low bits, codes >= 4 stored as 0, zero beyond the block.  A 64-base window that starts at ANY base position `pos` is
 // four DWORD-ALIGNED dwords of copy (pos & 3, (pos >> 2) & 3) at byte (pos >> 2) - ((pos >> 2) & 3): no byte-granular load
 // and no funnel shifts in the filter.  Each thread produces one dword of one copy from the 19 codes it spans.
+// (round 4: the class filter takes its windows out of copy 0 alone with funnel shifts -- extend.hip ONE_COPY -- so the engine builds
+//  `copies` = 1 of them unless option cls_one_copy = 2 asks for the sixteen)
 __global__ __launch_bounds__(256) void pack2_shifted_kernel(const uint8_t* __restrict__ codes, uint32_t len,
-                                                            uint8_t* __restrict__ out, size_t copy_stride) {
+                                                            uint8_t* __restrict__ out, size_t copy_stride, uint32_t copies) {
     const uint32_t ndw = (uint32_t)(copy_stride / 4);
-    const uint64_t total = (uint64_t)ndw * Q2_COPIES;
+    const uint64_t total = (uint64_t)ndw * copies;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t c = (uint32_t)(i / ndw), w = (uint32_t)(i % ndw);
         const uint32_t p = c & 3u, sh = c >> 2;
@@ -205,8 +207,8 @@ void launch_pack4_phases(const uint8_t* codes, uint32_t len, uint8_t* out, size_
     hipLaunchKernelGGL(pack4_phase_kernel, dim3(grid_for((uint64_t)(nbytes + PACK4_FRONT) * PACK4_COPIES, 256)), dim3(256), 0, s, codes, len, out, copy_stride, nbytes);
 }
 size_t q2_copy_stride(uint32_t len) { return (((size_t)len / 4 + 1 + Q2_TAIL) + 127) & ~(size_t)127; }
-void launch_pack2_shifted(const uint8_t* codes, uint32_t len, uint8_t* out, size_t copy_stride, hipStream_t s) {
-    hipLaunchKernelGGL(pack2_shifted_kernel, dim3(grid_for((uint64_t)(copy_stride / 4) * Q2_COPIES, 256)), dim3(256), 0, s, codes, len, out, copy_stride);
+void launch_pack2_shifted(const uint8_t* codes, uint32_t len, uint8_t* out, size_t copy_stride, uint32_t copies, hipStream_t s) {
+    hipLaunchKernelGGL(pack2_shifted_kernel, dim3(grid_for((uint64_t)(copy_stride / 4) * copies, 256)), dim3(256), 0, s, codes, len, out, copy_stride, copies);
 }
 void launch_code_presence(const uint8_t* codes, uint32_t len, uint32_t* mask, hipStream_t s) {
     if (len == 0) return;

@@ -150,6 +150,8 @@ struct SeqBuf {  // encoded sequence with SEQ_PAD guard bytes on both sides; the
     }
 };
 
+extern int g_q2_copies;  // 2-bit copies of a query strand the engine builds: 1 (the class filter's one-copy form), 16 with option cls_one_copy = 2
+
 struct PackedBuf {  // phase copies of a packed sequence (packed X-drop filter): copy k at base + k*stride; grow-only like SeqBuf
     uint8_t* alloc = nullptr;
     uint8_t* base = nullptr;
@@ -182,10 +184,12 @@ struct PackedBuf {  // phase copies of a packed sequence (packed X-drop filter):
     // the sixteen shifted 2-bit copies of a query strand (class filter, encode.hip): every byte is written, no pads
     void create_q2(const uint8_t* codes, uint32_t len, const char* tag, hipStream_t s) {
         stride = q2_copy_stride(len);
-        reserve(stride * Q2_COPIES, tag);
+        copies = (uint32_t)g_q2_copies;
+        reserve(stride * copies, tag);
         base = alloc;
-        launch_pack2_shifted(codes, len, base, stride, s);
+        launch_pack2_shifted(codes, len, base, stride, copies, s);
     }
+    uint32_t copies = 0;  // (2-bit query copies: how many create_q2 built)
     void clear() {
         base = nullptr;
         stride = 0;

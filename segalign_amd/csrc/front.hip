@@ -208,8 +208,8 @@ bool ensure_nbr(DevCtx* dc) {
 // copies of BOTH query strands, all sixteen of a strand below `q2_limit` bytes (one 32-bit offset next to a scalar base: blocks of up
 // to ~1 Gbp).  A call that cannot have them takes the general path.
 bool q2_usable(const PackedBuf* q2_own, const PackedBuf* q2_other) {
-    return q2_own && q2_own->base && q2_other && q2_other->base && q2_own->stride * Q2_COPIES < g_q2_limit &&
-           q2_other->stride * Q2_COPIES < g_q2_limit;
+    return q2_own && q2_own->base && q2_other && q2_other->base && q2_own->stride * q2_own->copies < g_q2_limit &&
+           q2_other->stride * q2_other->copies < g_q2_limit;
 }
 bool td_eligible(DevCtx* dc, const PackedBuf* query4, const PackedBuf* q2_own, const PackedBuf* q2_other) {
     if (!(g_td && g_packed_filter && !g_count_examined && query4 && query4->base && dc->ref2.base && ensure_nbr(dc))) return false;

@@ -206,7 +206,7 @@ void launch_pack2_phases(const uint8_t* codes, uint32_t len, uint8_t* out, size_
 void launch_pack4_phases(const uint8_t* codes, uint32_t len, uint8_t* out, size_t copy_stride, uint32_t nbytes, hipStream_t s);
 // 2-bit query copies of the class filter: copy (p, s) byte j = bases [4 (j + s) + p, +4), codes >= 4 as 0, zero past the end
 size_t q2_copy_stride(uint32_t len);
-void launch_pack2_shifted(const uint8_t* codes, uint32_t len, uint8_t* out, size_t copy_stride, hipStream_t s);
+void launch_pack2_shifted(const uint8_t* codes, uint32_t len, uint8_t* out, size_t copy_stride, uint32_t copies /* 1 or Q2_COPIES */, hipStream_t s);
 // *mask |= 1 << code for every code that occurs in codes[0, len)
 void launch_code_presence(const uint8_t* codes, uint32_t len, uint32_t* mask, hipStream_t s);
 

@@ -58,6 +58,7 @@ uint32_t SPEC_RECS = 16384;
 uint32_t g_dedup_seg_max = 0;
 int SLOTS_PER_DEVICE = 4;
 size_t g_q2_limit = (size_t)1 << 32;
+int g_q2_copies = 1;
 int g_seed_upload = 0;  // option seed_upload: 0 pinned staging (memcpy + DMA), 1 pageable hipMemcpyAsync, 2 hipHostRegister + DMA
 
 // Class scores of the class filter (extend.hip 1d): cls[x] bounds every matrix entry a base pair with (target code ^ query
@@ -184,6 +185,7 @@ void resolve_options() {
     CHAIN_CAP = (uint32_t)opt_value("chain_cap");
     g_audit_cap = (uint32_t)opt_value("audit_cap");
     g_q2_limit = (size_t)opt_value("q2_limit_mb") << 20;
+    g_q2_copies = opt_value("cls_one_copy") == 2 ? Q2_COPIES : 1;
 }
 
 void require_init(const char* who) {

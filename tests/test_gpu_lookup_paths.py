@@ -206,6 +206,7 @@ def test_query_block_beyond_the_2bit_copy_limit_takes_the_general_path(oracle, c
     E = clean
     t, q = synth.make_pair(300000, 61, 62, sub_rate=0.09, mask_frac=0.1, records=2, indel_every=500)
     try:
+        E.set_option("cls_one_copy", 2)  # the sixteen shifted copies (the default one-copy form has no such limit)
         E.set_option("q2_limit_mb", 1)  # 16 copies x ~75 KB = 1.2 MB > 1 MB
         c = Case(t, q, chunk=100000).oracle_setup(oracle).engine_setup(E)
         assert E.lookup_mode() == 2     # the table itself is the context table ...
@@ -226,6 +227,7 @@ def test_query_block_beyond_the_2bit_copy_limit_takes_the_general_path(oracle, c
         assert n > 50
     finally:
         E.reset_option("q2_limit_mb")
+        E.reset_option("cls_one_copy")
 
 
 @pytest.mark.parametrize("mode,env", MODES)

@@ -235,7 +235,11 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                 ea.chain_q_bits = chain_rel ? 32u : 29u;  // (32: diagonal | relative position, no iteration field -- kernels.h)
                 ea.chain_q_base = chain_rel ? ca.q_lo : 0u;
                 ea.chain_cap = chain ? CHAIN_CAP : 0u;
-                ea.chain_buckets = chain_buckets_for(bh);
+                ea.chain_buckets = (uint32_t)g_chain_buckets;  // (0: the device sizes them by the candidates it finds)
+                ea.chain_bucket_target = (uint32_t)g_chain_bucket_target;
+                ea.chain_sort_blocks = (uint32_t)g_chain_sort_blocks;
+                ea.chain_group_max = (uint32_t)g_chain_group_max;
+                ea.chain_no_link = (uint32_t)opt_value("chain_no_link");
                 ea.chain_sort_threads = (uint32_t)g_chain_sort_threads;
                 if (chain) {
                     sl->chain_tmp.ensure(CHAIN_CAP, "chain candidates");

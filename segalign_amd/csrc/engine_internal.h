@@ -431,7 +431,7 @@ extern int g_l2_blocks;
 extern int g_max_waves;
 extern int g_fast_filter;
 extern int g_packed_filter;
-extern int g_chain_sort_threads;
+extern int g_chain_sort_threads, g_chain_buckets, g_chain_bucket_target, g_chain_sort_blocks, g_chain_group_max;
 extern int g_chunks_per_call;
 extern int64_t g_call_hits, g_call_hits_max;
 extern int g_no_small_dedup;

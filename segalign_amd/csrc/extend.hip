@@ -1329,27 +1329,28 @@ constexpr uint32_t CHAIN_WALK_EXTRA = 96; // bases walked past the predecessor's
 // quadratic rank sort is a few microseconds; all buckets together are the candidate list with every diagonal's
 // candidates contiguous and ordered by position -- exactly what the link test needs.  No host involvement.
 constexpr uint32_t CHAIN_BUCKETS_MIN = 16384, CHAIN_BUCKETS_MAX = 262144;  // the host picks a power of two from the batch's hits (ExtendArgs.chain_buckets)
-constexpr uint32_t CHAIN_SORT_MAX = 4096;  // entries a bucket may hold and still be sorted (its keys fill the workgroup's LDS); larger: left unsorted,
+constexpr uint32_t CHAIN_SORT_MAX = 4096;  // most entries a bucket may hold and still be sorted (option chain_group_max <= this); larger: left unsorted,
                                            // which only makes link tests fail, i.e. costs extensions, never correctness
 
 // A bucket = hash of (iteration, diagonal, 512-position window): one diagonal can carry every candidate of a call (a
 // collinear query), so the window keeps a group at <= 512 entries and spreads the counting atomics; chains simply
 // restart at window borders (one extra extension per 512 bases of HSP).
 constexpr uint32_t CHAIN_QSHIFT = 9;
-__device__ __forceinline__ uint32_t chain_bucket_of(const ExtendArgs& a, uint32_t seg, const CandRec& c) {
+__device__ __forceinline__ uint32_t chain_bucket_of(uint32_t buckets, uint32_t seg, const CandRec& c) {
     const uint32_t diag = c.ref_loc - c.query_loc;
-    return (((diag * 2654435761u) ^ ((c.query_loc >> CHAIN_QSHIFT) * 0x85EBCA6Bu) ^ (seg * 0x9E3779B1u)) >> 14) & (a.chain_buckets - 1u);
+    return (((diag * 2654435761u) ^ ((c.query_loc >> CHAIN_QSHIFT) * 0x85EBCA6Bu) ^ (seg * 0x9E3779B1u)) >> 14) & (buckets - 1u);
 }
-__device__ __forceinline__ unsigned long long chain_key(const ExtendArgs& a, const uint64_t* __restrict__ s_seg, const CandRec& c) {
-    // iteration | diagonal (32) | query position (q bits): 3 | 32 | 29 with absolute positions (general path, <= 8 iterations per
-    // batch), 6 | 32 | 26 with positions relative to the call's first one (table-direct calls: <= 64 iterations, <= 8 M positions)
-    const uint32_t qb = a.chain_q_bits;
-    if (qb == 32u) return ((unsigned long long)(uint32_t)(c.ref_loc - c.query_loc) << 32) | (unsigned long long)(c.query_loc - a.chain_q_base);
-    return ((unsigned long long)(seg_of(a, s_seg, c.hidx) - a.seg_base) << (32u + qb)) |
-           ((unsigned long long)(uint32_t)(c.ref_loc - c.query_loc) << qb) |
-           (unsigned long long)((c.query_loc - a.chain_q_base) & ((1u << qb) - 1u));
+// Buckets of this launch: a power of two that leaves ~chain_bucket_target candidates per bucket, from the candidate count ON THE
+// DEVICE (the host has no count before its sync, and the share of the hits that become candidates runs from 0.6 % on ordinary
+// sequence to 3 % on sparse-hit calls and 8 % on repeat-rich ones: sized by hits -- rounds 2-4 -- a bucket held 50 or 300, and the
+// rank sort is quadratic in that).  Every chain kernel of a launch derives the same number from the same count.
+__device__ __forceinline__ uint32_t chain_buckets_of(const ExtendArgs& a, uint32_t n) {
+    if (a.chain_buckets) return a.chain_buckets;  // (forced: option chain_buckets)
+    const uint32_t want = n / a.chain_bucket_target;
+    uint32_t b = CHAIN_BUCKETS_MIN;
+    while (b < CHAIN_BUCKETS_MAX && b < want) b <<= 1;
+    return b;
 }
-
 // The candidates the chain stages of this launch work on: all of the batch when they fit the chain buffers; a slice of the list when
 // the host runs an oversized batch slice by slice; nothing (false) for an oversized batch that is not sliced yet -- the counts live
 // on the device, so the first attempt finds out here and the host follows up after its sync.
@@ -1369,7 +1370,9 @@ __device__ __forceinline__ bool chain_range(const ExtendArgs& a, uint32_t& first
 // bucket (same diagonal, same 512-base window), so 64 lanes used to queue up 20-60 deep on one L2 address -- with 3 % of the hits
 // candidates (sparse-hit calls) counting and scattering took 0.32 ms per call.  The lanes agree on the buckets among themselves:
 // the first active lane's bucket is broadcast, its holders are counted by a ballot and retired, until no lane is left.
-// Returns this lane's rank among the wave's lanes with the same bucket and, in `base`, what the leader's atomic returned.
+// Returns this lane's rank among the wave's lanes with the same bucket and, in `base`, the first slot of the wave's lanes: what the
+// leader's atomic returned (counting up), or that minus the wave's k lanes (DOWN: the counter is taken down by k).
+template <bool DOWN>
 __device__ __forceinline__ uint32_t wave_bucket_add(uint32_t* __restrict__ counters, bool active, uint32_t b, uint32_t& base) {
     const int lane = threadIdx.x & 63;
     uint32_t rank = 0;
@@ -1380,7 +1383,8 @@ __device__ __forceinline__ uint32_t wave_bucket_add(uint32_t* __restrict__ count
         const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)b, leader);
         const unsigned long long same = __ballot(active && b == b0) & todo;
         uint32_t got = 0;
-        if (lane == leader) got = atomicAdd(&counters[b0], (uint32_t)__popcll(same));
+        const uint32_t k = (uint32_t)__popcll(same);
+        if (lane == leader) got = DOWN ? atomicSub(&counters[b0], k) - k : atomicAdd(&counters[b0], k);
         got = (uint32_t)__builtin_amdgcn_readlane((int)got, leader);
         if ((same >> lane) & 1ull) {
             base = got;
@@ -1395,6 +1399,7 @@ __global__ __launch_bounds__(256) void chain_count_kernel(ExtendArgs a) {
     uint32_t first, n;
     if (!chain_range(a, first, n)) return;
     SEG_TABLE()
+    const uint32_t B = chain_buckets_of(a, n);
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t rounds = (n + stride - 1) / stride;  // wave-uniform trip count (ballots inside)
     for (uint32_t r = 0; r < rounds; r++) {
@@ -1402,53 +1407,60 @@ __global__ __launch_bounds__(256) void chain_count_kernel(ExtendArgs a) {
         uint32_t b = 0;
         if (i < n) {
             const CandRec c = a.cand_list[first + i];
-            b = chain_bucket_of(a, seg_of(a, s_seg, c.hidx), c);
+            b = chain_bucket_of(B, seg_of(a, s_seg, c.hidx), c);
         }
         uint32_t base;
-        wave_bucket_add(a.chain_bucket_cnt, i < n, b, base);
+        wave_bucket_add<false>(a.chain_bucket_cnt, i < n, b, base);
     }
 }
 
-// one block: exclusive scan of the a.chain_buckets counters into chain_bucket_start[0..buckets]; counters become cursors.  Tiles of
-// 4096 counters: every thread takes four consecutive ones as ONE 16-byte load (coalesced), wave scan + the totals of the waves
-// before + the running total of the tiles before, results stored the same way.  (Round 3: every thread walked 64 consecutive
-// counters with 4-byte loads, 20 us for 16384 buckets and 80 us for 65536.)
-constexpr uint32_t CHAIN_SCAN_THREADS = 1024;
+// Exclusive scan of the bucket counters into chain_bucket_start[0..buckets].  One workgroup per tile of 4096 counters (every thread
+// takes four consecutive ones as ONE 16-byte load); a workgroup first adds up everything in front of its tile by itself -- at most
+// 1 MB out of the L2, no second kernel and no waiting for another workgroup -- then scans the tile (wave scan + the totals of the
+// waves before).  The counters stay as they are: the scatter counts them DOWN to zero.  (One workgroup walking all tiles, rounds
+// 3-4: 7 us for 16384 buckets, 37 us for 131072.)
+constexpr uint32_t CHAIN_SCAN_THREADS = 1024, CHAIN_SCAN_TILE = CHAIN_SCAN_THREADS * 4;
 __global__ __launch_bounds__(CHAIN_SCAN_THREADS) void chain_scan_kernel(ExtendArgs a) {
-    __shared__ uint32_t s_part[CHAIN_SCAN_THREADS / 64];
-    __shared__ uint32_t s_carry;
-    const uint32_t B = a.chain_buckets;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    uint4* cnt4 = reinterpret_cast<uint4*>(a.chain_bucket_cnt);
+    __shared__ uint32_t s_tile[CHAIN_SCAN_THREADS / 64], s_front[CHAIN_SCAN_THREADS / 64];
+    uint32_t first, n;
+    if (!chain_range(a, first, n)) return;
+    const uint32_t B = chain_buckets_of(a, n);
+    const uint32_t t0 = blockIdx.x * CHAIN_SCAN_TILE;  // (the grid is sized for CHAIN_BUCKETS_MAX)
+    if (t0 >= B) return;
+    const uint4* cnt4 = reinterpret_cast<const uint4*>(a.chain_bucket_cnt);
     uint4* start4 = reinterpret_cast<uint4*>(a.chain_bucket_start);
-    for (uint32_t t0 = 0; t0 < B; t0 += CHAIN_SCAN_THREADS * 4) {
-        const uint32_t q = (t0 >> 2) + threadIdx.x;
-        const uint4 v = cnt4[q];
-        const uint32_t sum = v.x + v.y + v.z + v.w;
-        uint32_t inc = sum;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = __shfl_up(inc, off, 64);
-            if ((int)(threadIdx.x & 63) >= off) inc += t;
-        }
-        if ((threadIdx.x & 63) == 63) s_part[threadIdx.x >> 6] = inc;
-        __syncthreads();
-        uint32_t base = s_carry + inc - sum;
-        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) base += s_part[w];
-        start4[q] = make_uint4(base, base + v.x, base + v.x + v.y, base + v.x + v.y + v.z);
-        cnt4[q] = make_uint4(0u, 0u, 0u, 0u);  // reused as the scatter cursor
-        __syncthreads();
-        if (threadIdx.x == CHAIN_SCAN_THREADS - 1) s_carry = base + sum;
-        __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t front = 0;  // this thread's share of the counters in front of the tile
+    for (uint32_t q = threadIdx.x; q < (t0 >> 2); q += CHAIN_SCAN_THREADS) {
+        const uint4 f = cnt4[q];
+        front += f.x + f.y + f.z + f.w;
     }
-    if (threadIdx.x == 0) a.chain_bucket_start[B] = s_carry;
+    const uint4 v = cnt4[(t0 >> 2) + threadIdx.x];
+    const uint32_t sum = v.x + v.y + v.z + v.w;
+    uint32_t inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) front += __shfl_xor(front, off, 64);
+    if (lane == 63) {
+        s_tile[wave] = inc;
+        s_front[wave] = front;
+    }
+    __syncthreads();
+    uint32_t base = inc - sum;
+    for (int w = 0; w < (int)(CHAIN_SCAN_THREADS / 64); w++) base += s_front[w] + (w < wave ? s_tile[w] : 0u);
+    start4[(t0 >> 2) + threadIdx.x] = make_uint4(base, base + v.x, base + v.x + v.y, base + v.x + v.y + v.z);
+    if (t0 + CHAIN_SCAN_TILE >= B && threadIdx.x == CHAIN_SCAN_THREADS - 1) a.chain_bucket_start[B] = base + sum;  // (= n)
 }
 
 __global__ __launch_bounds__(256) void chain_scatter_kernel(ExtendArgs a) {
     uint32_t first, n;
     if (!chain_range(a, first, n)) return;
     SEG_TABLE()
+    const uint32_t B = chain_buckets_of(a, n);
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t rounds = (n + stride - 1) / stride;
     for (uint32_t r = 0; r < rounds; r++) {
@@ -1457,10 +1469,11 @@ __global__ __launch_bounds__(256) void chain_scatter_kernel(ExtendArgs a) {
         CandRec c = {0u, 0u, 0u};
         if (i < n) {
             c = a.cand_list[first + i];
-            b = chain_bucket_of(a, seg_of(a, s_seg, c.hidx), c);
+            b = chain_bucket_of(B, seg_of(a, s_seg, c.hidx), c);
         }
+        // the counters of the counting pass are the cursors, counted down to zero: a wave takes the k slots below what it finds
         uint32_t base;
-        const uint32_t rank = wave_bucket_add(a.chain_bucket_cnt, i < n, b, base);  // (one cursor atomic per distinct bucket of the wave)
+        const uint32_t rank = wave_bucket_add<true>(a.chain_bucket_cnt, i < n, b, base);  // (one cursor atomic per distinct bucket of the wave)
         if (i < n) a.chain_tmp[a.chain_bucket_start[b] + base + rank] = c;
     }
 }
@@ -1472,7 +1485,9 @@ __global__ __launch_bounds__(256) void chain_scatter_kernel(ExtendArgs a) {
 // sorted list less).  The sorted order is kept as a permutation in LDS; the records are read from the scatter's output and
 // written in order, coalesced.
 constexpr uint32_t CHAIN_SORT_GROUP = 8;
-constexpr uint32_t CHAIN_GROUP_MAX = CHAIN_SORT_MAX;  // entries the workgroup's LDS holds at a time (32 KB of keys): a whole group usually
+// Entries the workgroup's LDS holds at a time = ExtendArgs.chain_group_max (dynamic LDS, 18 bytes per entry; <= CHAIN_SORT_MAX): a
+// whole group usually.  It sets the kernel's occupancy -- round 4 started with 4096 entries = 45 KB = 3 workgroups of 4 waves per CU,
+// and the link test is a chain of dependent random reads that wants every wave slot (4096 -> 1024: -25 % on the kernel).
 
 // does candidate c start a run?  (test (L) of DESIGN.md 4.5' against its predecessor pc on the same diagonal, bounded walk)
 template <bool XDROP_NONNEG>
@@ -1500,19 +1515,38 @@ __device__ __forceinline__ bool chain_is_run_head(const ExtendArgs& a, const uin
     return true;
 }
 
+// Sort key of an entry, 32 bits, unique inside a piece: 11 bits of a hash of its diagonal and 512-position window (and iteration) |
+// its position inside the window | its index in the piece.  Entries of one diagonal AND window always share a bucket
+// (chain_bucket_of) and these hash bits, so the low position bits order them; two (diagonal, window) pairs of a bucket that share the
+// 11 bits (1 in 2048) interleave, which only makes link tests fail.  The window must be in the hash: a collinear query puts most
+// candidates on ONE diagonal, a bucket then holds several windows of it, and ordered by (diagonal, position mod 512) they interleave
+// completely (first cut of this key: 8 x the extensions).  The multipliers are not the bucket hash's: a bucket's entries agree in
+// bits 14.. of THAT product.  (Rounds 1-4 ranked 64-bit keys {diagonal, position}: twice the LDS bytes, 64-bit compares, one key
+// per LDS read.)
+__device__ __forceinline__ uint32_t chain_key32(const ExtendArgs& a, const uint64_t* __restrict__ s_seg, const CandRec& c, uint32_t idx) {
+    uint32_t h = ((c.ref_loc - c.query_loc) * 0xC2B2AE35u) ^ ((c.query_loc >> CHAIN_QSHIFT) * 0x27D4EB2Fu);
+    if (a.chain_q_bits != 32u) h ^= (seg_of(a, s_seg, c.hidx) - a.seg_base) * 0x165667B1u;  // (several iterations per batch: general path)
+    return (h & 0xFFE00000u) | ((c.query_loc & ((1u << CHAIN_QSHIFT) - 1u)) << 12) | idx;
+}
+static_assert(CHAIN_QSHIFT == 9 && CHAIN_SORT_MAX <= 4096, "chain_key32: 11 + 9 + 12 bits");
+
 template <bool XDROP_NONNEG>
 __global__ __launch_bounds__(512) void chain_sort_link_kernel(ExtendArgs a) {
-    __shared__ unsigned long long s_key[CHAIN_GROUP_MAX];  // 32 KB: the group's keys, when they fit
-    __shared__ uint16_t s_perm[CHAIN_GROUP_MAX];            // sorted position -> entry of the group
+    // LDS of a piece (chain_group_max = GM entries, 18 bytes each): keys -- every bucket's keys start at a multiple of four and are
+    // padded with 0xFFFFFFFF, so the rank loop reads four per instruction --, the records themselves (read once from the scatter's
+    // output, then ranked, linked and written in order from here), the permutation sorted position -> entry
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_chain_dyn[];
+    const uint32_t CHAIN_GROUP_MAX = a.chain_group_max;
+    uint32_t* s_key = s_chain_dyn;                                                          // [GM + 4 * CHAIN_SORT_GROUP]
+    CandRec* s_rec = reinterpret_cast<CandRec*>(s_chain_dyn + CHAIN_GROUP_MAX + 4 * CHAIN_SORT_GROUP);  // [GM]
+    uint16_t* s_perm = reinterpret_cast<uint16_t*>(s_rec + CHAIN_GROUP_MAX);               // [GM]
     __shared__ uint32_t s_b[CHAIN_SORT_GROUP + 1];
     __shared__ int s_tab[128];
     uint32_t first, n;
     if (!chain_range(a, first, n)) return;
     SEG_TABLE()
     if (threadIdx.x < 128) s_tab[threadIdx.x] = threadIdx.x < 64 ? a.sub_mat[threadIdx.x] : NEG;
-    if (threadIdx.x <= CHAIN_SORT_GROUP) s_b[threadIdx.x] = a.chain_bucket_start[blockIdx.x * CHAIN_SORT_GROUP + threadIdx.x];
-    __syncthreads();
-    if (s_b[CHAIN_SORT_GROUP] == s_b[0]) return;
+    const uint32_t groups = chain_buckets_of(a, n) / CHAIN_SORT_GROUP;
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     const uint8_t* __restrict__ R8b = a.ref8 - BIAS;
@@ -1520,27 +1554,50 @@ __global__ __launch_bounds__(512) void chain_sort_link_kernel(ExtendArgs a) {
     // The group is handled in pieces of consecutive buckets that fit the LDS together (usually the whole group at once; a group of
     // crowded buckets -- sparse-hit calls carry 3 % candidates -- goes bucket by bucket).  Only a single bucket above the LDS
     // capacity is left unsorted, every entry of it a run head (costs extensions, never results).
+    for (uint32_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {  // (the grid is the host's, the group count the device's)
+    __syncthreads();  // (s_b of the group before is done with; first round: s_tab is written)
+    if (threadIdx.x <= CHAIN_SORT_GROUP) s_b[threadIdx.x] = a.chain_bucket_start[grp * CHAIN_SORT_GROUP + threadIdx.x];
+    __syncthreads();
+    if (s_b[CHAIN_SORT_GROUP] == s_b[0]) continue;
     for (uint32_t ja = 0; ja < CHAIN_SORT_GROUP;) {
         uint32_t jb = ja + 1;
         while (jb < CHAIN_SORT_GROUP && s_b[jb + 1] - s_b[ja] <= CHAIN_GROUP_MAX) jb++;
         const uint32_t g0 = s_b[ja], m_all = s_b[jb] - g0;
         const bool big = m_all > CHAIN_GROUP_MAX;  // (then jb == ja + 1: one bucket that does not fit)
         if (m_all == 0) { ja = jb; continue; }
+        // entry i of the piece -> its bucket [lo, hi) (piece-relative) and where the bucket's padded keys start
+        auto bucket_of = [&](uint32_t i, uint32_t& lo, uint32_t& hi, uint32_t& kb) {
+            uint32_t j = ja;
+            kb = 0;
+            while (g0 + i >= s_b[j + 1]) {
+                kb += (s_b[j + 1] - s_b[j] + 3u) & ~3u;
+                j++;
+            }
+            lo = s_b[j] - g0;
+            hi = s_b[j + 1] - g0;
+        };
         if (!big) {
-            for (uint32_t i = threadIdx.x; i < m_all; i += blockDim.x) s_key[i] = chain_key(a, s_seg, a.chain_tmp[g0 + i]);
+            for (uint32_t i = threadIdx.x; i < m_all; i += blockDim.x) {
+                const CandRec c = a.chain_tmp[g0 + i];
+                s_rec[i] = c;
+                uint32_t lo, hi, kb;
+                bucket_of(i, lo, hi, kb);
+                s_key[kb + (i - lo)] = chain_key32(a, s_seg, c, i);
+                if (i + 1 == hi)
+                    for (uint32_t t = kb + (hi - lo); t < kb + ((hi - lo + 3u) & ~3u); t++) s_key[t] = 0xFFFFFFFFu;
+            }
             __syncthreads();
             for (uint32_t i = threadIdx.x; i < m_all; i += blockDim.x) {
-                uint32_t j = ja;  // the entry's bucket
-                while (g0 + i >= s_b[j + 1]) j++;
-                const uint32_t lo = s_b[j] - g0, hi = s_b[j + 1] - g0;
-                const unsigned long long k = s_key[i];
-                // rank = entries below this one; keys are unique per hit, and hand-made ties (a foreign host's duplicate seed words) are
-                // broken by the index: "<=" before i, "<" behind it -- one compare + one add-with-carry per entry either way
-                uint32_t rank = 0;
-#pragma unroll 4
-                for (uint32_t t = lo; t < i; t++) rank += s_key[t] <= k ? 1u : 0u;
-#pragma unroll 4
-                for (uint32_t t = i + 1; t < hi; t++) rank += s_key[t] < k ? 1u : 0u;
+                uint32_t lo, hi, kb;
+                bucket_of(i, lo, hi, kb);
+                const uint32_t k = s_key[kb + (i - lo)];
+                uint32_t rank = 0;  // entries of the bucket below this one (keys are unique: the index is part of them)
+                const uint32_t ke = kb + ((hi - lo + 3u) & ~3u);
+#pragma unroll 2
+                for (uint32_t t = kb; t < ke; t += 4) {
+                    const uint4 kk = *reinterpret_cast<const uint4*>(s_key + t);
+                    rank += (kk.x < k ? 1u : 0u) + (kk.y < k ? 1u : 0u) + (kk.z < k ? 1u : 0u) + (kk.w < k ? 1u : 0u);
+                }
                 s_perm[lo + rank] = (uint16_t)i;
             }
             __syncthreads();
@@ -1552,13 +1609,13 @@ __global__ __launch_bounds__(512) void chain_sort_link_kernel(ExtendArgs a) {
             const uint32_t p = r * blockDim.x + threadIdx.x;  // sorted position inside the piece
             bool head = false;
             if (p < m_all) {
-                const CandRec c = a.chain_tmp[g0 + (big ? p : (uint32_t)s_perm[p])];
+                const CandRec c = big ? a.chain_tmp[g0 + p] : s_rec[s_perm[p]];
                 a.chain_sorted[g0 + p] = c;
                 head = true;
                 if (!big) {
-                    uint32_t j = ja;
-                    while (g0 + p >= s_b[j + 1]) j++;
-                    if (g0 + p > s_b[j]) head = chain_is_run_head<XDROP_NONNEG>(a, s_seg, s_tab, R8b, Qb, c, a.chain_tmp[g0 + (uint32_t)s_perm[p - 1]]);
+                    uint32_t lo, hi, kb;
+                    bucket_of(p, lo, hi, kb);
+                    if (p > lo && !a.chain_no_link) head = chain_is_run_head<XDROP_NONNEG>(a, s_seg, s_tab, R8b, Qb, c, s_rec[s_perm[p - 1]]);
                 }
                 a.chain_is_head[g0 + p] = head ? 1u : 0u;
             }
@@ -1574,6 +1631,7 @@ __global__ __launch_bounds__(512) void chain_sort_link_kernel(ExtendArgs a) {
         }
         __syncthreads();  // (the next piece reuses the LDS)
         ja = jb;
+    }
     }
 }
 
@@ -1709,17 +1767,12 @@ void launch_extend_filter_cls(const ExtendArgs& a, hipStream_t s) {
 void launch_chain_group(const ExtendArgs& a, hipStream_t s) {  // chain_bucket_cnt must be zero on entry
     if (a.num_hits == 0 || !a.chain_cap) return;
     hipLaunchKernelGGL(chain_count_kernel, dim3(1024), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(chain_scan_kernel, dim3(1), dim3(CHAIN_SCAN_THREADS), 0, s, a);
+    hipLaunchKernelGGL(chain_scan_kernel, dim3(CHAIN_BUCKETS_MAX / CHAIN_SCAN_TILE), dim3(CHAIN_SCAN_THREADS), 0, s, a);
     hipLaunchKernelGGL(chain_scatter_kernel, dim3(1024), dim3(256), 0, s, a);
-    hipLaunchKernelGGL((chain_sort_link_kernel<true>), dim3(a.chain_buckets / CHAIN_SORT_GROUP), dim3(a.chain_sort_threads ? a.chain_sort_threads : 256), 0, s, a);
+    hipLaunchKernelGGL((chain_sort_link_kernel<true>), dim3(a.chain_sort_blocks ? a.chain_sort_blocks : 4096), dim3(a.chain_sort_threads ? a.chain_sort_threads : 256),
+                       (size_t)a.chain_group_max * (sizeof(uint32_t) + sizeof(CandRec) + sizeof(uint16_t)) + 4 * CHAIN_SORT_GROUP * sizeof(uint32_t), s, a);
 }
 uint32_t chain_num_buckets() { return CHAIN_BUCKETS_MAX; }  // (what the bucket arrays are sized for)
-// buckets for a batch of `hits` seed hits: ~0.6 % of them become candidates on ordinary sequence, and a bucket should hold ~100
-uint32_t chain_buckets_for(uint64_t hits) {
-    uint32_t b = CHAIN_BUCKETS_MIN;
-    while (b < CHAIN_BUCKETS_MAX && (uint64_t)b * 16384ull < hits) b <<= 1;
-    return b;
-}
 void launch_extend_exact_chain(const ExtendArgs& a, hipStream_t s) {
     if (a.num_hits == 0 || !a.chain_cap) return;
     hipLaunchKernelGGL((extend_exact_chain_kernel<true>), dim3(a.long_blocks), dim3(EXT_THREADS), 0, s, a);

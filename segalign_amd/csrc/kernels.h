@@ -120,7 +120,11 @@ struct ExtendArgs {
     uint32_t ent_cap_recs;
     // chain shortcut of the exact stage (extend.hip 2b); chain_cap == 0 disables it
     uint32_t chain_cap;                      // candidates per batch the chain buffers hold
-    uint32_t chain_buckets;                  // hash buckets of this batch (power of two, chain_buckets_for)
+    uint32_t chain_buckets;                  // 0: the device picks the hash buckets from the candidate count (chain_buckets_of); else forced (power of two)
+    uint32_t chain_bucket_target;            // candidates a bucket should hold (> 0)
+    uint32_t chain_group_max;                // entries the sort + link kernel holds in LDS at a time (64 .. 4096)
+    uint32_t chain_no_link;                  // (measurement) 1: no link test, every candidate is a run head
+    uint32_t chain_sort_blocks;              // workgroups of the sort + link kernel (0: 4096); they loop over the bucket groups
     uint32_t cand_sliced, cand_first;        // cand_sliced: the chain stages work on candidates [cand_first, cand_first + chain_cap) of the list
                                              // (a batch with more candidates than the chain buffers hold is run slice by slice)
     uint32_t* chain_bucket_cnt;              // [buckets] counters, then scatter cursors (zero on entry)
@@ -164,10 +168,10 @@ struct ExtendArgs {
     uint32_t* l2_max;           // -> largest sub-list count (> l2_cap: records were dropped, the host regrows and reruns)
     int src_cand;               // packed filter reads its anchors from l2_list / *l2_count instead of `hits`
     uint32_t ctx_waves;         // wave budget of the context filter (0: one chunk of TD_CHUNK_HITS hits per wave)
-    uint32_t chain_q_bits;      // chain sort key = iteration | diagonal (32) | query position (chain_q_bits) relative to chain_q_base;
-                                // 32: no iteration field -- diagonal (32) | relative position (32): table-direct calls, where the hits of a
-                                // diagonal are in iteration order anyway (the link test compares the iterations itself)
-    uint32_t chain_q_base;
+    uint32_t chain_q_bits;      // 32: table-direct call -- the chain sort key (chain_key32) hashes the diagonal alone, the hits of a diagonal are in
+                                // iteration order anyway and the link test compares the iterations itself; else (general path, several iterations
+                                // per batch) the iteration goes into the hash
+    uint32_t chain_q_base;      // (unused since the 32-bit keys: positions enter the key modulo the bucket window)
     uint32_t ctx_threads;       // workgroup size of the context filter (0: its default)
     uint32_t cls_one_copy;      // 0 / 1: query windows from the unshifted copy (default), 2: from the sixteen shifted copies
     uint32_t l2_blocks;         // grid of the second level (its hit count is known on the device only)
@@ -264,7 +268,6 @@ void launch_extend_exact(const ExtendArgs& a, hipStream_t s);    // candidates -
 // chain shortcut: keys -> (sort, dedup.hip) -> links/run heads -> one exact extension per run
 void launch_chain_group(const ExtendArgs& a, hipStream_t s);
 uint32_t chain_num_buckets();
-uint32_t chain_buckets_for(uint64_t hits);
 void launch_extend_exact_chain(const ExtendArgs& a, hipStream_t s);
 void launch_extend_entropy(const ExtendArgs& a, hipStream_t s);  // entropy records -> survivors
 

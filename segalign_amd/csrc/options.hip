@@ -39,6 +39,7 @@ int g_max_waves = 4096;    // SEGALIGN_AMD_MAX_WAVES: waves of the filter kernel
 int g_fast_filter = 0;     // derived in InitializeProcessor: xdrop >= 0 && 7*max(M) <= xdrop
 int g_packed_filter = 0;   // derived in InitializeProcessor: the packed upper-bound filter may be used
 int g_chain_sort_threads = 256;  // SEGALIGN_AMD_CHAIN_SORT_THREADS
+int g_chain_buckets = 0, g_chain_bucket_target = 32, g_chain_sort_blocks = 0, g_chain_group_max = 1024;
 int64_t g_call_hits_max = 1ll << 30;  // option call_hits_max
 int64_t g_call_hits = 128ll << 20;  // option call_hits: seed hits a call is sized for when the resident target's hits are sparse (0: chunks_per_call only)
 int g_chunks_per_call = SA_DEFAULT_CHUNKS;  // SEGALIGN_AMD_CHUNKS_PER_CALL: chunks sa_seed_interval hands to one multi-chunk call
@@ -123,12 +124,14 @@ static Option g_opts[] = {
     {"long_blocks", 1792, 1, 1 << 20, 0}, {"max_waves", 4096, 4, 1 << 20, 0}, {"packed_waves", 4096, 8, 1 << 20, 0},
     {"l2_blocks", 512, 1, 1 << 20, 0}, {"ctx_waves", 0, 0, 1 << 20, 0}, {"ctx_threads", 0, 0, 1024, 0},
     {"chain_sort_threads", 256, 64, 512, 0}, {"dedup_threads", 0, 0, 1024, 0},
+    {"chain_buckets", 0, 0, 262144, 0},                // chain hash buckets: 0 = picked on the device, ~chain_bucket_target candidates each; else forced (rounded to a power of two in 64 .. 262144; small counts crowd the buckets: tests)
+    {"chain_bucket_target", 32, 1, 4096, 0}, {"chain_sort_blocks", 0, 0, 1 << 16, 0}, {"chain_group_max", 1024, 64, 4096, 0},
     {"cls_one_copy", 0, 0, 2, 0},                      // class filter's query windows: 0 / 1 unshifted copy + funnel shifts (default), 2 the sixteen shifted copies (round 3's form)
     {"nbr_one_stage", 0, 0, 1, 0}, {"table_atomic", 0, 0, 1, 0}, {"seed_upload", 0, 0, 2, 0},
     // test-only: small capacities that force the overflow / fallback branches
     {"l2_cap", 0, 0, 1 << 30, 1}, {"spec_dedup", 1, 0, 1, 1}, {"spec_recs", 16384, 1, 16384, 1}, {"dedup_seg_max", 0, 0, 1 << 30, 1},
     {"q2_limit_mb", 4096, 1, 4096, 1},                 // (tests) bytes the 16 two-bit copies of a query strand may span before calls leave the table-direct path
-    {"no_small_dedup", 0, 0, 1, 1}, {"chain_cap", 1 << 23, 1, 1 << 30, 1}, {"audit_cap", 0, 0, 1 << 28, 1},
+    {"no_small_dedup", 0, 0, 1, 1}, {"chain_no_link", 0, 0, 1, 1}, {"chain_cap", 1 << 23, 1, 1 << 30, 1}, {"audit_cap", 0, 0, 1 << 28, 1},
 };
 static Option* find_option(const char* name) {
     for (auto& o : g_opts)
@@ -173,6 +176,14 @@ void resolve_options() {
     g_ctx_waves = (int)opt_value("ctx_waves");
     g_ctx_threads = (int)opt_value("ctx_threads");
     g_chain_sort_threads = (int)opt_value("chain_sort_threads") & ~63;
+    g_chain_buckets = 0;
+    if (opt_value("chain_buckets")) {
+        g_chain_buckets = 64;
+        while (g_chain_buckets < 262144 && g_chain_buckets < (int)opt_value("chain_buckets")) g_chain_buckets <<= 1;
+    }
+    g_chain_bucket_target = (int)opt_value("chain_bucket_target");
+    g_chain_sort_blocks = (int)opt_value("chain_sort_blocks");
+    g_chain_group_max = (int)opt_value("chain_group_max") & ~63;
     g_dedup_threads = (int)opt_value("dedup_threads");
     g_nbr_two_stage = opt_value("nbr_one_stage") ? 0 : 1;
     g_table_atomic = (int)opt_value("table_atomic");

@@ -103,3 +103,23 @@ def test_candidate_list_larger_than_the_chain_buffers(oracle, engine):
     finally:
         os.environ.pop("SEGALIGN_AMD_CHAIN_CAP", None)
     assert surv > 0 and run.flags & engine.PATH_CHAIN_SLICED
+
+
+def test_crowded_buckets_keep_the_windows_of_one_diagonal_apart(oracle, engine):
+    """A collinear pair puts every candidate on ONE diagonal; with few hash buckets (option chain_buckets) a bucket holds several
+    512-position windows of it.  The sort key must keep the windows apart -- ordered by (diagonal, position mod 512) alone they
+    interleave, every link test fails and every candidate is extended (the first cut of the 32-bit keys did exactly that: same
+    output, 8 x the extensions).  Same output with 128 buckets as with the default, and nearly as few extensions."""
+    t1, q1 = synth.make_pair(60000, 41, 42, sub_rate=0.03, invert_frac=0.0)
+    base, s_base = run(engine, oracle, t1, q1, True, chunk=30000)
+    os.environ["SEGALIGN_AMD_CHAIN_BUCKETS"] = "128"   # ~60 windows of 512 candidates per call in 128 buckets: a dozen shared buckets,
+    os.environ["SEGALIGN_AMD_CHAIN_GROUP_MAX"] = "4096"  # each still within what a workgroup sorts (larger ones are left unsorted)
+    try:
+        few, s_few = run(engine, oracle, t1, q1, True, chunk=30000)
+    finally:
+        os.environ.pop("SEGALIGN_AMD_CHAIN_BUCKETS", None)
+        os.environ.pop("SEGALIGN_AMD_CHAIN_GROUP_MAX", None)
+    off, s_off = run(engine, oracle, t1, q1, False, chunk=30000)
+    assert all(np.array_equal(a, b) for a, b in zip(base, few))
+    assert s_base * 5 < s_off          # the shortcut is worth something on this input at all ...
+    assert s_few <= 1.25 * s_base + 64  # ... and crowding the buckets costs next to nothing (interleaved windows: thousands)

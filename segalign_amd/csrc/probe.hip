@@ -197,6 +197,7 @@ void launch_nbr_fill(const uint32_t* bucket_start, const uint32_t* pos_table, ui
 constexpr int PR_THREADS = 256;
 constexpr int PR_ITEMS = 4;                       // positions per thread: one ALIGNED group of four (kmer4_at)
 constexpr int PR_TILE = PR_THREADS * PR_ITEMS;    // positions per workgroup
+constexpr int HB_LDS_WORDS = 4096;                // head-bit words a workgroup of the compaction gathers in LDS (16 KB: 131072 hits)
 
 struct Tri { uint64_t hits; uint32_t ne, valid; };  // (hits, non-empty positions, valid positions)
 
@@ -245,23 +246,36 @@ __global__ __launch_bounds__(PR_THREADS) void probe_kernel(const uint8_t* __rest
     if (e0 < n + skew) {
         uint32_t key[4];
         const uint32_t valid = kmer4_at(query, (start - skew) + e0, sh, key);
+        uint64_t off[PR_ITEMS];
+        uint32_t cnt[PR_ITEMS];
 #pragma unroll
         for (int j = 0; j < PR_ITEMS; j++) {
             const uint32_t e = e0 + j;
+            off[j] = 0;
+            cnt[j] = 0;
             if (e < skew || e - skew >= n) continue;
-            const uint32_t i = e - skew;
-            uint64_t off = 0;
-            uint32_t cnt = 0;
             if (((valid >> j) & 1u) && key[j] < nkeys) {
                 const uint64_t b = nbr_start[key[j]], en = nbr_start[key[j] + 1];  // adjacent: one 16-byte extent per POSITION
-                off = b | PR_VALID;
-                cnt = (uint32_t)(en - b);
+                off[j] = b | PR_VALID;
+                cnt[j] = (uint32_t)(en - b);
                 mine.valid++;
-                mine.ne += cnt ? 1u : 0u;
-                mine.hits += cnt;
+                mine.ne += cnt[j] ? 1u : 0u;
+                mine.hits += cnt[j];
             }
-            t_off[i] = off;
-            t_cnt[i] = cnt;
+        }
+        if (skew == 0u && e0 + (PR_ITEMS - 1) < n) {  // (calls start at multiples of four as a rule: three aligned 16-byte stores)
+            static_assert(PR_ITEMS == 4, "vector stores of four positions");
+            *reinterpret_cast<uint4*>(t_off + e0) = make_uint4((uint32_t)off[0], (uint32_t)(off[0] >> 32), (uint32_t)off[1], (uint32_t)(off[1] >> 32));
+            *reinterpret_cast<uint4*>(t_off + e0 + 2) = make_uint4((uint32_t)off[2], (uint32_t)(off[2] >> 32), (uint32_t)off[3], (uint32_t)(off[3] >> 32));
+            *reinterpret_cast<uint4*>(t_cnt + e0) = make_uint4(cnt[0], cnt[1], cnt[2], cnt[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < PR_ITEMS; j++) {
+                const uint32_t e = e0 + j;
+                if (e < skew || e - skew >= n) continue;
+                t_off[e - skew] = off[j];
+                t_cnt[e - skew] = cnt[j];
+            }
         }
     }
     Tri total;
@@ -269,20 +283,32 @@ __global__ __launch_bounds__(PR_THREADS) void probe_kernel(const uint8_t* __rest
     if (threadIdx.x == 0) partial[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(PR_THREADS) void probe_partials_kernel(Tri* __restrict__ partial, uint32_t nblocks, Tri* __restrict__ total_out) {
-    // one workgroup: every thread owns a contiguous slice of the block sums (serial sum, ONE workgroup scan, serial write-back)
-    const uint32_t per = (nblocks + PR_THREADS - 1) / PR_THREADS;
-    const uint32_t lo = min(threadIdx.x * per, nblocks), hi = min(lo + per, nblocks);
+// Exclusive prefixes of the workgroup sums, OUT of place (`scanned`; the sums stay, so a repeated compaction needs no second scan).
+// One workgroup per 1024 sums: it adds up everything in front of its tile by itself (at most ~0.4 MB out of the L2), then scans its
+// tile; the last workgroup also leaves the total.  (Rounds 2-4: ONE workgroup walked all sums serially, 75 us per 22 M positions.)
+constexpr int PP_ITEMS = 4;
+__global__ __launch_bounds__(PR_THREADS) void probe_partials_kernel(const Tri* __restrict__ partial, uint32_t nblocks, Tri* __restrict__ scanned,
+                                                                    Tri* __restrict__ total_out) {
+    const uint32_t t0 = blockIdx.x * (PR_THREADS * PP_ITEMS);
+    Tri front = {0, 0, 0};
+    for (uint32_t i = threadIdx.x; i < t0; i += PR_THREADS) front = tri_add(front, partial[i]);
+    const uint32_t lo = t0 + threadIdx.x * PP_ITEMS;
+    Tri v[PP_ITEMS];
     Tri mine = {0, 0, 0};
-    for (uint32_t i = lo; i < hi; i++) mine = tri_add(mine, partial[i]);
-    Tri total;
-    Tri run = block_excl_scan(mine, total);
-    for (uint32_t i = lo; i < hi; i++) {
-        const Tri v = partial[i];
-        partial[i] = run;
-        run = tri_add(run, v);
+#pragma unroll
+    for (int j = 0; j < PP_ITEMS; j++) {
+        v[j] = lo + j < nblocks ? partial[lo + j] : Tri{0, 0, 0};
+        mine = tri_add(mine, v[j]);
     }
-    if (threadIdx.x == 0) *total_out = total;
+    Tri front_total, tile_total;
+    block_excl_scan(front, front_total);
+    Tri run = tri_add(block_excl_scan(mine, tile_total), front_total);
+#pragma unroll
+    for (int j = 0; j < PP_ITEMS; j++) {
+        if (lo + j < nblocks) scanned[lo + j] = run;
+        run = tri_add(run, v[j]);
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = tri_add(front_total, tile_total);
 }
 
 // bounds[c] = exclusive prefix (hits, non-empty, valid) at position bpos[c] - start, c = 0..nb-1 (a bound == n takes the total)
@@ -297,21 +323,51 @@ __global__ __launch_bounds__(PR_THREADS) void probe_compact_kernel(uint32_t star
     uint64_t off[PR_ITEMS];
     uint32_t cnt[PR_ITEMS];
     Tri mine = {0, 0, 0};
+    if (skew == 0u && i0 + (PR_ITEMS - 1) < n) {
+        // (the usual case -- calls start at chunk borders, multiples of four: the thread's four extents and counts are three aligned
+        //  16-byte loads instead of eight narrow ones, each of which made the wave touch four times the lines it used)
+        static_assert(PR_ITEMS == 4, "vector loads of four positions");
+        const uint4 o01 = *reinterpret_cast<const uint4*>(t_off + i0), o23 = *reinterpret_cast<const uint4*>(t_off + i0 + 2);
+        const uint4 c4 = *reinterpret_cast<const uint4*>(t_cnt + i0);
+        off[0] = ((uint64_t)o01.y << 32) | o01.x; off[1] = ((uint64_t)o01.w << 32) | o01.z;
+        off[2] = ((uint64_t)o23.y << 32) | o23.x; off[3] = ((uint64_t)o23.w << 32) | o23.z;
+        cnt[0] = c4.x; cnt[1] = c4.y; cnt[2] = c4.z; cnt[3] = c4.w;
+    } else {
 #pragma unroll
-    for (int j = 0; j < PR_ITEMS; j++) {
-        const uint32_t i = i0 + j;
-        off[j] = 0;
-        cnt[j] = 0;
-        if (i < n) {
-            off[j] = t_off[i];
-            cnt[j] = t_cnt[i];
-            mine.valid += (off[j] & PR_VALID) ? 1u : 0u;
-            mine.ne += cnt[j] ? 1u : 0u;
-            mine.hits += cnt[j];
+        for (int j = 0; j < PR_ITEMS; j++) {
+            const uint32_t i = i0 + j;
+            off[j] = 0;
+            cnt[j] = 0;
+            if (i < n) {
+                off[j] = t_off[i];
+                cnt[j] = t_cnt[i];
+            }
         }
     }
+#pragma unroll
+    for (int j = 0; j < PR_ITEMS; j++) {
+        mine.valid += (off[j] & PR_VALID) ? 1u : 0u;
+        mine.ne += cnt[j] ? 1u : 0u;
+        mine.hits += cnt[j];
+    }
     Tri tot;
-    Tri run = tri_add(block_excl_scan(mine, tot), partial[blockIdx.x]);
+    const Tri block_base = partial[blockIdx.x];
+    Tri run = tri_add(block_excl_scan(mine, tot), block_base);
+    // The workgroup's records and head bits are put together in LDS and leave in whole lines: its <= 1024 records are consecutive
+    // in c_rec (16-byte stores at a 64-byte stride per lane before: every line was touched by four store instructions), and its
+    // head bits span the words [w0, w0 + hb_words) of the map -- set with LDS atomics, the inner words stored plainly, only the
+    // first and the last one OR-ed into memory (they are shared with the neighbouring workgroups).  Before: one global atomic per
+    // position on dense input, 10 M per call.  A workgroup whose hits span more words than the LDS holds (> 128 hits per position
+    // on average) keeps the per-thread atomics.
+    __shared__ TdRec s_rec[PR_TILE];
+    __shared__ uint32_t s_hb[HB_LDS_WORDS];
+    const uint32_t w0 = (uint32_t)(block_base.hits >> 5);
+    const uint32_t hb_words = tot.hits ? (uint32_t)((block_base.hits + tot.hits - 1) >> 5) - w0 + 1u : 0u;
+    const bool hb_lds = head_bits && hb_words <= (uint32_t)HB_LDS_WORDS;
+    if (hb_lds) {
+        for (uint32_t t = threadIdx.x; t < hb_words; t += PR_THREADS) s_hb[t] = 0u;
+        __syncthreads();
+    }
     // the first chunk boundary at or behind this thread's first position (boundaries sit at multiples of the chunk size: at most one
     // falls into the thread's PR_ITEMS consecutive positions, PR_ITEMS <= chunk)
     const uint32_t i_first = i0 + ((int32_t)i0 < 0 ? skew : 0u);  // (the first thread of the grid starts below position 0)
@@ -335,10 +391,12 @@ __global__ __launch_bounds__(PR_THREADS) void probe_compact_kernel(uint32_t star
             r.prefix = (uint32_t)run.hits;  // (a call with >= 2^32 hits is sent down the general path, engine.hip td_front)
             r.qpos = start + i;
             r.off = off[j] & ~PR_VALID;
-            c_rec[run.ne] = r;
+            s_rec[run.ne - block_base.ne] = r;
             // head bit of the position's first hit: bit g of the call-wide bitmap <=> a record starts at hit g.  The class filter
             // finds the record of every hit of a 64-hit buffer from ONE 64-bit word of it (extend.hip 1d)
-            if (head_bits && (uint32_t)(run.hits >> 5) < head_words) {
+            if (hb_lds) {
+                atomicOr(&s_hb[(uint32_t)(run.hits >> 5) - w0], 1u << (run.hits & 31u));
+            } else if (head_bits && (uint32_t)(run.hits >> 5) < head_words) {
                 const uint32_t w = (uint32_t)(run.hits >> 5);
                 if (w != hb_word) {
                     if (hb_mask) atomicOr(&head_bits[hb_word], hb_mask);
@@ -356,6 +414,18 @@ __global__ __launch_bounds__(PR_THREADS) void probe_compact_kernel(uint32_t star
         run.valid += (off[j] & PR_VALID) ? 1u : 0u;
     }
     if (hb_mask) atomicOr(&head_bits[hb_word], hb_mask);
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < tot.ne; t += PR_THREADS) c_rec[block_base.ne + t] = s_rec[t];
+    if (hb_lds)
+        for (uint32_t t = threadIdx.x; t < hb_words; t += PR_THREADS) {
+            const uint32_t w = w0 + t, m = s_hb[t];
+            if (w >= head_words) break;  // (a map that is too small is regrown by the host and the compaction repeated)
+            if (t == 0u || t + 1u == hb_words) {
+                if (m) atomicOr(&head_bits[w], m);
+            } else {
+                head_bits[w] = m;
+            }
+        }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const Tri t = *total;
         TdRec r;
@@ -430,7 +500,8 @@ __global__ __launch_bounds__(256) void call_clear_kernel(const Tri* __restrict__
         for (uint64_t i = tid; i < z.n[r]; i += nth) z.p[r][i] = 0u;
 }
 
-size_t probe_partial_bytes(uint32_t n) { return ((size_t)(n + 3 + PR_TILE - 1) / PR_TILE + 2) * sizeof(Tri); }
+// workgroup sums [blocks] | total, pad | their exclusive prefixes [blocks]
+size_t probe_partial_bytes(uint32_t n) { return (2 * ((size_t)(n + 3 + PR_TILE - 1) / PR_TILE) + 2) * sizeof(Tri); }
 size_t probe_bounds_bytes() { return (size_t)TD_MAX_BOUNDS * sizeof(Tri); }
 
 static inline uint32_t probe_blocks(uint32_t start, uint32_t n) { return (n + (start & 3u) + PR_TILE - 1) / PR_TILE; }
@@ -446,11 +517,13 @@ void launch_probe_compact(uint32_t start, uint32_t n, const uint64_t* t_off, con
     Tri* partial = reinterpret_cast<Tri*>(partial_buf);
     const uint32_t nblocks = probe_blocks(start, n);
     Tri* total = partial + nblocks;
-    // (the block sums are turned into prefixes IN PLACE: only once per probe -- a repeated compaction, after the head-bit map
-    //  was regrown, starts from the prefixes)
-    if (first_pass) hipLaunchKernelGGL(probe_partials_kernel, dim3(1), dim3(PR_THREADS), 0, s, partial, nblocks, total);
+    Tri* scanned = partial + nblocks + 2;
+    // (only once per probe: a repeated compaction, after the head-bit map was regrown, finds the prefixes in place)
+    if (first_pass)
+        hipLaunchKernelGGL(probe_partials_kernel, dim3((nblocks + PR_THREADS * PP_ITEMS - 1) / (PR_THREADS * PP_ITEMS)), dim3(PR_THREADS), 0, s, partial,
+                           nblocks, scanned, total);
     hipLaunchKernelGGL(call_clear_kernel, dim3(head_bits ? 1024 : 64), dim3(256), 0, s, total, head_bits, head_words, zero);
-    hipLaunchKernelGGL(probe_compact_kernel, dim3(nblocks), dim3(PR_THREADS), 0, s, start, n, t_off, t_cnt, partial, total, c_rec, chunk_rec,
+    hipLaunchKernelGGL(probe_compact_kernel, dim3(nblocks), dim3(PR_THREADS), 0, s, start, n, t_off, t_cnt, scanned, total, c_rec, chunk_rec,
                        chunk_cap, head_bits, head_words, bpos, reinterpret_cast<Tri*>(bounds_buf));
 }
 void launch_probe_plan(const uint8_t* query, SeedShape sh, uint32_t tmask, const uint32_t* bucket_start, const void* bounds_buf, int nchunks,

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Counter passes for the context filter on ONE interval of the default workload (25 sixteen-chunk calls... one call in flight):
+# Counter passes for the context filter on ONE interval of the default workload (its calls of the engine's default size, one call in flight):
 # each --pmc pass serialises the kernels, so the command is kept short.  Usage (GPU box): [KERNEL=name] [OUTTAG=dir] bash tools/pmc_ctx.sh
 KERNEL=${KERNEL:-extend_filter_cls_kernel}
 cd /tmp && export TMPDIR=/tmp

@@ -798,14 +798,20 @@ def committed_profile(args, E):
     return None, other, None, None
 
 
+PROFILE_TOLERANCE = 0.15
+
+
 def profile_check(prof, solo, kstats, args):
     """Does the committed rocprofv3 collection describe the kernels of THIS run?  (With several calls in flight a kernel's
     duration depends on what it overlaps with, which a tracer perturbs: collections made with ONE call in flight -- workload.json
     "single_stream" -- are compared with this run's own single-stream launches instead.)  Per scope, the committed
     --kernel-trace --stats average (sum over the scope's kernels) is compared with the average this run's own HIP events
     predict for the same command: warmup + timed launches at the timed region's (concurrent) duration and the single-stream
-    launches of the extra untimed pass.  The committed traffic is only quoted when they agree within 10 % (else the
-    collection is stale: a kernel or the launch shape changed)."""
+    launches of the extra untimed pass.  The committed traffic is only quoted when they agree within the tolerance (else the
+    collection is stale: a kernel or the launch shape changed).  The tolerance is 15 %: a process that runs one call at a time
+    THROUGHOUT -- what the single-stream collection is -- shows the class filter 8 % slower than the single-stream pass that
+    follows a timed region with six calls in flight (3.70 against 3.42 ms on one box, without any profiler; rocprofv3 adds ~1 %:
+    profiles/README.md), and boxes of the pool differ by +-4 %."""
     if not kstats:
         return {"ok": False, "reason": "no committed kernel_stats for this workload"}
     out, ok = {}, True
@@ -824,9 +830,9 @@ def profile_check(prof, solo, kstats, args):
             ev = 1e3 * (prof[scope][0] * scale + s_ms) / (prof[scope][1] * scale + s_n)
         out[scope] = {"events_us": round(ev, 2), "committed_us": round(committed, 2) if committed else None,
                       "ratio": round(ev / committed, 3) if committed else None}
-        if not committed or abs(ev / committed - 1.0) > 0.12:
+        if not committed or abs(ev / committed - 1.0) > PROFILE_TOLERANCE:
             ok = False
-    return {"ok": ok and bool(out), "tolerance": 0.12, "scopes": out,
+    return {"ok": ok and bool(out), "tolerance": PROFILE_TOLERANCE, "scopes": out,
             "compared": "single-stream launches of this run vs a single-stream collection" if single else
                         "this run's launch mix (timed + warmup concurrent, extra pass single-stream) vs the same command under rocprofv3"}
 

@@ -224,10 +224,12 @@ int sa_max_hits_for_mem(uint64_t total_global_mem);
  *                     1 hipMemcpyAsync from the pageable vector (the runtime stages it), 2 hipHostRegister the vector + DMA
  * Launch geometry (defaults are the measured optima, tools/sweep_*.sh)
  *   fin_batch, bufs_per_wave, long_cap, long_blocks, max_waves, packed_waves, l2_blocks, ctx_waves, ctx_threads,
- *   chain_sort_threads, dedup_threads, nbr_one_stage, table_atomic (1: seed table by the atomic counting sort even for seed
- *   weights 9..12, where the LDS-staged partition build is the default)
+ *   chain_sort_threads, chain_sort_blocks, chain_group_max (candidates a chain workgroup sorts in LDS at a time), chain_bucket_target
+ *   (candidates per chain hash bucket the device sizes the bucket count for; chain_buckets forces a count), cls_one_copy,
+ *   dedup_threads, nbr_one_stage, table_atomic (1: seed table by the atomic counting sort even for seed weights 9..14, where the
+ *   LDS-staged partition build is the default), work_gb (GiB of work arena per slot), arena_vmm, call_hits, call_hits_max
  * Test-only options (small capacities that force the overflow / fallback branches of the orchestration)
- *   l2_cap, spec_dedup, spec_recs, dedup_seg_max, no_small_dedup, chain_cap, audit_cap
+ *   l2_cap, spec_dedup, spec_recs, dedup_seg_max, no_small_dedup, chain_cap, chain_no_link, q2_limit_mb, audit_cap
  */
 int sa_set_option(const char* name, int64_t value);
 int sa_reset_option(const char* name);     /* NULL: every option back to environment / default */

@@ -575,7 +575,11 @@ def roofline(args, E, wl, prof, busy, call_stats, run_step, run_job, jobs, elaps
     kernels = {k: {"ms_total": round(v[0], 3), "launches": v[1], "avg_us": round(1e3 * v[0] / max(v[1], 1), 2)}
                for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
     gpu_ms = sum(v[0] for v in prof.values())
-    name, (ms, launches) = max(prof.items(), key=lambda kv: kv[1][0])
+    # the dominant kernel: by what the scopes cost with ONE call in flight when that pass exists (with six calls in flight a scope's
+    # summed durations mostly measure how long its launches queued behind the other streams' kernels)
+    ranked = {k: v for k, v in (solo or {}).items() if k in prof and prof[k][1]} or prof
+    name = max(ranked.items(), key=lambda kv: kv[1][0])[0]
+    ms, launches = prof[name]
     symbol = {"extend_filter": "extend_filter_cls_kernel" if ctx_filter else FILTER_KERNELS.get(E.filter_mode()),
               "extend_filter2": "extend_filter_packed_kernel"}.get(name) or (SCOPE_KERNELS.get(name) or [None])[0]
 

@@ -1375,23 +1375,27 @@ __device__ __forceinline__ bool chain_range(const ExtendArgs& a, uint32_t& first
 template <bool DOWN>
 __device__ __forceinline__ uint32_t wave_bucket_add(uint32_t* __restrict__ counters, bool active, uint32_t b, uint32_t& base) {
     const int lane = threadIdx.x & 63;
-    uint32_t rank = 0;
-    base = 0;
+    uint32_t rank = 0, k = 0;
+    int my_leader = lane;
+    // 1. who shares a bucket with whom: registers only.  (First form: the leader's atomic sat INSIDE this loop and every round
+    //    waited for its return -- fine for a wave of one HSP's candidates, two or three rounds; on ordinary input a wave holds ~64
+    //    different buckets and paid 64 atomic round trips one after the other.)
     unsigned long long todo = __ballot(active);
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
         const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)b, leader);
         const unsigned long long same = __ballot(active && b == b0) & todo;
-        uint32_t got = 0;
-        const uint32_t k = (uint32_t)__popcll(same);
-        if (lane == leader) got = DOWN ? atomicSub(&counters[b0], k) - k : atomicAdd(&counters[b0], k);
-        got = (uint32_t)__builtin_amdgcn_readlane((int)got, leader);
         if ((same >> lane) & 1ull) {
-            base = got;
+            my_leader = leader;
             rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            k = (uint32_t)__popcll(same);
         }
         todo &= ~same;
     }
+    // 2. all leaders' atomics in one instruction, the answers handed to their lanes by one shuffle
+    uint32_t got = 0;
+    if (active && lane == my_leader) got = DOWN ? atomicSub(&counters[b], k) - k : atomicAdd(&counters[b], k);
+    base = (uint32_t)__shfl((int)got, my_leader, 64);
     return rank;
 }
 

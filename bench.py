@@ -211,6 +211,8 @@ def main():
     import torch
     from segalign_amd import shard
     dist = None
+    group = None        # (process group of the barrier and the reductions: None = the default one)
+    nccl_failed = False
     dev = "cpu" if args.dry_run else "cuda"
     if world > 1:
         import torch.distributed as dist_mod
@@ -222,8 +224,26 @@ def main():
             dist.init_process_group(backend="gloo")
             dev = "cpu"  # (the reductions below run on host tensors)
         else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # "nccl" IS RCCL on ROCm
+            # "nccl" IS RCCL on ROCm.  It carries a barrier and three tiny reductions, nothing of the data path.  The default group is
+            # gloo (the rendezvous cannot fail on a transport), the RCCL group is made on top of it and tried once: if it cannot be
+            # brought up, or its first all-reduce fails, the run goes on over gloo on host tensors and says so in its line
+            di = 0 if args.share_gpu else local_rank
+            torch.cuda.set_device(di)
+            dist.init_process_group(backend="gloo")
+            try:
+                g = dist.new_group(backend="nccl")
+                probe = torch.ones(1, dtype=torch.int64, device="cuda")
+                dist.all_reduce(probe, group=g)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError("all_reduce returned %d for world %d" % (int(probe.item()), world))
+                group = g
+            except Exception as ex:  # noqa: BLE001
+                msg = str(ex).strip().splitlines()[-1][:120] if str(ex).strip() else type(ex).__name__
+                print("rank %d: nccl/RCCL group failed (%s); the reductions go over gloo" % (rank, msg), file=sys.stderr)
+                dev = "cpu"
+                args.backend = "gloo (nccl failed: %s)" % msg
+                nccl_failed = True
     elif not args.dry_run:
         torch.cuda.set_device(0 if args.share_gpu else local_rank)
     if args.share_gpu:
@@ -380,7 +400,7 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=group)
         torch.cuda.synchronize()
 
     # ---------------- warmup (untimed) ----------------
@@ -426,14 +446,14 @@ def main():
     # max over ranks, sums of bases / HSPs / checksum
     if dist is not None and drained:
         td = torch.tensor(drained, dtype=torch.float64, device=dev)
-        dist.all_reduce(td, op=dist.ReduceOp.MAX)
+        dist.all_reduce(td, op=dist.ReduceOp.MAX, group=group)
         drained = [float(x) for x in td.tolist()]
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=group)
         elapsed = float(tt.item())
         tb = torch.tensor([bases, hsps, check], dtype=torch.int64, device=dev)
-        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tb, op=dist.ReduceOp.SUM, group=group)
         bases, hsps, check = int(tb[0].item()), int(tb[1].item()), int(tb[2].item()) % CHECK_MOD
 
     if rank == 0 and not prof and args.no_kernel_events:  # event-free timed region: kernel times from one extra (untimed) pass
@@ -517,6 +537,11 @@ def main():
     pool.shutdown()
     E.ShutdownProcessor()
     if dist is not None:
+        if nccl_failed:  # (tearing down a communicator that never came up can hang: leave after everybody has printed)
+            dist.barrier()
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
         dist.destroy_process_group()
 
 

@@ -21,9 +21,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(nproc, extra, port):
+def run_bench(nproc, extra, port, backend="gloo"):
     base = [os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "2", "--warmup", "1", "--no-roofline", "--no-cpu-baseline",
-            "--backend", "gloo", "--share-gpu"] + extra
+            "--backend", backend, "--share-gpu"] + extra
     if nproc == 1:
         cmd = [sys.executable] + base
     else:
@@ -73,3 +73,13 @@ def test_two_ranks_reproduce_one_rank_on_a_20_mbp_stand_in():
     assert one["config"]["calls_per_step"] == 16   # 2 intervals x 2 strands x 40 chunks in calls of 10
     imb = two["config"]["partition_imbalance"]
     assert imb["ranks"] == 2 and 1.0 <= imb["by_hits"] < 1.2
+
+
+def test_a_failing_rccl_group_does_not_take_the_run_down():
+    """`--backend nccl` (the driver's launch) with both ranks on ONE device: RCCL refuses ("Duplicate GPU detected").  The transport
+    only carries a barrier and three tiny reductions, so bench.py keeps its gloo default group, says in its line that the reductions
+    went over gloo and why -- and the pass is the same pass."""
+    one = run_bench(1, ["--workload", "plumbing", "--partition", "hits"], 29615)
+    two = run_bench(2, ["--workload", "plumbing"], 29616, backend="nccl")
+    assert two["n_gpus"] == 2 and two["config"]["backend"].startswith("gloo (nccl failed")
+    same_pass(one, two)

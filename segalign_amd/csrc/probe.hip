@@ -144,6 +144,29 @@ __global__ __launch_bounds__(256) void nbr_copy_ctx_kernel(const uint32_t* __res
         }
     }
 }
+// stage 2 for SPARSE tables -- fewer seed positions than keys: 14of22 (2^28 keys, 0.37 positions per bucket on a 100 Mbp block, a
+// run of ~6 entries) and every small target.  A wave per key spent 119 ms on 14of22's 268 M keys with 6 of its 64 lanes at work;
+// here a LANE takes a key: the extents of consecutive keys are read coalesced (piece j of key k is bucket k ^ const), the lane
+// copies its few records one after the other, and the runs of a wave's 64 keys are one contiguous stretch of the table.
+__global__ __launch_bounds__(256) void nbr_copy_ctx_sparse_kernel(const uint32_t* __restrict__ bucket_start, uint32_t nkeys, uint32_t tmask, int weight,
+                                                                  const uint64_t* __restrict__ nbr_start, const uint4* __restrict__ by_index,
+                                                                  uint4* __restrict__ ctx) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nkeys; k += stride) {
+        uint64_t o = nbr_start[k];
+        if (nbr_start[k + 1] == o) continue;
+        for (int j = -1; j < weight; j++) {  // (seed word order, seeder.cpp:60-69: the key itself, then one piece per transition position)
+            if (j >= 0 && !((tmask >> j) & 1u)) continue;
+            const uint32_t kk = j < 0 ? k : (k ^ (2u << (2 * j)));
+            const uint32_t pe = bucket_start[kk + 1];
+            for (uint32_t e = bucket_start[kk]; e < pe; e++, o++) {
+                const uint4 a = by_index[2 * (size_t)e], b = by_index[2 * (size_t)e + 1];
+                ctx[2 * o] = a;
+                ctx[2 * o + 1] = b;
+            }
+        }
+    }
+}
 // one-stage form (no scratch): every table entry cuts its own context out of the target
 __global__ __launch_bounds__(256) void nbr_fill_ctx_kernel(const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ pos_table,
                                                            uint32_t nkeys, uint32_t tmask, int weight, const uint64_t* __restrict__ nbr_start,
@@ -174,8 +197,12 @@ void launch_nbr_fill_ctx(const uint32_t* bucket_start, const uint32_t* pos_table
     if (scratch) {
         hipLaunchKernelGGL(ctx_by_index_kernel, dim3(8192), dim3(256), 0, s, pos_table, num_index, ref2, ref2_stride, seed_size,
                            reinterpret_cast<uint4*>(scratch));
-        hipLaunchKernelGGL(nbr_copy_ctx_kernel, dim3(8192), dim3(256), 0, s, bucket_start, nkeys, tmask, weight, nbr_start,
-                           reinterpret_cast<const uint4*>(scratch), reinterpret_cast<uint4*>(ctx));
+        if (num_index < nkeys)  // (less than one position per bucket: a lane per key)
+            hipLaunchKernelGGL(nbr_copy_ctx_sparse_kernel, dim3(8192), dim3(256), 0, s, bucket_start, nkeys, tmask, weight, nbr_start,
+                               reinterpret_cast<const uint4*>(scratch), reinterpret_cast<uint4*>(ctx));
+        else
+            hipLaunchKernelGGL(nbr_copy_ctx_kernel, dim3(8192), dim3(256), 0, s, bucket_start, nkeys, tmask, weight, nbr_start,
+                               reinterpret_cast<const uint4*>(scratch), reinterpret_cast<uint4*>(ctx));
         return;
     }
     hipLaunchKernelGGL(nbr_fill_ctx_kernel, dim3(8192), dim3(256), 0, s, bucket_start, pos_table, nkeys, tmask, weight, nbr_start, ref2,

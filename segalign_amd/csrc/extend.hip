@@ -1323,12 +1323,13 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_exact_kernel(ExtendArgs a)
 constexpr uint32_t CHAIN_GAP_MAX = 256;   // predecessor further away than this: no test, the candidate starts a run
 constexpr uint32_t CHAIN_WALK_EXTRA = 96; // bases walked past the predecessor's anchor looking for the new best
 
-// Grouping without a general sort: candidates are dealt into CHAIN_BUCKETS buckets by a hash of (iteration, diagonal)
-// (counting pass, one-block scan, scatter), then ONE WORKGROUP PER BUCKET rank-sorts its entries in LDS by
-// (iteration, diagonal, position).  A bucket holds a handful of diagonals with a few hundred candidates each, so the
-// quadratic rank sort is a few microseconds; all buckets together are the candidate list with every diagonal's
-// candidates contiguous and ordered by position -- exactly what the link test needs.  No host involvement.
-constexpr uint32_t CHAIN_BUCKETS_MIN = 16384, CHAIN_BUCKETS_MAX = 262144;  // the host picks a power of two from the batch's hits (ExtendArgs.chain_buckets)
+// Grouping without a general sort: candidates are dealt into hash buckets of (iteration, diagonal, 512-position window) --
+// counting pass, scan (a workgroup per 4096 counters), scatter --, then workgroups take eight buckets at a time and rank-sort every
+// bucket's entries in LDS by a 32-bit key (chain_key32: hash of the bucket's coordinates | position inside the window | index).  A
+// bucket holds ~32 candidates by construction (its count is picked on the device from the candidate count) and up to 512 where
+// one HSP fills a window, so the quadratic rank sort stays small; all buckets together are the candidate list with every
+// (diagonal, window)'s candidates contiguous and ordered by position -- exactly what the link test needs.  No host involvement.
+constexpr uint32_t CHAIN_BUCKETS_MIN = 16384, CHAIN_BUCKETS_MAX = 262144;  // what chain_buckets_of picks between (option chain_buckets forces any power of two >= 64)
 constexpr uint32_t CHAIN_SORT_MAX = 4096;  // most entries a bucket may hold and still be sorted (option chain_group_max <= this); larger: left unsorted,
                                            // which only makes link tests fail, i.e. costs extensions, never correctness
 
@@ -1482,12 +1483,11 @@ __global__ __launch_bounds__(256) void chain_scatter_kernel(ExtendArgs a) {
     }
 }
 
-// CHAIN_SORT_GROUP consecutive buckets per workgroup (a bucket holds a few dozen candidates: one workgroup per bucket was thousands
-// of tiny workgroups whose dispatch cost more than their work): rank sort in LDS by (diagonal, position) -- table-direct calls -- or
-// (iteration, diagonal, position), every entry ranked inside its own bucket; then, in the SAME workgroup, the link test of every
-// entry against its predecessor in the bucket (the separate chain_link_kernel of rounds 1-3: one launch and one pass over the
-// sorted list less).  The sorted order is kept as a permutation in LDS; the records are read from the scatter's output and
-// written in order, coalesced.
+// CHAIN_SORT_GROUP consecutive buckets per workgroup step (a bucket holds a few dozen candidates: one workgroup per bucket was
+// thousands of tiny workgroups whose dispatch cost more than their work): rank sort in LDS, every entry ranked inside its own
+// bucket; then, in the SAME workgroup, the link test of every entry against its predecessor in the bucket (the separate
+// chain_link_kernel of rounds 1-3: one launch and one pass over the sorted list less).  The records are read once from the
+// scatter's output into LDS, the sorted order is a permutation in LDS, and the records leave in order, coalesced.
 constexpr uint32_t CHAIN_SORT_GROUP = 8;
 // Entries the workgroup's LDS holds at a time = ExtendArgs.chain_group_max (dynamic LDS, 18 bytes per entry; <= CHAIN_SORT_MAX): a
 // whole group usually.  It sets the kernel's occupancy -- round 4 started with 4096 entries = 45 KB = 3 workgroups of 4 waves per CU,

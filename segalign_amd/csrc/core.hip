@@ -226,14 +226,14 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                 ea.max_waves = (uint32_t)(ea.fast_filter == 3 ? g_packed_waves : g_max_waves);
                 ea.ent_blocks = 256;  // (grid-stride over a count that lives on the device: a few thousand records usually, millions on repeats)
                 sl->cand_list.ensure((size_t)std::max<uint64_t>(1u << 16, bh / 16), "candidate list");
-                // chain shortcut: valid for the plain X-drop recurrence (xdrop >= 0), needs the 29-bit position field of its
-                // sort key, and is off while E is being counted.  The repeat masker takes it too: its window only decides WHICH
+                // chain shortcut: valid for the plain X-drop recurrence (xdrop >= 0), kept to query blocks below 2^29 bases on the
+                // general path (the envelope it is tested in; the 64-bit sort key of rounds 1-4 needed it, chain_key32 does not), and
+                // off while E is being counted.  The repeat masker takes it too: its window only decides WHICH
                 // hits are extended (all candidates lie inside it), and its chain starts with an exact-duplicate unique
                 // (rm :819-823), so the duplicates the shortcut never produces would be removed there anyway
                 const bool chain_rel = ca.td && ca.q_hi > ca.q_lo;  // table-direct call: anchors relative to the call's first position
                 const bool chain = g_chain && g_xdrop >= 0 && (chain_rel || (nseg <= MAX_SEGS_ABS && ca.query_len < (1u << 29))) && !g_count_examined;
-                ea.chain_q_bits = chain_rel ? 32u : 29u;  // (32: diagonal | relative position, no iteration field -- kernels.h)
-                ea.chain_q_base = chain_rel ? ca.q_lo : 0u;
+                ea.chain_q_bits = chain_rel ? 32u : 29u;  // (32: table-direct call, no iteration in the sort key's hash -- kernels.h)
                 ea.chain_cap = chain ? CHAIN_CAP : 0u;
                 ea.chain_buckets = (uint32_t)g_chain_buckets;  // (0: the device sizes them by the candidates it finds)
                 ea.chain_bucket_target = (uint32_t)g_chain_bucket_target;

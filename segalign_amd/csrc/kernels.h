@@ -109,7 +109,7 @@ struct ExtendArgs {
     int fin_batch;            // finished lanes a wave accumulates before it finalises + refills them
     int bufs_per_wave;        // launch heuristic: 64-hit buffers each wave should own at least
     uint32_t long_cap;        // bases per side the filter walks before it forwards the hit to the exact kernel
-    uint32_t chain_sort_threads;  // workgroup size of the chain bucket sort (0: 512)
+    uint32_t chain_sort_threads;  // workgroup size of the chain sort + link kernel (0: 256)
     int fast_filter;          // 1: xdrop >= 0 && 7*max(M) <= xdrop: the filter may skip the sticky select (extend.hip)
                               // 3: the packed 2-bit / 4-bit upper-bound filter is used (extend.hip 1b)
     CandRec* cand_list;
@@ -171,7 +171,6 @@ struct ExtendArgs {
     uint32_t chain_q_bits;      // 32: table-direct call -- the chain sort key (chain_key32) hashes the diagonal alone, the hits of a diagonal are in
                                 // iteration order anyway and the link test compares the iterations itself; else (general path, several iterations
                                 // per batch) the iteration goes into the hash
-    uint32_t chain_q_base;      // (unused since the 32-bit keys: positions enter the key modulo the bucket window)
     uint32_t ctx_threads;       // workgroup size of the context filter (0: its default)
     uint32_t cls_one_copy;      // 0 / 1: query windows from the unshifted copy (default), 2: from the sixteen shifted copies
     uint32_t l2_blocks;         // grid of the second level (its hit count is known on the device only)

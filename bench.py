@@ -21,12 +21,13 @@ of configs[2] (a 500 Mbp target block, the size at which the reference closes a 
 seed hits -- the sharding BASELINE configs[2] names; --scaling weak: every rank on a block pair of its own, as the 6 x 6 block
 pairs of a 3 Gbp x 3 Gbp run are independent), `plumbing` = configs[0] (1 Mbp x 1 Mbp).
 
-Multi-GPU: the unit of work is one engine CALL (up to 32 consecutive 250 kbp chunks of one strand of one interval; 20 by
-default, so a strand's 40 chunks of an interval are two calls and a pass of the default workload is 40 calls); calls are independent and their output position is fixed by the host loop.  Default
-`--scaling strong`: the calls of ONE pass are dealt to the N ranks (by their seed hits, counted by a lookup-only pass every rank
-runs identically; --partition round-robin: in turn) -- every call on exactly one GPU, total work fixed,
-`value` = query bases of the block / max-rank time, and the order-independent HSP checksum of the pass must equal the 1-GPU
-checksum.  `--scaling weak`: every rank runs the whole pass (rank-dependent start).  Every rank holds target + tables; there is
+Multi-GPU: the unit of work is one engine CALL (consecutive 250 kbp chunks of one strand; forty by default -- one call per
+strand of a 10 Mbp interval, 20 calls per pass of the default workload -- more when the resident target's seed hits are sparse, up to
+sa_max_chunks_per_call(); the SAME grain at every N); calls are independent and their output position is fixed by the host loop.
+Default `--scaling strong`: the calls of ONE pass are dealt to the N ranks round-robin, like the reference's dynamic pool with no
+weighting pass (src/seed_filter.cu:699-706,798-803) -- every call on exactly one GPU, total work fixed, `value` = query bases of the
+block / max-rank time, and the order-independent HSP checksum of the pass must equal the 1-GPU checksum.  `--partition hits` deals by
+seed hits instead; the lookup-only pass that counts them then runs INSIDE the timed region, once per pass on every rank.  `--scaling weak`: every rank runs the whole pass (rank-dependent start).  Every rank holds target + tables; there is
 NO data-path collective (torch.distributed only carries the barrier and the max / sum of the timing and counts).
 """
 import argparse
@@ -97,9 +98,9 @@ def parse():
                     help="do not record per-kernel HIP events in the timed region (roofline block from the untimed passes only)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = the calls of ONE pass are dealt to the ranks (total work fixed); weak = every rank runs the whole pass")
-    ap.add_argument("--partition", default="auto", choices=["auto", "hits", "round-robin"],
-                    help="strong scaling: how the calls of a pass are dealt to the ranks -- by measured seed hits (auto: when there is "
-                         "more than one rank) or round-robin")
+    ap.add_argument("--partition", default="round-robin", choices=["auto", "hits", "round-robin"],
+                    help="strong scaling: how the calls of a pass are dealt to the ranks -- round-robin (default; auto means the same) or by "
+                         "seed hits, counted by a lookup-only pass that every rank runs inside the timed region, once per pass")
     ap.add_argument("--no-dropin", action="store_true",
                     help="skip the drop-in leg (one-chunk g_SeedAndFilter calls): profile collections use it so that per-kernel averages "
                          "describe the calls of the timed region only")
@@ -111,8 +112,8 @@ def parse():
                     help="every rank uses HIP device 0 (with --backend gloo): the N-rank strong-scaling path -- partition, per-rank engines, "
                          "reductions, checksum -- on a one-GPU box; the timing then says nothing about scaling")
     ap.add_argument("--chunks-per-call", type=int, default=None,
-                    help="chunks of a strand that share one engine call (engine option chunks_per_call, default 20): smaller calls give the "
-                         "partition of a pass over many GPUs a finer grain")
+                    help="chunks of a strand that share one engine call (engine option chunks_per_call, default 40; the engine raises it "
+                         "when the target's seed hits are sparse): an explicit value is kept as it is at every N")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU-only rehearsal of the launch/shard/reduce/JSON contract (gloo, no GPU): real shard + chunk "
                          "arithmetic around a stub engine")
@@ -241,9 +242,18 @@ def main():
             except Exception as ex:  # noqa: BLE001
                 msg = str(ex).strip().splitlines()[-1][:120] if str(ex).strip() else type(ex).__name__
                 print("rank %d: nccl/RCCL group failed (%s); the reductions go over gloo" % (rank, msg), file=sys.stderr)
-                dev = "cpu"
                 args.backend = "gloo (nccl failed: %s)" % msg
                 nccl_failed = True
+            # every rank must use the SAME group: agree on the outcome over the gloo default group (a failure on one rank only would
+            # leave the ranks on different process groups, and the next barrier would hang)
+            ok = torch.tensor([0 if nccl_failed else 1], dtype=torch.int64)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if not nccl_failed:
+                    args.backend = "gloo (nccl failed on another rank)"
+                nccl_failed = True
+                group = None
+                dev = "cpu"
     elif not args.dry_run:
         torch.cuda.set_device(0 if args.share_gpu else local_rank)
     if args.share_gpu:
@@ -270,10 +280,7 @@ def main():
     os.environ.setdefault("SEGALIGN_AMD_SLOTS", str(max(2, inflight)))  # one engine slot per call in flight (default 2)
     if args.workload == "human":
         os.environ.setdefault("SEGALIGN_AMD_ARENA_GB", "180")
-    if not args.chunks_per_call and world > 2 and scaling == "strong":
-        # strong scaling over many ranks: a finer grain, so that every rank gets >= 10 calls of a pass to balance (N = 4: calls of
-        # twenty chunks, N = 8: of ten); N <= 2 keeps the engine's default of forty
-        E.set_option("chunks_per_call", max(10, 80 // world))
+    # (the call grain is the SAME at every N: a scaling curve must not mix scaling with grain)
     if args.chunks_per_call:
         E.set_option("chunks_per_call", args.chunks_per_call)
         E.set_option("call_hits", 0)  # (an explicit grain is kept as it is: no sizing by hits)
@@ -310,7 +317,7 @@ def main():
         jobs = shard.call_jobs(intervals, q_block_len, args.chunk, E.lib().sa_get_chunks_per_call())
 
     def run_job(job, collect=None):
-        """one engine call: up to 32 (default 20) 250 kbp chunks of one strand of one interval (src/seeder.cpp:47-121), or one interval task
+        """one engine call: consecutive 250 kbp chunks of one strand (forty by default; src/seeder.cpp:47-121), or one interval task
         of the repeat masker (repeat_masker_src/seeder.cpp:28-195).  -> (query bases counted once, HSPs, checksum)"""
         if job.get("rm"):
             iv, tot = E.RmMaskInterval(job["a"], job["b"], job["ref_start"], job["ref_end"], E.STRAND_BOTH, 1)
@@ -328,35 +335,34 @@ def main():
     # Strong scaling over several ranks: the calls are dealt by their seed-hit counts (longest first, to the least loaded rank).  The
     # counts come from ONE untimed pass over all calls that every rank runs for itself -- same data, same counts, same map on
     # every rank, no communication; it is part of the warm-up (tables, buffers and clocks are warm afterwards).
-    weights = None
+    # With --partition hits the calls are dealt by their seed-hit counts (longest first, to the least loaded rank); the counts come
+    # from a lookup-only pass over all calls (sa_count_chunk_hits: position probe + chunk plans, no filtering, no extension) that
+    # every rank runs for itself -- same data, same counts, same map, no communication -- INSIDE the timed region, once per pass:
+    # a production host pays it per (target block, query block) pair, and the reference has no such pass at all (dynamic pool)
+    by_hits = scaling == "strong" and not wl["rm"] and args.partition == "hits"
     imbalance = None
-    t_weigh = None
+    weigh_s = []        # seconds of every weighting pass (all of them inside a timed or warm-up pass)
     chunk_hits = None   # {(rev, chunk start): seed hits} of every 250 kbp piece of the pass
-    if scaling == "strong" and not wl["rm"] and (args.partition == "hits" or (args.partition == "auto" and (world > 1 or args.workload in ("lumpy", "human")))):
-        # lookup only (sa_count_chunk_hits: the position probe + chunk plans of every call, no filtering, no extension): what the map
-        # costs a production host per (target block, query block) pair -- reported as partition_cost_ms
-        t0 = time.perf_counter()
+
+    def count_chunk_hits():
         per_chunk = E.CountCallHits([(j["a"], j["b"], j["rev"]) for j in jobs], 0, inflight, per_chunk=True)
-        t_weigh = time.perf_counter() - t0
         keys = [(j["rev"], c) for j in jobs for c in range(j["a"], j["b"], args.chunk)]
-        chunk_hits = dict(zip(keys, per_chunk))
+        return dict(zip(keys, per_chunk))
 
-        def call_weights(js):
-            return [sum(chunk_hits[(j["rev"], c)] for c in range(j["a"], j["b"], args.chunk)) for j in js]
-        weights = call_weights(jobs)
-    my_jobs = shard.partition(jobs, rank, world, weights) if scaling == "strong" else jobs
-    if weights and world >= 1:
-        # (what the map promises: heaviest rank / mean, by seed hits; and what round-robin would have given.  A 1-rank run shows it for
-        #  the call list an 8-rank run of the same pass would deal: calls of ten chunks)
-        n_show = world if world > 1 else 8
-        js = jobs if world > 1 else shard.call_jobs(intervals, q_block_len, args.chunk, min(10, max(j["chunks"] for j in jobs)))
-        ws = weights if world > 1 else call_weights(js)
+    def call_weights(js, ch):
+        return [sum(ch[(j["rev"], c)] for c in range(j["a"], j["b"], args.chunk)) for j in js]
 
-        def spread(w_or_none, n):
-            pos = {id(j): k for k, j in enumerate(js)}
-            loads = [sum(ws[pos[id(j)]] for j in shard.partition(js, r, n, w_or_none)) for r in range(n)]
-            return round(max(loads) / (sum(loads) / n), 4)
-        imbalance = {"ranks": n_show, "calls": len(js), "by_hits": spread(ws, n_show), "round_robin": spread(None, n_show)}
+    def my_share():
+        """this rank's calls of one pass (strong scaling)"""
+        nonlocal chunk_hits
+        if not by_hits:
+            return shard.partition(jobs, rank, world, None)
+        t0w = time.perf_counter()
+        chunk_hits = count_chunk_hits()
+        share = shard.partition(jobs, rank, world, call_weights(jobs, chunk_hits))
+        weigh_s.append(time.perf_counter() - t0w)
+        return share
+    my_jobs = shard.partition(jobs, rank, world, None) if scaling == "strong" else jobs
     # never more calls in flight than this rank's share of one pass holds (the 1 Mbp plumbing case is two calls per pass: six
     # tiny calls in flight only contend for the engine's locks, 1.1 -> 0.67 Gbp/s)
     inflight = max(1, min(inflight, len(my_jobs)))
@@ -374,6 +380,20 @@ def main():
         Plain workloads hand the list to the engine's own worker pool (sa_seed_calls: `inflight` calls in flight on C++ threads,
         like the reference's TBB seeder bodies); the repeat masker's interval tasks are issued from a Python pool.
         -> (query bases, HSPs, checksum of the LAST pass)"""
+        if by_hits and not wl["rm"]:
+            # one pass at a time: the weighting pass of a pass comes before its calls, both inside whatever region times them
+            tot_b = tot_h = chk = 0
+            for k in ks:
+                todo = my_share()
+                outs, st = E.SeedCalls([(j["a"], j["b"], j["rev"]) for j in todo], 0, threads or inflight)
+                if collect is not None:
+                    collect.append(st)
+                chk = 0
+                for j, o in zip(todo, outs):
+                    chk = (chk + shard.hsp_checksum(o, j["rev"])) % CHECK_MOD
+                tot_b += sum(j["b"] - j["a"] for j in todo if not j["rev"])
+                tot_h += sum(int(o.size) for o in outs)
+            return tot_b, tot_h, chk
         per = [step_jobs(k) for k in ks]
         todo = [j for p in per for j in p]
         last0 = len(todo) - len(per[-1]) if per else 0
@@ -392,7 +412,8 @@ def main():
         return run_steps([k], collect, threads)
 
     if args.one_interval:
-        first = [j for j in jobs if j.get("rm") or j["interval"] == 0] if not wl["rm"] else jobs[:1]
+        # (the calls of interval 0 alone: a hit-sized call of the whole pass may span several intervals)
+        first = shard.call_jobs(intervals[:1], q_block_len, args.chunk, E.lib().sa_get_chunks_per_call()) if not wl["rm"] else jobs[:1]
         res = [run_job(j) for j in first]
         print(json.dumps({"one_interval": True, "bases": sum(r[0] for r in res), "hsps": sum(r[1] for r in res), "workload": args.workload}))
         E.ShutdownProcessor()
@@ -423,11 +444,13 @@ def main():
     E.profile_reset()
     E.profile_enable(not args.no_kernel_events)
     call_stats = []
+    weigh_s.clear()
     barrier()
     t0 = time.perf_counter()
     bases, hsps, check = run_steps(list(range(args.steps)), call_stats)  # (every step is the same pass: the checksum of one is kept)
     barrier()
     elapsed = time.perf_counter() - t0
+    t_weigh = sum(weigh_s) / len(weigh_s) if weigh_s else None  # per pass, all of it inside `elapsed`
     E.profile_enable(False)
     prof = E.profile_entries()
     busy = {k: E.profile_busy_ms(k) for k in prof}  # per scope: ms with at least one launch running (the slots' launches overlap)
@@ -472,9 +495,19 @@ def main():
 
     # how evenly the seed hits are spread over the 250 kbp chunks of the pass (lookup only; rank 0, outside the timed region)
     hit_spread = None
-    if rank == 0 and not wl["rm"] and not args.no_roofline:
-        ch = np.array(list(chunk_hits.values()) if chunk_hits else
-                      E.CountCallHits([(j["a"], j["b"], j["rev"]) for j in jobs], 0, inflight, per_chunk=True), dtype=np.float64)
+    if rank == 0 and not wl["rm"] and (not args.no_roofline or by_hits or world > 1):
+        if chunk_hits is None:
+            chunk_hits = count_chunk_hits()
+        # what either map promises for THIS call list: heaviest rank / mean, by seed hits (a 1-rank run shows it for 8 ranks)
+        n_show = world if world > 1 else 8
+        ws = call_weights(jobs, chunk_hits)
+
+        def spread(w_or_none, n):
+            pos = {id(j): k for k, j in enumerate(jobs)}
+            loads = [sum(ws[pos[id(j)]] for j in shard.partition(jobs, r, n, w_or_none)) for r in range(n)]
+            return round(max(loads) / max(sum(loads) / n, 1e-9), 4)
+        imbalance = {"ranks": n_show, "calls": len(jobs), "by_hits": spread(ws, n_show), "round_robin": spread(None, n_show)}
+        ch = np.array(list(chunk_hits.values()), dtype=np.float64)
         if ch.size and ch.sum() > 0:
             hit_spread = {"chunks": int(ch.size), "hits_per_pass": int(ch.sum()), "heaviest_chunk_over_mean": round(float(ch.max() / ch.mean()), 3),
                           "lightest_chunk_over_mean": round(float(ch.min() / ch.mean()), 3)}
@@ -501,13 +534,16 @@ def main():
                                                                                                  E.lib().sa_get_chunks_per_call()),
                        "workload_key": args.workload + ("" if args.seed == "12of19" else "_" + args.seed), "seed": args.seed,
                        "parallelism": ("the %d engine calls of one pass dealt to %d rank(s) %s: every call on exactly one GPU, target + tables on every GPU, "
-                                       "no collective" % (len(jobs), world, "by seed-hit count (longest first to the least loaded rank; counts from an "
-                                                          "untimed pass every rank runs identically)" if weights else "round-robin")) if scaling == "strong" else
+                                       "no collective" % (len(jobs), world, "by seed-hit count (longest first to the least loaded rank; counts from a "
+                                                          "lookup-only pass every rank runs inside the timed region, once per pass)" if by_hits else "round-robin")) if scaling == "strong" else
                                       ("every one of %d rank(s) runs all %d calls of a pass (`human`: on a block pair of its own), no collective"
                                        % (world, len(jobs))),
                        "calls_per_step": len(jobs), "calls_in_flight_per_gpu": inflight, "partition_imbalance": imbalance, "hit_spread": hit_spread,
-                       # what the by-hits map costs: one lookup-only pass over all calls on every rank (outside the timed region)
+                       # what the by-hits map costs per pass: one lookup-only pass over all calls on every rank, INSIDE ms_per_step
+                       # (None: round-robin, no such pass)
                        "partition_cost_ms": round(1e3 * t_weigh, 3) if t_weigh is not None else None,
+                       "partition": "hits" if by_hits else "round-robin",
+                       "chunks_per_call": E.lib().sa_get_chunks_per_call(),
                        # one pass at a time with a barrier + drain on both sides (max over ranks), next to ms_per_step of the
                        # concatenated passes: the difference is the tail of a single pass
                        "ms_per_pass_drained": [round(1e3 * x, 3) for x in drained] or None,
@@ -537,11 +573,19 @@ def main():
     pool.shutdown()
     E.ShutdownProcessor()
     if dist is not None:
-        if nccl_failed:  # (tearing down a communicator that never came up can hang: leave after everybody has printed)
+        if nccl_failed:
+            # tearing down an RCCL communicator that never came up can hang: everybody has printed; try the ordinary teardown on a
+            # helper thread and only cut the process short if it does not come back
+            import threading
             dist.barrier()
             sys.stdout.flush()
             sys.stderr.flush()
-            os._exit(0)
+            th = threading.Thread(target=dist.destroy_process_group, daemon=True)
+            th.start()
+            th.join(20.0)
+            if th.is_alive():
+                os._exit(0)
+            return
         dist.destroy_process_group()
 
 
@@ -881,9 +925,9 @@ def dry_run(args, rank, world, dist, torch, shard, scaling):
     t0 = time.perf_counter()
     bases, check = 0, 0
     for k in range(args.steps):
-        # (strong, several ranks: weighted like the real bench -- there by seed hits, here by the calls' lengths)
-        todo = (shard.partition(jobs, rank, world, [j["b"] - j["a"] for j in jobs] if world > 1 else None) if scaling == "strong"
-                else rotate(jobs, rank + k))
+        # (strong: the real bench's default map, round-robin; --partition hits: weighted -- there by seed hits, here by the calls' lengths)
+        todo = (shard.partition(jobs, rank, world, [j["b"] - j["a"] for j in jobs] if world > 1 and args.partition == "hits" else None)
+                if scaling == "strong" else rotate(jobs, rank + k))
         for i, j in enumerate(todo):
             bases += 0 if j["rev"] else j["b"] - j["a"]
             w = 1 if scaling == "strong" else (i + 1)  # (weak: weighted by the walk position, so the walk order is checked too)

@@ -1549,7 +1549,7 @@ __global__ __launch_bounds__(512) void chain_sort_link_kernel(ExtendArgs a) {
     uint32_t first, n;
     if (!chain_range(a, first, n)) return;
     SEG_TABLE()
-    if (threadIdx.x < 128) s_tab[threadIdx.x] = threadIdx.x < 64 ? a.sub_mat[threadIdx.x] : NEG;
+    for (uint32_t t = threadIdx.x; t < 128u; t += blockDim.x) s_tab[t] = t < 64u ? a.sub_mat[t] : NEG;  // (any workgroup size: option chain_sort_threads goes down to 64)
     const uint32_t groups = chain_buckets_of(a, n) / CHAIN_SORT_GROUP;
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
@@ -1773,8 +1773,17 @@ void launch_chain_group(const ExtendArgs& a, hipStream_t s) {  // chain_bucket_c
     hipLaunchKernelGGL(chain_count_kernel, dim3(1024), dim3(256), 0, s, a);
     hipLaunchKernelGGL(chain_scan_kernel, dim3(CHAIN_BUCKETS_MAX / CHAIN_SCAN_TILE), dim3(CHAIN_SCAN_THREADS), 0, s, a);
     hipLaunchKernelGGL(chain_scatter_kernel, dim3(1024), dim3(256), 0, s, a);
+    // (chain_group_max = 4096 asks for 72 KB of dynamic LDS next to ~4.6 KB static: above the 64 KB a launch gets without being asked)
+    const size_t sort_lds = (size_t)a.chain_group_max * (sizeof(uint32_t) + sizeof(CandRec) + sizeof(uint16_t)) + 4 * CHAIN_SORT_GROUP * sizeof(uint32_t);
+    static size_t sort_lds_set[64] = {0};  // per device ordinal: the attribute is per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (sort_lds > 48 * 1024 && dev >= 0 && dev < 64 && sort_lds_set[dev] < sort_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_sort_link_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds);
+        sort_lds_set[dev] = sort_lds;
+    }
     hipLaunchKernelGGL((chain_sort_link_kernel<true>), dim3(a.chain_sort_blocks ? a.chain_sort_blocks : 4096), dim3(a.chain_sort_threads ? a.chain_sort_threads : 256),
-                       (size_t)a.chain_group_max * (sizeof(uint32_t) + sizeof(CandRec) + sizeof(uint16_t)) + 4 * CHAIN_SORT_GROUP * sizeof(uint32_t), s, a);
+                       sort_lds, s, a);
 }
 uint32_t chain_num_buckets() { return CHAIN_BUCKETS_MAX; }  // (what the bucket arrays are sized for)
 void launch_extend_exact_chain(const ExtendArgs& a, hipStream_t s) {

@@ -1,7 +1,8 @@
 """GPU: the N-rank path of bench.py with the REAL engine.  The driver launches `bench.py --gpus N` with one rank per GPU over RCCL;
 a one-GPU box cannot do that, but everything except the transport can be shown on it: `--backend gloo --share-gpu` runs N ranks --
-N processes, N engines, N copies of target + tables -- on HIP device 0, deals the calls of ONE pass to them (by seed hits, counted by
-the lookup-only pass every rank runs for itself) and reduces time, bases, HSP count and the order-independent HSP checksum over gloo.
+N processes, N engines, N copies of target + tables -- on HIP device 0, deals the calls of ONE pass to them (round-robin by default, like the reference's
+dynamic pool; `--partition hits`: by seed hits, counted by a lookup-only pass every rank runs INSIDE the timed region) and reduces
+time, bases, HSP count and the order-independent HSP checksum over gloo.
 Checked: the 2-rank line reproduces the 1-rank checksum, HSP count and bases; and for the plumbing case (BASELINE configs[0]) the
 checksum equals the one computed from the ORACLE's HSPs (src/seeder.cpp:47-121 + src/seed_filter.cu:682-828), so the number a
 multi-GPU run is verified by is itself pinned to the CPU restatement."""
@@ -49,7 +50,12 @@ def test_two_ranks_reproduce_one_rank_on_the_plumbing_case_and_the_oracle(oracle
     one = run_bench(1, ["--workload", "plumbing", "--partition", "hits"], 29611)
     two = run_bench(2, ["--workload", "plumbing"], 29612)
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
-    assert "gloo" in two["config"]["backend"] and two["config"]["partition_cost_ms"] > 0
+    # the default map is round-robin (the reference has no weighting pass): nothing is counted, nothing is hidden outside the timing
+    assert "gloo" in two["config"]["backend"] and two["config"]["partition_cost_ms"] is None and two["config"]["partition"] == "round-robin"
+    # --partition hits: the lookup-only pass runs once per pass INSIDE the timed region
+    assert one["config"]["partition"] == "hits" and 0 < one["config"]["partition_cost_ms"] < one["ms_per_step"]
+    # the call grain does not depend on the number of ranks
+    assert one["config"]["chunks_per_call"] == two["config"]["chunks_per_call"]
     same_pass(one, two)
     # the same pass through the oracle: every 250 kbp chunk of [0, len - 19) on both strands (seeder.cpp:47-121)
     import bench
@@ -68,11 +74,13 @@ def test_two_ranks_reproduce_one_rank_on_the_plumbing_case_and_the_oracle(oracle
 def test_two_ranks_reproduce_one_rank_on_a_20_mbp_stand_in():
     args = ["--workload", "ce11cb4", "--target-mbp", "20", "--chunks-per-call", "10"]
     one = run_bench(1, args, 29613)
-    two = run_bench(2, args, 29614)
+    two = run_bench(2, args + ["--partition", "hits"], 29614)
     same_pass(one, two)
     assert one["config"]["calls_per_step"] == 16   # 2 intervals x 2 strands x 40 chunks in calls of 10
+    assert one["config"]["partition_cost_ms"] is None
+    assert 0 < two["config"]["partition_cost_ms"] < two["ms_per_step"]   # the weighting pass is timed
     imb = two["config"]["partition_imbalance"]
-    assert imb["ranks"] == 2 and 1.0 <= imb["by_hits"] < 1.2
+    assert imb["ranks"] == 2 and 1.0 <= imb["by_hits"] < 1.2 and 1.0 <= imb["round_robin"] < 1.5
 
 
 def test_a_failing_rccl_group_does_not_take_the_run_down():

@@ -23,7 +23,14 @@ __global__ __launch_bounds__(256) void k(uint32_t* out, int iters, uint32_t seed
     if (OP == 5) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                                 \
     if (OP == 6) asm volatile("v_bfe_u32 %0, %0, 4, 4" : "+v"(a[i]));                                                        \
     if (OP == 7) asm volatile("v_lshl_or_b32 %0, %0, 2, %1" : "+v"(a[i]) : "v"(b));                                          \
-    if (OP == 8) asm volatile("v_max_i16_sdwa %0, %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "+v"(a[i]));
+    if (OP == 8) asm volatile("v_max_i16_sdwa %0, %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "+v"(a[i]));            \
+    if (OP == 9) asm volatile("v_pk_add_i16 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,1]" : "+v"(a[i]) : "v"(b));                  \
+    if (OP == 10) asm volatile("v_min_i16_sdwa %0, %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0" : "+v"(a[i]) : "v"(b)); \
+    if (OP == 11) asm volatile("v_pk_min_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                             \
+    if (OP == 12) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(a[i]) : "v"(b));                                        \
+    if (OP == 13) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(0x7Cu));                             \
+    if (OP == 14) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                                \
+    if (OP == 15) asm volatile("v_lshrrev_b32 %0, 5, %0" : "+v"(a[i]));
         REP8(ONE) REP8(ONE) REP8(ONE) REP8(ONE)
 #undef ONE
     }
@@ -62,5 +69,12 @@ int main() {
     run<6>("v_bfe_u32", out, ghz);
     run<7>("v_lshl_or_b32", out, ghz);
     run<8>("v_max_i16_sdwa", out, ghz);
+    run<9>("v_pk_add_i16 op_sel", out, ghz);
+    run<10>("v_min_i16_sdwa preserve", out, ghz);
+    run<11>("v_pk_min_i16", out, ghz);
+    run<12>("v_alignbit_b32", out, ghz);
+    run<13>("v_and_or_b32", out, ghz);
+    run<14>("v_xor_b32", out, ghz);
+    run<15>("v_lshrrev_b32", out, ghz);
     return 0;
 }

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libsegalign_hip.so")
-SOURCES = ["encode.hip", "scan.hip", "table.hip", "seeds.hip", "probe.hip", "extend.hip", "dedup.hip", "coverage.hip",
+SOURCES = ["encode.hip", "scan.hip", "table.hip", "seeds.hip", "probe.hip", "join.hip", "extend.hip", "dedup.hip", "coverage.hip",
            "arena.hip", "options.hip", "profile.hip", "pool.hip", "front.hip", "core.hip", "api_setup.hip", "api_calls.hip", "api_rm.hip",
            "api_introspect.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]

@@ -88,6 +88,13 @@ int sa_get_chunks_per_call(void) {
             // call_hits_max = 1 G hits by this estimate (its lists are sized by its hits; 2^32 is the hard limit of a pass)
             const double most = (double)g_call_hits_max / per_chunk;
             if (g_call_hits_max > 0 && most < (double)k) k = (int)std::max(1.0, most);
+            // key-ordered calls (join.h) want MANY positions per call -- a key's run is fetched once for all the call's positions that
+            // carry the key: option key_order_chunks (200 chunks = 50 Mbp = three positions per 12-mer), as long as the call's lists
+            // stay in bounds (option key_order_hits) and the call still holds about a position per key
+            if (g_key_order && dc->nbr_ctx) {
+                const int kj = (int)std::min<double>((double)g_key_order_chunks, std::max(1.0, (double)g_key_order_hits / per_chunk));
+                if (kj > k && join_wanted(dc, kj, (uint32_t)std::min<uint64_t>((uint64_t)kj * g_wga_chunk, 0xFFFFFFFFull))) k = kj;
+            }
         }
     }
     return k;
@@ -136,7 +143,11 @@ static size_t chunks_pass(uint32_t start, uint32_t end, int rev, uint32_t buffer
     const PackedBuf* q4 = rev ? &dc->query4_rc[buffer] : &dc->query4[buffer];
     uint32_t ns = 0xFFFFFFFFu, words = 0;
     const bool eligible = td_eligible(dc, q4, rev ? &dc->query2_rc[buffer] : &dc->query2[buffer], rev ? &dc->query2[buffer] : &dc->query2_rc[buffer]);
-    if (eligible) ns = td_front(dc, sl, q, K, bpos, 0, &words);
+    const PackedBuf* q2o = rev ? &dc->query2_rc[buffer] : &dc->query2[buffer];
+    const PackedBuf* q2x = rev ? &dc->query2[buffer] : &dc->query2_rc[buffer];
+    const bool join = eligible && send > start && q2_usable(q2o, q2x) && join_wanted(dc, K, send - start);
+    if (join) ns = join_front(dc, sl, q, qlen, K, bpos, q2o, q2x, &words);
+    else if (eligible) ns = td_front(dc, sl, q, K, bpos, 0, &words);
     const bool td = ns != 0xFFFFFFFFu;
     if (!td && (eligible || K > SA_MAX_CHUNKS_GENERAL)) {
         // one of the chunks needs the general path (num_hits >= MAX_HITS), the pass holds 2^32 hits or more, or it is too long for
@@ -152,6 +163,7 @@ static size_t chunks_pass(uint32_t start, uint32_t end, int rev, uint32_t buffer
         set_query2(ca, dc, buffer, rev);
         ca.nchunks = K;
         ca.td = td ? 1 : 0;
+        ca.join = (td && join) ? 1 : 0;
         ca.td_words = words;
         for (int c = 0; c <= K; c++) ca.seed_bound[c] = td ? 0u : bseed[c];  // (a table-direct call derives them from its chunk plans)
         ca.outs = outs;

@@ -7,20 +7,21 @@ namespace sa {
 // Every slot issues its kernels on a stream of its own, next to the upload stream.  The HIP runtime multiplexes streams onto
 // GPU_MAX_HW_QUEUES hardware queues (default 4), and two slots that share a queue run one after the other: with four slots the
 // small kernels of one call then wait behind another call's filter kernel instead of overlapping it (0.94 -> 1.03 Gbp/s on the
-// default workload with 8 queues).  The runtime reads the variable when it initialises, i.e. at the first HIP call of the process;
-// a value the user has set is left alone.
-static bool g_hwq_ours = false;  // the variable was unset when the library was loaded, i.e. the value 8 is this library's
-__attribute__((constructor)) static void default_hw_queues() {
-    g_hwq_ours = getenv("GPU_MAX_HW_QUEUES") == nullptr;
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
-}
-// (No API reports how many hardware queues the runtime really uses.  When HIP was initialised before this library was loaded --
-//  a Python host that imported torch first -- the setenv above came too late and four slots run pairwise one after the other
-//  (1.03 -> 0.94 Gbp/s); such hosts export GPU_MAX_HW_QUEUES=8 themselves, as bench.py does.  Option debug says what applies.)
-static void report_hw_queues() {
+// default workload with 8 queues).  The runtime reads the variable when it initialises, i.e. at the first HIP call of the process.
+// A library has no business changing its host's environment (rounds 2-4 did, from a load-time constructor): the requirement is
+// documented (export GPU_MAX_HW_QUEUES=8, as bench.py and the C++ hosts do for themselves), and
+// InitializeProcessor says so ONCE on stderr when more than four slots per device meet an unset or smaller value.
+static void report_hw_queues(bool debug) {
     const char* v = getenv("GPU_MAX_HW_QUEUES");
-    fprintf(stderr, "engine: %d slot(s) per device, GPU_MAX_HW_QUEUES=%s (%s)\n", SLOTS_PER_DEVICE, v ? v : "unset",
-            g_hwq_ours ? "set by this library at load time: in effect only if HIP was initialised afterwards" : "set by the host");
+    const int have = v ? atoi(v) : 4;
+    static bool warned = false;
+    if (debug)
+        fprintf(stderr, "engine: %d slot(s) per device, GPU_MAX_HW_QUEUES=%s\n", SLOTS_PER_DEVICE, v ? v : "unset (the runtime's default is 4)");
+    if (!warned && have < 8 && SLOTS_PER_DEVICE > have) {
+        warned = true;
+        fprintf(stderr, "segalign_amd: %d engine slots per device on %d hardware queues: calls in flight run pairwise one after the other; "
+                        "export GPU_MAX_HW_QUEUES=8 before the process initialises HIP (INTEGRATION.md)\n", SLOTS_PER_DEVICE, have);
+    }
 }
 
 // ---- ASCII upload through the pinned ring (see DevCtx) -------------------------------------------------------------
@@ -144,7 +145,7 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
                            !opt_value("no_packed_filter")) ? 1 : 0;
         if (opt_value("no_fast_filter")) { g_fast_filter = 0; g_packed_filter = 0; }
     }
-    if (opt_value("debug")) report_hw_queues();
+    report_hw_queues(opt_value("debug") != 0);
     std::lock_guard<std::mutex> lk(g_mu);
     g_tokens.clear();
     for (int g = 0; g < g_ndev; g++) {
@@ -157,9 +158,21 @@ void sa_initialize_processor(int transition, uint32_t wga_chunk, uint32_t seed_s
         const size_t work_per_slot = (size_t)opt_value("work_gb") << 30;
         if (work_per_slot && g_td && g_packed_filter) arena_request(dc->work_arena, work_per_slot * (size_t)SLOTS_PER_DEVICE);
         for (int k = 0; k < SLOTS_PER_DEVICE; k++) {
-            if (!dc->slots[k].stream) slot_init(dc->slots[k], dc);
+            // a slot that exists already (no ShutdownProcessor in between) keeps its region unless the layout changes (option work_gb,
+            // or the slot count moved its offset): then its buffers still point into the OLD layout, where a neighbour's new region
+            // would carve over them -- the slot is torn down and set up again before it is re-based
+            Slot& sk = dc->slots[k];
+            const size_t off_k = (size_t)k * work_per_slot;
+            if (sk.stream && (sk.work.size != work_per_slot || sk.work.off != off_k || sk.work.arena != (work_per_slot ? &dc->work_arena : nullptr))) {
+                hipDeviceSynchronize();
+                slot_destroy(sk);
+            }
+            if (!sk.stream) {
+                slot_init(sk, dc);
+                sk.work.used = 0;
+            }
             dc->slots[k].work.arena = work_per_slot ? &dc->work_arena : nullptr;
-            dc->slots[k].work.off = (size_t)k * work_per_slot;
+            dc->slots[k].work.off = off_k;
             dc->slots[k].work.size = work_per_slot;
             dc->slots[k].seeds.ensure((size_t)g_max_seeds, "seed_offsets");
         }

@@ -184,6 +184,11 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                     // (the one-copy form unless the sixteen copies were asked for AND built: the option is read at InitializeProcessor, the
                     //  copies are made at SendQueryWriteRequest)
                     ea.cls_one_copy = (ca.q2_own->copies == (uint32_t)Q2_COPIES && ca.q2_other->copies == (uint32_t)Q2_COPIES && opt_value("cls_one_copy") == 2) ? 2u : 1u;
+                    if (ca.join) {  // key-ordered call (join.h): segments are resolved per hit from the chunk table join_plan_kernel left in d_seg_end
+                        ea.join = 1;
+                        ea.join_q_lo = ca.q_lo;
+                        ea.join_chunk = sl->jq_chunk;
+                    }
                 } else if (!ca.raw_hits) {
                     sl->hits.ensure((size_t)bh, "hits");
                     ProfScope p(sl, "expand_hits");
@@ -288,7 +293,20 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                         ea.l2_list = sl->l2_list.p;
                         ea.l2_cap = (uint32_t)std::min<size_t>(sl->l2_list.cap / L2_NSUB, 0xFFFFFFu);  // per sub-list
                         if (!cleared) check_memcpy(hipMemsetAsync(sl->l2_counts.p, 0, (size_t)L2_NSUB * L2_CNT_STRIDE * sizeof(uint32_t), st), "second-level counters");
-                        { ProfScope p(sl, "extend_filter"); launch_extend_filter_cls(ea, st); }
+                        if (ca.join) {
+                            JoinArgs ja;
+                            ja.head = sl->d_jhead;
+                            ja.head_rw = sl->d_jhead;
+                            ja.ent = sl->jq_ent.p;
+                            ja.vstart = sl->jq_vstart.p;
+                            ja.qx = sl->jq_qx.p;
+                            check_memcpy(hipMemsetAsync(&sl->d_jhead->work_next, 0, sizeof(unsigned long long), st), "join work cursor");  // (reruns start over)
+                            ProfScope p(sl, "extend_filter");
+                            launch_join_filter(ea, ja, st);
+                        } else {
+                            ProfScope p(sl, "extend_filter");
+                            launch_extend_filter_cls(ea, st);
+                        }
                         ExtendArgs e2 = ea;
                         e2.td = 0;
                         e2.src_cand = 1;

@@ -35,6 +35,7 @@
 #include "kernels.h"
 #include "plan.h"
 #include "probe.h"
+#include "join.h"
 
 namespace sa {
 
@@ -313,6 +314,15 @@ struct Slot {
     std::vector<ProfRec> prof_pending;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
     size_t events_used = 0;
+    // key-ordered calls (join.h / join.hip): the call's positions sorted by key, entries by class, the query field words
+    DevBuf<uint32_t> jq_keys, jq_pairs, jq_misc, jq_start, jq_pos, jq_ent_nt, jq_qx;
+    DevBuf<uint4> jq_ent;
+    DevBuf<unsigned long long> jq_vstart, jq_stats;
+    DevBuf<uint8_t> jq_scan;
+    JoinHead* d_jhead = nullptr;
+    JoinChunk* d_jplan = nullptr;
+    JoinChunk* h_jplan = nullptr;     // pinned
+    uint32_t jq_chunk = 0;            // chunk size of the running key-ordered call
     WorkRegion work;                  // this slot's share of the device's work arena
 };
 
@@ -433,6 +443,8 @@ extern int g_fast_filter;
 extern int g_packed_filter;
 extern int g_chain_sort_threads, g_chain_buckets, g_chain_bucket_target, g_chain_sort_blocks, g_chain_group_max;
 extern int g_chunks_per_call;
+extern int g_key_order, g_key_order_chunks;
+extern int64_t g_key_order_hits, g_key_order_min_pos;
 extern int64_t g_call_hits, g_call_hits_max;
 extern int g_no_small_dedup;
 extern int g_ctx;
@@ -525,6 +537,7 @@ struct CoreArgs {
     const PackedBuf* q2_own;
     const PackedBuf* q2_other;
     uint32_t q_present;
+    int join;                             // key-ordered call (join_front has sorted the positions and planned the chunks): td is set as well
 };
 
 size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa_segment_pair** out);
@@ -539,6 +552,9 @@ bool ensure_nbr(DevCtx* dc);
 bool q2_usable(const PackedBuf* q2_own, const PackedBuf* q2_other);
 bool td_eligible(DevCtx* dc, const PackedBuf* query4, const PackedBuf* q2_own, const PackedBuf* q2_other);
 uint32_t td_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, int K, const uint32_t* bpos, int rm, uint32_t* words_out);
+bool join_wanted(DevCtx* dc, int K, uint32_t n_positions);  // should this call take the key-ordered form?
+uint32_t join_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, uint32_t qlen, int K, const uint32_t* bpos, const PackedBuf* q2_own, const PackedBuf* q2_other,
+                    uint32_t* words_out);
 uint32_t dropin_td_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, uint32_t qlen, const uint64_t* host_seeds, size_t n,
                          const PackedBuf* q4, const PackedBuf* q2_own, const PackedBuf* q2_other, int rm, uint32_t* first_out,
                          uint32_t* end_out, uint32_t* words_out);

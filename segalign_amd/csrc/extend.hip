@@ -37,6 +37,7 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#include "join.h"
 #include "kmer_dev.h"  // load8u
 
 namespace sa {
@@ -113,7 +114,16 @@ __device__ __forceinline__ void chunk8_exact(const int* __restrict__ s_tab, uint
 // ends.  Every candidate-stage workgroup stages the ends in LDS first (SEG_TABLE below): the search is 6-9 dependent reads, and from
 // the device array itself it cost the five candidate-stage kernels ~100 us per call together (a 63-step compare loop over kernel
 // arguments, which is what a 64-segment limit allowed, cost about the same).
-__device__ __forceinline__ uint32_t seg_of(const ExtendArgs& a, const uint64_t* __restrict__ s_seg, uint64_t local_idx) {
+__device__ __forceinline__ uint32_t seg_of(const ExtendArgs& a, const uint64_t* __restrict__ s_seg, uint64_t local_idx, uint32_t query_loc) {
+    if (a.join) {
+        // key-ordered call (join.h): no hit indices.  `local_idx` is the hit's entry index inside its key's run, s_seg holds per chunk
+        // {p_last : e_thr} and, 256 entries further on, the chunk's first segment: second iteration of the chunk iff the hit sits at the
+        // chunk's last non-empty position at or behind the last hit-bearing seed word (src/seed_filter.cu:732-741)
+        const uint32_t p = query_loc - a.seed_size;
+        const uint32_t c = (p - a.join_q_lo) / a.join_chunk;
+        const uint64_t w = s_seg[c];
+        return (uint32_t)s_seg[256u + c] + ((p == (uint32_t)w && (uint32_t)local_idx >= (uint32_t)(w >> 32)) ? 1u : 0u);
+    }
     const uint64_t g = a.hit_base + local_idx;
     uint32_t lo = 0, hi = (uint32_t)a.num_segs - 1u;  // answer in [lo, hi]; a hit beyond the last end belongs to the last segment
     while (lo < hi) {
@@ -124,7 +134,7 @@ __device__ __forceinline__ uint32_t seg_of(const ExtendArgs& a, const uint64_t* 
 }
 #define SEG_TABLE()                                                                                                      \
     __shared__ uint64_t s_seg[MAX_SEGS];                                                                                 \
-    for (uint32_t t_ = threadIdx.x; t_ < (uint32_t)a.num_segs; t_ += blockDim.x) s_seg[t_] = a.seg_end[t_];             \
+    for (uint32_t t_ = threadIdx.x; t_ < (a.join ? (uint32_t)MAX_SEGS : (uint32_t)a.num_segs); t_ += blockDim.x) s_seg[t_] = a.seg_end[t_]; \
     __syncthreads();
 
 // What to do with a finished hit: 0 = reject, 1 = survivor with entropy 1, 2 = needs the entropy factor (:608,:633)
@@ -1154,6 +1164,174 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(E
 }
 
 // =====================================================================================================================
+// 1e. the class filter of a KEY-ORDERED call (join.h, join.hip): the same verdicts as 1d on the same (record, position) pairs, the
+//     pairs enumerated per seed key
+// =====================================================================================================================
+// 1d streams the hits in query order: every hit brings its own 32-byte record through the memory system, a buffer's 64 lanes hold 64
+// different records and one or two query positions, and a field's LDS address costs shift + mask (+ funnel shift).  Here a wave takes a
+// TILE of 64 consecutive records of the entry list (one or two keys' runs, all of class c = c query positions each) and walks the c
+// positions in lockstep:
+//   * the record is fetched once for c hits and lives in registers as its 19 FIELD WORDS -- fw_k(t) = the byte offset of field k of the
+//     record's class string in the table -- computed once per tile;
+//   * the query side of every address was computed once per position (QRecX, join_qx_kernel): shift and mask are linear over xor, so
+//     the address of field k of (t ^ q) is fw_k(t) ^ fw_k(q): ONE v_xor per lookup;
+//   * right and left walk are interleaved (two independent dependency chains);
+//   * work is claimed dynamically, JOIN_GRAIN steps at a time: the per-tile cost differs by class, static shares finished unevenly
+//     (142 -> 215 G hits/s in the prototype, tools/micro/join_proto.hip).
+// Table, walk state, verdicts and the L2Rec hand-over are those of 1d (the four-base tail table included), so both forms forward the
+// same hits with the same state; L2Rec::hidx is the hit's entry index inside its run (ExtendArgs::join).
+constexpr int JOIN_THREADS = 1024;
+constexpr int JOIN_NFR = 8, JOIN_NFL = 11;  // lookups of the right / left walk (the left one ends with the tail field)
+
+__global__ __launch_bounds__(JOIN_THREADS, 8) void join_filter_kernel(ExtendArgs a, JoinArgs jn) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_cls[CLS_LDS_DWORDS];
+    extern __shared__ L2Rec s_l2_dyn[];
+    cls_table_init(s_cls, a.cls, (int)blockDim.x);
+    __syncthreads();
+    L2Rec* stage = s_l2_dyn + (threadIdx.x >> 6) * CTX_STAGE_CAP;
+    int n_stage = 0;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    const int xdrop = a.xdrop;
+    const uint4* __restrict__ ctx = reinterpret_cast<const uint4*>(a.td_ctx);
+    const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    const uint32_t my_sub = wid & (uint32_t)(L2_NSUB - 1);
+    L2Rec* __restrict__ my_list = a.l2_list + (size_t)my_sub * a.l2_cap;
+    uint32_t* __restrict__ my_count = a.l2_count + my_sub * L2_CNT_STRIDE;
+    const JoinHead* __restrict__ H = jn.head;
+    const unsigned long long work_total = H->work_total;
+
+    for (;;) {
+        // claim JOIN_GRAIN work units (a unit = one 64-hit step of one tile)
+        unsigned long long g = 0;
+        if (lane == 0) g = atomicAdd(&jn.head_rw->work_next, (unsigned long long)JOIN_GRAIN);
+        g = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(g >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)g);
+        if (g >= work_total) break;
+        const unsigned long long w_lo = g, w_hi = min(g + (unsigned long long)JOIN_GRAIN, work_total);
+        for (int c = JOIN_CMAX; c >= 1; c--) {
+            const unsigned long long B = H->work_base[c], vb = H->vbase[c], tot = H->vbase[c + 1] - vb;
+            const unsigned long long ntiles = (tot + 63ull) >> 6;
+            if (ntiles == 0 || w_hi <= B || w_lo >= B + ntiles * (unsigned long long)c) continue;
+            const unsigned long long m_lo = w_lo <= B ? 0ull : min((w_lo - B + (unsigned long long)c - 1ull) / (unsigned long long)c, ntiles);
+            const unsigned long long m_hi = min((w_hi - B + (unsigned long long)c - 1ull) / (unsigned long long)c, ntiles);
+            if (m_lo >= m_hi) continue;
+            const uint32_t e_first = H->cls_first[c], e_last = H->cls_first[c + 1];  // entries of the class (e_last > e_first: tot > 0)
+            // the entry that holds the first record of tile m_lo: the last e with vstart[e] <= v (uniform binary search, once per claim and class)
+            uint32_t e_cur;
+            {
+                const unsigned long long v0 = vb + (m_lo << 6);
+                uint32_t lo = e_first, hi = e_last - 1u;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi + 1u) >> 1;
+                    if (jn.vstart[mid] <= v0) lo = mid; else hi = mid - 1u;
+                }
+                e_cur = lo;
+            }
+            for (unsigned long long m = m_lo; m < m_hi; m++) {
+                const unsigned long long v = vb + (m << 6) + (unsigned long long)lane;
+                const unsigned long long v_end = vb + (m << 6) + 63ull;
+                const bool valid = v < vb + tot;
+                // ---- which entry?  the starts of the next sixteen entries, one per lane group; a tile spans one to three entries as a rule ----
+                uint32_t e = e_cur;
+                for (;;) {
+                    const uint32_t ej = min(e_cur + 1u + (uint32_t)(lane & 15), e_last);
+                    const unsigned long long ps = jn.vstart[ej];
+                    bool more = false;
+#pragma unroll 1
+                    for (int j = 0; j < 16; j++) {
+                        const unsigned long long pj = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(ps >> 32), j) << 32) |
+                                                      (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ps, j);
+                        if (e_cur + 1u + (uint32_t)j >= e_last || pj > v_end) break;  // (uniform) the class ends, or entry j starts behind the tile
+                        e += (v >= pj) ? 1u : 0u;
+                        more = j == 15;
+                    }
+                    if (!more) break;
+                    e_cur += 16u;
+                }
+                const uint4 en = jn.ent[e];
+                const unsigned long long p_start = jn.vstart[e];
+                const uint32_t tidx = valid ? (uint32_t)(v - p_start) : 0u;  // entry index inside the run (lanes past the class stay on entry 0 of the last run)
+                const unsigned long long rec = (((unsigned long long)en.y << 32) | en.x) + tidx;
+                e_cur = (uint32_t)__builtin_amdgcn_readlane((int)e, 63);
+                const uint4 c0 = ctx[2 * rec], tl = ctx[2 * rec + 1];
+                const uint32_t ref_loc = c0.x + a.seed_size;  // :220
+                // the record's field words, once per tile
+                uint32_t tf[JOIN_NFR + JOIN_NFL];
+                {
+                    const uint32_t r[3] = {c0.y, c0.z, c0.w}, l[4] = {tl.x, tl.y, tl.z, tl.w};
+#pragma unroll
+                    for (int k = 0; k < JOIN_NFR; k++) {
+                        const int bit = 12 * k, d = bit >> 5, o = bit & 31;
+                        const uint64_t two = (uint64_t)r[d] | ((uint64_t)(d + 1 < 3 ? r[d + 1 < 3 ? d + 1 : d] : 0u) << 32);
+                        tf[k] = (uint32_t)((two >> o) << 2) & 0x3FFCu;
+                    }
+#pragma unroll
+                    for (int k = 0; k < JOIN_NFL - 1; k++) {
+                        const int bit = 12 * k, d = bit >> 5, o = bit & 31;
+                        const uint64_t two = (uint64_t)l[d] | ((uint64_t)(d + 1 < 4 ? l[d + 1 < 4 ? d + 1 : d] : 0u) << 32);
+                        tf[JOIN_NFR + k] = (uint32_t)((two >> o) << 2) & 0x3FFCu;
+                    }
+                    tf[JOIN_NFR + JOIN_NFL - 1] = ((l[3] >> 22) & 0x3FCu) | JOIN_TAIL_OFF;
+                }
+                const uint32_t* __restrict__ qp = jn.qx + (size_t)en.z * JOIN_QX_DW;
+                for (int qi = 0; qi < c; qi++, qp += JOIN_QX_DW) {
+                    uint32_t q[JOIN_QX_DW];
+#pragma unroll
+                    for (int k = 0; k < JOIN_QX_DW / 4; k++) {
+                        const uint4 t4 = reinterpret_cast<const uint4*>(qp)[k];
+                        q[4 * k] = t4.x; q[4 * k + 1] = t4.y; q[4 * k + 2] = t4.z; q[4 * k + 3] = t4.w;
+                    }
+                    uint32_t PR = 0, WR = 0, PL = 0, WL = 0;
+#pragma unroll
+                    for (int k = 0; k < JOIN_NFL; k++) {
+                        if (k < JOIN_NFR) cls_step(s_cls, tf[k] ^ q[1 + k], PR, WR);
+                        cls_step(s_cls, tf[JOIN_NFR + k] ^ q[1 + JOIN_NFR + k], PL, WL);
+                    }
+                    const bool r_alive = (int)(short)((CLS_TRACK_DROP ? WR : PR) & 0xFFFFu) >= -xdrop;  // (:374)
+                    const int bestR = ((int)PR >> 16) - (int)(short)(PR & 0xFFFFu);
+                    const bool l_alive = (int)(short)((CLS_TRACK_DROP ? WL : PL) & 0xFFFFu) >= -xdrop;  // (:523)
+                    const int bestL = ((int)PL >> 16) - (int)(short)(PL & 0xFFFFu);
+                    const bool fwd = valid && (r_alive || l_alive || classify(a, bestR + bestL) != 0);
+                    const uint32_t query_loc = q[0] + a.seed_size;  // :204
+                    const unsigned long long fm = __ballot(fwd);
+                    if (fm) {
+                        L2Rec cr;
+                        cr.ref_loc = ref_loc;
+                        cr.query_loc = query_loc;
+                        cr.hidx = tidx;
+                        cr.state = (PL & 0xFFFF0000u) | ((0u - PL) & 0xFFFFu);
+                        const uint32_t fl = (r_alive ? 1u : 0u) | (l_alive ? 2u : 0u);
+                        cr.meta = (uint32_t)(r_alive ? bestL : bestR) | ((fl ? fl : 3u) << 16);
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+                        if (fwd) stage[n_stage + (int)rank] = cr;
+                        n_stage += __popcll(fm);
+                        __builtin_amdgcn_wave_barrier();
+                        if (n_stage >= CTX_STAGE_FLUSH) {
+                            const int k = n_stage < 64 ? n_stage : 64;
+                            stage_flush(stage, k, my_list, my_count, a.l2_cap, lane);
+                            const int rest = n_stage - k;
+                            L2Rec tmp = cr;
+                            if (lane < rest) tmp = stage[k + lane];
+                            __builtin_amdgcn_wave_barrier();
+                            if (lane < rest) stage[lane] = tmp;
+                            __builtin_amdgcn_wave_barrier();
+                            n_stage = rest;
+                        }
+                    }
+                    if (a.audit_list) {  // (tests) the hits this level rejects
+                        uint2 ar;
+                        ar.x = ref_loc;
+                        ar.y = query_loc;
+                        wave_append(valid && !fwd, ar, a.audit_list, a.audit_count, a.audit_cap, lane, lane_lt);
+                    }
+                }
+            }
+        }
+    }
+    stage_flush(stage, n_stage, my_list, my_count, a.l2_cap, lane);
+}
+
+// =====================================================================================================================
 // 2. exact extension of the candidates: one wave per hit, 512 bases per step
 // =====================================================================================================================
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -1302,7 +1480,7 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_exact_kernel(ExtendArgs a)
         const uint32_t hidx = (uint32_t)rfl((int)cr.hidx);
         int bestR, bposR, bestL, boffL;
         wave_extend_exact<COUNT_EXAMINED, XDROP_NONNEG>(a, s_tab, R8b, Qb, lane, ref_loc, query_loc, bestR, bposR, bestL, boffL, examined);
-        wave_finalize(a, st, lane, ref_loc, query_loc, seg_of(a, s_seg, hidx), bestR, bposR, bestL, boffL);
+        wave_finalize(a, st, lane, ref_loc, query_loc, seg_of(a, s_seg, hidx, query_loc), bestR, bposR, bestL, boffL);
     }
     EXACT_KERNEL_EPILOGUE()
 }
@@ -1412,7 +1590,7 @@ __global__ __launch_bounds__(256) void chain_count_kernel(ExtendArgs a) {
         uint32_t b = 0;
         if (i < n) {
             const CandRec c = a.cand_list[first + i];
-            b = chain_bucket_of(B, seg_of(a, s_seg, c.hidx), c);
+            b = chain_bucket_of(B, seg_of(a, s_seg, c.hidx, c.query_loc), c);
         }
         uint32_t base;
         wave_bucket_add<false>(a.chain_bucket_cnt, i < n, b, base);
@@ -1474,7 +1652,7 @@ __global__ __launch_bounds__(256) void chain_scatter_kernel(ExtendArgs a) {
         CandRec c = {0u, 0u, 0u};
         if (i < n) {
             c = a.cand_list[first + i];
-            b = chain_bucket_of(B, seg_of(a, s_seg, c.hidx), c);
+            b = chain_bucket_of(B, seg_of(a, s_seg, c.hidx, c.query_loc), c);
         }
         // the counters of the counting pass are the cursors, counted down to zero: a wave takes the k slots below what it finds
         uint32_t base;
@@ -1498,7 +1676,7 @@ template <bool XDROP_NONNEG>
 __device__ __forceinline__ bool chain_is_run_head(const ExtendArgs& a, const uint64_t* __restrict__ s_seg, const int* __restrict__ s_tab, const uint8_t* __restrict__ R8b,
                                                   const uint8_t* __restrict__ Qb, const CandRec& c, const CandRec& pc) {
     // same iteration, same diagonal, predecessor strictly before this anchor
-    if (!((c.ref_loc - c.query_loc) == (pc.ref_loc - pc.query_loc) && c.query_loc > pc.query_loc && seg_of(a, s_seg, c.hidx) == seg_of(a, s_seg, pc.hidx)))
+    if (!((c.ref_loc - c.query_loc) == (pc.ref_loc - pc.query_loc) && c.query_loc > pc.query_loc && seg_of(a, s_seg, c.hidx, c.query_loc) == seg_of(a, s_seg, pc.hidx, pc.query_loc)))
         return true;
     const uint32_t g = c.query_loc - pc.query_loc;  // anchor gap (> 0)
     if (g > CHAIN_GAP_MAX) return true;
@@ -1529,7 +1707,7 @@ __device__ __forceinline__ bool chain_is_run_head(const ExtendArgs& a, const uin
 // per LDS read.)
 __device__ __forceinline__ uint32_t chain_key32(const ExtendArgs& a, const uint64_t* __restrict__ s_seg, const CandRec& c, uint32_t idx) {
     uint32_t h = ((c.ref_loc - c.query_loc) * 0xC2B2AE35u) ^ ((c.query_loc >> CHAIN_QSHIFT) * 0x27D4EB2Fu);
-    if (a.chain_q_bits != 32u) h ^= (seg_of(a, s_seg, c.hidx) - a.seg_base) * 0x165667B1u;  // (several iterations per batch: general path)
+    if (a.chain_q_bits != 32u) h ^= (seg_of(a, s_seg, c.hidx, c.query_loc) - a.seg_base) * 0x165667B1u;  // (several iterations per batch: general path)
     return (h & 0xFFE00000u) | ((c.query_loc & ((1u << CHAIN_QSHIFT) - 1u)) << 12) | idx;
 }
 static_assert(CHAIN_QSHIFT == 9 && CHAIN_SORT_MAX <= 4096, "chain_key32: 11 + 9 + 12 bits");
@@ -1655,7 +1833,7 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_exact_chain_kernel(ExtendA
             const uint32_t hidx = (uint32_t)rfl((int)cr.hidx);
             int bestR, bposR, bestL, boffL;
             wave_extend_exact<false, XDROP_NONNEG>(a, s_tab, R8b, Qb, lane, ref_loc, query_loc, bestR, bposR, bestL, boffL, examined);
-            wave_finalize(a, st, lane, ref_loc, query_loc, seg_of(a, s_seg, hidx), bestR, bposR, bestL, boffL);
+            wave_finalize(a, st, lane, ref_loc, query_loc, seg_of(a, s_seg, hidx, query_loc), bestR, bposR, bestL, boffL);
             // members of the run follow in the sorted list until the next run head
             const int64_t right_end = (int64_t)ref_loc + (int64_t)bposR;  // E_R(head) as a target position
             uint32_t nxt = 0xFFFFFFFFu;
@@ -1766,6 +1944,14 @@ void launch_extend_filter_cls(const ExtendArgs& a, hipStream_t s) {
     const bool one_copy = a.cls_one_copy != 2;
     if (one_copy) hipLaunchKernelGGL(extend_filter_cls_kernel<true>, dim3(blocks), dim3(threads), lds, s, a);
     else hipLaunchKernelGGL(extend_filter_cls_kernel<false>, dim3(blocks), dim3(threads), lds, s, a);
+}
+
+// class filter of a key-ordered call (1e): persistent waves that claim their work on the device
+void launch_join_filter(const ExtendArgs& a, const JoinArgs& j, hipStream_t s) {
+    if (a.num_hits == 0) return;
+    const uint32_t wpb = JOIN_THREADS / 64;
+    const size_t lds = wpb * CTX_STAGE_CAP * sizeof(L2Rec);
+    hipLaunchKernelGGL(join_filter_kernel, dim3(512), dim3(JOIN_THREADS), lds, s, a, j);
 }
 
 void launch_chain_group(const ExtendArgs& a, hipStream_t s) {  // chain_bucket_cnt must be zero on entry

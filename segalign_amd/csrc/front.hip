@@ -293,6 +293,129 @@ uint32_t td_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, int K, const uint
     return (uint32_t)(nvalid * words);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// KEY-ORDERED calls (join.h): the front of a call whose hits are enumerated per seed key
+// ---------------------------------------------------------------------------------------------------------------------
+// A call goes key-ordered when that pays: the context table is resident, the seed keys are short enough for the two-level partition
+// build (<= 24 bits), a query position collects enough hits that the per-position work (sort, field words: ~110 bytes of traffic per
+// position) disappears behind them, and the call holds about one position per seed key or more -- below that a key's run is fetched
+// for one position anyway and the streamed filter (extend.hip 1d) is as good (tools/micro/join_proto.hip: 139 / 174 / 215 / 257 G hits/s
+// at 0.75 / 1.5 / 3 / 6 positions per key against 140-148 streamed).
+bool join_wanted(DevCtx* dc, int K, uint32_t n_positions) {
+    if (!g_key_order || !dc->nbr_ctx || dc->nbr_state != 1 || g_audit_cap > (1u << 27)) return false;
+    if (2 * g_shape.weight > 24 || !table_partition_build_supported(g_shape.weight) || dc->nkeys != (1u << (2 * g_shape.weight))) return false;
+    if (g_key_order == 2) return true;
+    const double per_pos = (double)dc->nbr_total / (double)std::max<uint32_t>(dc->nkeys, 1);
+    const uint64_t min_pos = g_key_order_min_pos > 0 ? (uint64_t)g_key_order_min_pos : (uint64_t)dc->nkeys;
+    return K > 1 && per_pos >= 16.0 && (uint64_t)n_positions >= min_pos;
+}
+
+// Sort the call's positions by key, plan its chunks, lay out the entries and the query field words -- everything the filter (extend.hip
+// 1e) and saf_core need; one D2H, one sync.  Returns the number of seed words the reference would have been handed (0: nothing to do),
+// or UINT32_MAX when the call must be split (a chunk with num_hits >= MAX_HITS needs the general path's iteration plan).
+uint32_t join_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, uint32_t qlen, int K, const uint32_t* bpos, const PackedBuf* q2_own, const PackedBuf* q2_other,
+                    uint32_t* words_out) {
+    hipStream_t st = sl->stream;
+    const uint32_t start = bpos[0], end = bpos[K];
+    const uint32_t tmask = seed_tmask();
+    const uint32_t words = 1u + (uint32_t)__builtin_popcount(tmask);
+    *words_out = words;
+    if (end <= start) return 0;
+    const uint32_t n = end - start;
+    const uint32_t chunk = K > 1 ? g_wga_chunk : std::max(n, 1u);
+    for (int c = 0; c <= K; c++)
+        if (bpos[c] != (uint32_t)std::min<uint64_t>((uint64_t)start + (uint64_t)c * chunk, end) || K > SA_MAX_CHUNKS) {
+            fprintf(stderr, "Error: key-ordered call with chunk bounds off the wga_chunk grid (chunk %d of %d)\n", c, K);
+            exit(15);
+        }
+    sl->jq_chunk = chunk;
+    SeedShape sh = g_shape;
+    sh.span = (int)g_seed_size;
+    const uint32_t nkeys = dc->nkeys;
+    // ---- 1. the positions of the call sorted by key: the table build's radix partition on the query strand (table.hip) ----
+    const size_t pw = table_partition_part_start_words();
+    sl->jq_keys.ensure(n, "join keys");
+    sl->jq_pairs.ensure((size_t)4 * n, "join partition pairs");
+    sl->jq_misc.ensure(3 * pw + 1024 + 16, "join partition scratch");
+    sl->jq_start.ensure((size_t)nkeys + 1, "join key starts");
+    sl->jq_pos.ensure(n, "join positions");
+    const size_t ent_cap = (size_t)std::min<uint32_t>(nkeys, n) + n / JOIN_CMAX + 64;
+    sl->jq_scan.ensure(std::max(scan_temp_bytes(std::max<size_t>(pw, (size_t)1 << 18)), scan_temp_bytes(ent_cap)), "join scan temp");
+    sl->jq_stats.ensure((size_t)2 * SA_MAX_CHUNKS, "join chunk statistics");  // hits (u64) | valid, last (u32 each)
+    sl->jq_ent.ensure(ent_cap, "join entries");
+    sl->jq_ent_nt.ensure(ent_cap, "join entry run lengths");
+    sl->jq_vstart.ensure(ent_cap + 1, "join entry starts");
+    sl->jq_qx.ensure((size_t)n * JOIN_QX_DW + 64, "join query field words");
+    uint32_t* coarse = sl->jq_misc.p;
+    uint32_t* part_start = coarse + pw;
+    uint32_t* cursor = part_start + pw;
+    uint8_t* part_unsorted = reinterpret_cast<uint8_t*>(cursor + pw);
+    uint32_t* key_a = sl->jq_pairs.p;
+    {
+        ProfScope p(sl, "join_sort");
+        check_memcpy(hipMemsetAsync(coarse, 0, pw * sizeof(uint32_t), st), "join coarse histogram");
+        launch_table_keys(qcodes, n, start, 1u, sh, sl->jq_keys.p, coarse, st);
+        launch_exclusive_scan_u32(coarse, part_start, pw - 1, sl->jq_scan.p, st);
+        // (the number of valid positions is only known on the device: the second pass runs over all n slots, the unused ones invalid)
+        check_memcpy(hipMemsetAsync(key_a, 0xFF, (size_t)n * sizeof(uint32_t), st), "join partition pairs");
+        launch_table_partition_build(sl->jq_keys.p, n, start, 1u, sh.weight, part_start, n, cursor, key_a, key_a + n, key_a + 2 * (size_t)n, key_a + 3 * (size_t)n,
+                                     part_unsorted, sl->jq_start.p, sl->jq_pos.p, nullptr, sl->jq_scan.p, nullptr, st);
+    }
+    // ---- 2. chunk statistics + the reference's iteration split per chunk ----
+    unsigned long long* d_hits = sl->jq_stats.p;
+    uint32_t* d_valid = reinterpret_cast<uint32_t*>(sl->jq_stats.p + SA_MAX_CHUNKS);
+    uint32_t* d_last = d_valid + SA_MAX_CHUNKS;
+    sl->l2_counts.ensure((size_t)L2_NSUB * L2_CNT_STRIDE, "second-level counters");
+    sl->chain_bucket_cnt.ensure(chain_num_buckets(), "chain buckets");
+    {
+        ProfScope p(sl, "join_plan");
+        check_memcpy(hipMemsetAsync(sl->jq_stats.p, 0, (size_t)2 * SA_MAX_CHUNKS * sizeof(unsigned long long), st), "join chunk statistics");
+        check_memcpy(hipMemsetAsync(sl->d_jhead, 0, sizeof(JoinHead), st), "join head");
+        launch_join_stats(sl->jq_start.p, sl->jq_pos.p, dc->nbr_start, nkeys, start, chunk, K, d_hits, d_valid, d_last, st);
+        launch_join_plan(qcodes, sh, tmask, dc->bucket_start, d_hits, d_valid, d_last, K, sl->d_jplan, sl->d_seg_end, sl->d_jhead, st);
+        // the device-side state the later stages of the call expect zeroed
+        ZeroList zl;
+        zl.p[0] = reinterpret_cast<uint32_t*>(sl->d_cnt);  zl.n[0] = (uint32_t)(sizeof(Counters) / sizeof(uint32_t));
+        zl.p[1] = sl->l2_counts.p;                         zl.n[1] = (uint32_t)(L2_NSUB * L2_CNT_STRIDE);
+        zl.p[2] = sl->chain_bucket_cnt.p;                  zl.n[2] = chain_num_buckets();
+        zl.p[3] = sl->d_seg_info;                          zl.n[3] = dedup_seg_info_words();
+        launch_call_clear(zl, st);
+    }
+    check_launch("join sort/plan");
+    check_memcpy(hipMemcpyAsync(sl->h_jplan, sl->d_jplan, sizeof(JoinChunk) * K, hipMemcpyDeviceToHost, st), "join plan");
+    // ---- 3. entries by class, their starts in the virtual record space, the query field words (queued behind the plan: the host's
+    //         decision below only ever drops the call, it never changes these) ----
+    {
+        ProfScope p(sl, "join_entries");
+        check_memcpy(hipMemsetAsync(sl->jq_ent_nt.p, 0, ent_cap * sizeof(uint32_t), st), "join entry run lengths");
+        launch_join_entries(sl->jq_start.p, dc->nbr_start, nkeys, sl->d_jhead, sl->jq_ent.p, sl->jq_ent_nt.p, (uint32_t)std::min<size_t>(ent_cap, 0xFFFFFFFFu), st);
+        launch_exclusive_scan_u64(sl->jq_ent_nt.p, reinterpret_cast<uint64_t*>(sl->jq_vstart.p), ent_cap, sl->jq_scan.p, st);
+        launch_join_finish(sl->d_jhead, sl->jq_vstart.p, st);
+    }
+    {
+        ProfScope p(sl, "join_qx");
+        launch_join_qx(sl->jq_start.p, nkeys, sl->jq_pos.p, q2_own->base, q2_other->base, qlen, g_seed_size, sl->jq_qx.p, st);
+    }
+    check_launch("join entries");
+    check_sync(st, "join plan");
+    uint64_t nvalid = 0, hit_base = 0;
+    for (int c = 0; c < K; c++) {
+        const JoinChunk& jc = sl->h_jplan[c];
+        TdPlan& tp = sl->h_td_plan[c];
+        tp.hit_base = hit_base;
+        tp.num_hits = jc.hits;
+        tp.split = hit_base;  // (hit offsets only size the lists of a key-ordered call: its segments are resolved per hit, extend.hip seg_of)
+        tp.num_valid = jc.valid;
+        tp.m_lo = tp.m_hi = 0;
+        hit_base += jc.hits;
+        nvalid += jc.valid;
+        if (jc.hits >= (uint64_t)(uint32_t)g_max_hits || jc.hits > 0xFFFFFFFFull) return 0xFFFFFFFFu;
+    }
+    if (nvalid * words >= 0xFFFFFFFFull) return 0xFFFFFFFFu;
+    t_front_flags |= SA_PATH_KEY_ORDERED;
+    return (uint32_t)(nvalid * words);
+}
+
 // DROP-IN FAST PATH.  g_SeedAndFilter hands the engine a host seed vector (src/seeder.cpp:57-78).  When that vector is exactly
 // what the device seeder would emit for the positions it spans -- checked on the device, one lane per position group, plus the
 // probe's own count of valid positions -- the call is the same as sa_seed_and_filter_range(first, last + 1) and takes the

@@ -184,6 +184,11 @@ struct ExtendArgs {
     uint32_t out_cap;         // capacity of out[]; the counter keeps counting past it, writes are dropped
     uint32_t* out_count;      // device counter
     unsigned long long* examined; // optional (null = do not count): [0] = E of the call, [1] = bases scored by the filter
+    // key-ordered call (join.h): hits carry no index -- seg_end points at the per-chunk table join_plan_kernel wrote ({p_last : e_thr}
+    // x 256, then the chunks' first segments x 256), L2Rec / CandRec::hidx is the hit's entry index inside its key's run
+    int join;
+    uint32_t join_q_lo;       // first query position of the call
+    uint32_t join_chunk;      // chunk size (wga_chunk)
     // repeat-masker deltas (repeat_masker_src/seed_filter.cu:239-244, 305-333, 705-708)
     int rm;
     uint32_t rm_win_start, rm_win_end;

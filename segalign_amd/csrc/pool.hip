@@ -38,6 +38,9 @@ void slot_init(Slot& s, DevCtx* dc) {
     s.l2_list.region = &s.work;
     s.cand_list.region = s.chain_tmp.region = s.chain_sorted.region = &s.work;
     s.ent_list.region = &s.work;
+    s.jq_keys.region = s.jq_pairs.region = s.jq_pos.region = s.jq_ent_nt.region = s.jq_qx.region = &s.work;
+    s.jq_ent.region = &s.work;
+    s.jq_vstart.region = &s.work;
     hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
     s.d_plan = (IterPlan*)dev_malloc(sizeof(IterPlan) * SA_MAX_CHUNKS_GENERAL, "plan");
     s.d_seg_end = (uint64_t*)dev_malloc(sizeof(uint64_t) * MAX_SEGS, "segment ends");
@@ -47,11 +50,14 @@ void slot_init(Slot& s, DevCtx* dc) {
     s.d_td_bounds = dev_malloc(probe_bounds_bytes(), "probe bounds");
     s.d_seg_info = (uint32_t*)dev_malloc(dedup_seg_info_words() * sizeof(uint32_t), "segment info");
     s.d_td_plan = (TdPlan*)dev_malloc(sizeof(TdPlan) * SA_MAX_CHUNKS, "probe plan");
+    s.d_jhead = (JoinHead*)dev_malloc(sizeof(JoinHead), "join head");
+    s.d_jplan = (JoinChunk*)dev_malloc(sizeof(JoinChunk) * SA_MAX_CHUNKS, "join plan");
     if (hipHostMalloc((void**)&s.h_cov, 8 * sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc((void**)&s.h_bounds, (SA_MAX_CHUNKS + 2) * sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc((void**)&s.h_plan, sizeof(IterPlan) * SA_MAX_CHUNKS_GENERAL) != hipSuccess ||
         hipHostMalloc((void**)&s.h_seg_end, sizeof(uint64_t) * MAX_SEGS) != hipSuccess ||
         hipHostMalloc((void**)&s.h_td_plan, sizeof(TdPlan) * SA_MAX_CHUNKS) != hipSuccess ||
+        hipHostMalloc((void**)&s.h_jplan, sizeof(JoinChunk) * SA_MAX_CHUNKS) != hipSuccess ||
         hipHostMalloc((void**)&s.h_seg_info, dedup_seg_info_words() * sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc((void**)&s.h_verify, sizeof(uint32_t)) != hipSuccess ||
         hipHostMalloc((void**)&s.h_cnt, sizeof(Counters)) != hipSuccess) {
@@ -75,6 +81,12 @@ void slot_destroy(Slot& s) {
     s.td_toff.release("probe"); s.td_tcnt.release("probe"); s.td_rec.release("probe"); s.td_chunk.release("probe"); s.td_bits.release("probe"); s.td_partial.release("probe");
     dev_free(s.d_td_bounds, "probe bounds"); dev_free(s.d_td_plan, "probe plan"); dev_free(s.d_seg_info, "segment info");
     s.d_td_bounds = nullptr; s.d_td_plan = nullptr; s.d_seg_info = nullptr;
+    s.jq_keys.release("join"); s.jq_pairs.release("join"); s.jq_misc.release("join"); s.jq_start.release("join"); s.jq_pos.release("join");
+    s.jq_ent_nt.release("join"); s.jq_qx.release("join"); s.jq_ent.release("join"); s.jq_vstart.release("join"); s.jq_stats.release("join"); s.jq_scan.release("join");
+    dev_free(s.d_jhead, "join head"); dev_free(s.d_jplan, "join plan");
+    s.d_jhead = nullptr; s.d_jplan = nullptr;
+    if (s.h_jplan) hipHostFree(s.h_jplan);
+    s.h_jplan = nullptr;
     if (s.h_seg_info) hipHostFree(s.h_seg_info);
     s.h_seg_info = nullptr;
     if (s.h_td_plan) hipHostFree(s.h_td_plan);

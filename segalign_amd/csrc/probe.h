@@ -51,6 +51,7 @@ void launch_probe_lookup(const uint8_t* query, uint32_t start, uint32_t n, SeedS
 void launch_probe_compact(uint32_t start, uint32_t n, const uint64_t* t_off, const uint32_t* t_cnt, void* partial_buf, void* bounds_buf,
                           TdRec* c_rec, uint32_t* chunk_rec, uint32_t chunk_cap, uint32_t* head_bits, uint32_t head_words,
                           const ZeroList& zero, const TdBounds& bpos, bool first_pass, hipStream_t s);
+void launch_call_clear(const ZeroList& zero, hipStream_t s);
 void launch_probe_plan(const uint8_t* query, SeedShape sh, uint32_t tmask, const uint32_t* bucket_start, const void* bounds_buf, int nchunks,
                        const TdRec* c_rec, TdPlan* plan, uint64_t* seg_end /* [2 * nchunks] */, hipStream_t s);
 

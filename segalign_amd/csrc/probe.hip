@@ -553,6 +553,9 @@ void launch_probe_compact(uint32_t start, uint32_t n, const uint64_t* t_off, con
     hipLaunchKernelGGL(probe_compact_kernel, dim3(nblocks), dim3(PR_THREADS), 0, s, start, n, t_off, t_cnt, scanned, total, c_rec, chunk_rec,
                        chunk_cap, head_bits, head_words, bpos, reinterpret_cast<Tri*>(bounds_buf));
 }
+void launch_call_clear(const ZeroList& zero, hipStream_t s) {  // the clearing kernel alone (key-ordered calls: no head-bit map)
+    hipLaunchKernelGGL(call_clear_kernel, dim3(64), dim3(256), 0, s, (const Tri*)nullptr, (uint32_t*)nullptr, 0u, zero);
+}
 void launch_probe_plan(const uint8_t* query, SeedShape sh, uint32_t tmask, const uint32_t* bucket_start, const void* bounds_buf, int nchunks,
                        const TdRec* c_rec, TdPlan* plan, uint64_t* seg_end, hipStream_t s) {
     hipLaunchKernelGGL(probe_plan_kernel, dim3(1), dim3((nchunks + 63) / 64 * 64), 0, s, query, sh, tmask, bucket_start, reinterpret_cast<const Tri*>(bounds_buf),

@@ -42,6 +42,7 @@ C_ABI_SYMBOLS = [
 IVL_DTYPE = np.dtype([("query_start", "<u4"), ("len", "<u4")])  # struct Segment, repeat_masker_src/graph.h:32-35
 STRAND_PLUS, STRAND_MINUS, STRAND_BOTH = 1, 2, 3
 PATH_LIST_REGROWN, PATH_DEDUP_FALLBACK, PATH_CHAIN_BUCKET_OVERFLOW, PATH_CHAIN_SLICED, PATH_HEAD_BITS_REGROWN, PATH_GENERAL_FALLBACK = 1, 2, 4, 8, 16, 32
+PATH_KEY_ORDERED = 64
 
 
 class CallStats(C.Structure):

@@ -45,6 +45,8 @@ struct JoinArgs {
     uint32_t* l2_count;
     uint32_t l2_cap;
     unsigned long long* n_hits;  // (check) hits scored
+    unsigned long long* work_next;  // dynamic distribution: next unclaimed work unit (variant 2 with GRAIN > 0)
+    uint32_t grain;
 };
 
 __host__ __device__ inline uint32_t hash32(uint32_t x) {
@@ -321,10 +323,19 @@ __global__ __launch_bounds__(THREADS) void join_filter2_kernel(JoinArgs a, const
     const uint32_t my_sub = (uint32_t)wid & (L2_NSUB - 1);
     L2Rec* __restrict__ my_list = a.l2_list + (size_t)my_sub * a.l2_cap;
     uint32_t* __restrict__ my_count = a.l2_count + my_sub * L2_CNT_STRIDE;
-    const uint64_t w_lo = wid * a.work_total / NWV, w_hi = (wid + 1) * a.work_total / NWV;
+    uint64_t w_lo = wid * a.work_total / NWV, w_hi = (wid + 1) * a.work_total / NWV;
     const int xdrop = a.xdrop;
     unsigned long long scored = 0;
 
+    for (bool first = true;; first = false) {
+    if (a.grain) {  // dynamic: a wave claims `grain` work units at a time (the per-tile overhead differs by class: static shares finish unevenly)
+        unsigned long long g = 0;
+        if (lane == 0) g = atomicAdd(a.work_next, (unsigned long long)a.grain);
+        g = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(g >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)g);
+        if (g >= a.work_total) break;
+        w_lo = g;
+        w_hi = std::min<uint64_t>(g + a.grain, a.work_total);
+    } else if (!first) break;
     for (int c = CMAX; c >= 1; c--) {
         const uint64_t B = a.work_base[c], tot = a.cls_total[c];
         const uint64_t ntiles = (tot + 63) >> 6;
@@ -424,6 +435,7 @@ __global__ __launch_bounds__(THREADS) void join_filter2_kernel(JoinArgs a, const
             }
         }
     }
+    }
     if (n_stage > 0) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(my_count, (uint32_t)n_stage);
@@ -512,7 +524,8 @@ static double run_variant(const char* name, JoinArgs a, int blocks, uint64_t hit
 }
 
 template <int FB, int REP, bool TRACKW, int THREADS>
-static double run_variant2(const char* name, JoinArgs a, int blocks, uint64_t hits, uint64_t ctx_bytes, uint64_t total_q, std::vector<L2Rec>* got) {
+static double run_variant2(const char* name, JoinArgs a, int blocks, uint64_t hits, uint64_t ctx_bytes, uint64_t total_q, std::vector<L2Rec>* got, uint32_t grain = 0) {
+    a.grain = grain;
     uint32_t* d_qx;
     CK(hipMalloc(&d_qx, (total_q + 64) * QX<FB>::DW * 4));
     hipEvent_t e0, e1;
@@ -529,6 +542,7 @@ static double run_variant2(const char* name, JoinArgs a, int blocks, uint64_t hi
     for (int it = 0; it < 4; it++) {
         CK(hipMemset(a.l2_count, 0, L2_NSUB * L2_CNT_STRIDE * 4));
         if (a.n_hits) CK(hipMemset(a.n_hits, 0, 8));
+        CK(hipMemset(a.work_next, 0, 8));
         CK(hipEventRecord(e0));
         hipLaunchKernelGGL((join_filter2_kernel<FB, REP, TRACKW, THREADS>), dim3(blocks), dim3(THREADS), lds, 0, a, d_qx);
         CK(hipEventRecord(e1));
@@ -636,6 +650,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&a.l2_list, (size_t)a.l2_cap * L2_NSUB * sizeof(L2Rec)));
     CK(hipMalloc(&a.l2_count, L2_NSUB * L2_CNT_STRIDE * 4));
     if (check) CK(hipMalloc(&a.n_hits, 8));
+    CK(hipMalloc(&a.work_next, 8));
     const uint64_t ctx_bytes = total_t * 32;
 
     std::vector<L2Rec> got;
@@ -677,5 +692,18 @@ int main(int argc, char** argv) {
     if (SEL()) { run_variant2<6, 1, false, 1024>("fw 6-base 1 rep, no W", a, 512, hits, ctx_bytes, total_q, g);     verify(6, "fw 6/1 noW", false); }
     if (SEL()) { run_variant2<6, 4, false, 512>("fw 6-base 4 rep, no W", a, 512, hits, ctx_bytes, total_q, g);      verify(6, "fw 6/4 noW", false); }
     if (SEL()) { run_variant2<5, 16, false, 512>("fw 5-base 16 rep, no W", a, 512, hits, ctx_bytes, total_q, g);    verify(5, "fw 5/16 noW", false); }
+    if (SEL()) { run_variant2<6, 1, true, 1024>("fw 6-base 1 rep, dynamic 4096", a, 512, hits, ctx_bytes, total_q, g, 4096);   verify(6, "fw 6/1 dyn"); }
+    if (SEL()) { run_variant2<6, 1, true, 1024>("fw 6-base 1 rep, dynamic 1024", a, 512, hits, ctx_bytes, total_q, g, 1024);   verify(6, "fw 6/1 dyn"); }
+    if (SEL()) { run_variant2<6, 1, false, 1024>("fw 6-base 1 rep, no W, dynamic 4096", a, 512, hits, ctx_bytes, total_q, g, 4096);   verify(6, "fw 6/1 noW dyn", false); }
+    if (SEL()) { run_variant2<6, 4, true, 512>("fw 6-base 4 rep, dynamic 4096", a, 512, hits, ctx_bytes, total_q, g, 4096);   verify(6, "fw 6/4 dyn"); }
+    if (SEL()) { run_variant2<5, 8, true, 1024>("fw 5-base 8 rep, dynamic 4096", a, 512, hits, ctx_bytes, total_q, g, 4096);   verify(5, "fw 5/8 dyn"); }
+    if (SEL()) { run_variant2<6, 1, true, 1024>("fw 6-base 1 rep, dynamic 512", a, 512, hits, ctx_bytes, total_q, g, 512);   verify(6, "fw 6/1 dyn"); }
+    if (SEL()) { run_variant2<6, 1, true, 1024>("fw 6-base 1 rep, dynamic 256", a, 512, hits, ctx_bytes, total_q, g, 256);   verify(6, "fw 6/1 dyn"); }
+    if (SEL()) { run_variant2<6, 1, true, 1024>("fw 6-base 1 rep, dynamic 128", a, 512, hits, ctx_bytes, total_q, g, 128);   verify(6, "fw 6/1 dyn"); }
+    if (SEL()) { run_variant2<6, 1, false, 1024>("fw 6-base 1 rep, no W, dynamic 256", a, 512, hits, ctx_bytes, total_q, g, 256);   verify(6, "fw 6/1 noW dyn", false); }
+    if (SEL()) { run_variant2<6, 2, true, 1024>("fw 6-base 2 rep, dynamic 256", a, 512, hits, ctx_bytes, total_q, g, 256);   verify(6, "fw 6/2 dyn"); }
+    if (SEL()) { run_variant2<6, 4, true, 512>("fw 6-base 4 rep, dynamic 256", a, 512, hits, ctx_bytes, total_q, g, 256);   verify(6, "fw 6/4 dyn"); }
+    if (SEL()) { run_variant2<5, 8, true, 1024>("fw 5-base 8 rep, dynamic 256", a, 512, hits, ctx_bytes, total_q, g, 256);   verify(5, "fw 5/8 dyn"); }
+    if (SEL()) { run_variant2<6, 1, true, 512>("fw 6-base 1 rep 512 thr, dynamic 256", a, 1024, hits, ctx_bytes, total_q, g, 256);   verify(6, "fw 6/1 dyn"); }
     return 0;
 }

@@ -257,6 +257,7 @@ static void usage() {
 }
 
 int main(int argc, char** argv) {
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);  // the host's own choice, before the first HIP call: one hardware queue per engine slot
     std::vector<std::string> pos;
     for (int i = 1; i < argc; i++) {
         std::string v;

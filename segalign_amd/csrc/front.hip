@@ -412,6 +412,10 @@ uint32_t join_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, uint32_t qlen, 
         if (jc.hits >= (uint64_t)(uint32_t)g_max_hits || jc.hits > 0xFFFFFFFFull) return 0xFFFFFFFFu;
     }
     if (nvalid * words >= 0xFFFFFFFFull) return 0xFFFFFFFFu;
+    // the call was sized by the hits a chunk of RANDOM sequence collects (sa_get_chunks_per_call); repeat-rich sequence collects a
+    // multiple (lumpy stand-in: 3.3 x), and the call's lists are sized by its hits: well above the bound it is halved like any
+    // other pass that cannot hold its chunks
+    if (K > 1 && hit_base > (uint64_t)g_key_order_hits + (uint64_t)g_key_order_hits / 2) return 0xFFFFFFFFu;
     t_front_flags |= SA_PATH_KEY_ORDERED;
     return (uint32_t)(nvalid * words);
 }

@@ -42,7 +42,7 @@ int g_chain_sort_threads = 256;  // SEGALIGN_AMD_CHAIN_SORT_THREADS
 int g_chain_buckets = 0, g_chain_bucket_target = 32, g_chain_sort_blocks = 0, g_chain_group_max = 1024;
 int64_t g_call_hits_max = 1ll << 30;  // option call_hits_max
 int64_t g_call_hits = 128ll << 20;  // option call_hits: seed hits a call is sized for when the resident target's hits are sparse (0: chunks_per_call only)
-int g_key_order = 1, g_key_order_chunks = 200;  // options key_order, key_order_chunks (join.h)
+int g_key_order = 0, g_key_order_chunks = 200;  // options key_order, key_order_chunks (join.h)
 int64_t g_key_order_hits = 3ll << 30, g_key_order_min_pos = 0;  // options key_order_hits, key_order_min_pos
 int g_chunks_per_call = SA_DEFAULT_CHUNKS;  // SEGALIGN_AMD_CHUNKS_PER_CALL: chunks sa_seed_interval hands to one multi-chunk call
 int g_no_small_dedup = 0;  // SEGALIGN_AMD_NO_SMALL_DEDUP=1: always use the library sorts
@@ -112,7 +112,7 @@ static Option g_opts[] = {
     {"chunks_per_call", SA_DEFAULT_CHUNKS, 1, SA_MAX_CHUNKS, 0},  // chunks sa_seed_interval / sa_rm_mask_interval hand to one pass
     {"call_hits", 128 << 20, 0, 1ll << 31, 0},
     {"call_hits_max", 1 << 30, 0, 1ll << 32, 0},      // ... and lowered when they are dense: chunks per call <= call_hits_max / estimated hits per chunk (0: no cap)        // seed hits a call is sized for when hits are sparse: chunks per call = max(chunks_per_call, call_hits / hits per chunk)
-    {"key_order", 1, 0, 2, 0},                          // key-ordered calls (join.h): 0 never, 1 when a call holds at least ~one position per seed key and the target's hits are dense enough, 2 whenever possible (tests)
+    {"key_order", 0, 0, 2, 0},                          // key-ordered calls (join.h): 0 never (default: the streamed pass is the faster one as a whole, profiles/r05/key_order_ab.txt), 1 when a call holds at least ~one position per seed key and the target's hits are dense enough, 2 whenever possible (tests)
     {"key_order_chunks", 200, 1, SA_MAX_CHUNKS, 0},    // chunks sa_get_chunks_per_call() hands to one call when key-ordered calls are on (a call's positions per key set the record reuse)
     {"key_order_hits", 3ll << 30, 1 << 20, 1ll << 34, 0},  // ... capped so that a call stays below about this many seed hits (its lists are sized by them)
     {"key_order_min_pos", 0, 0, 1ll << 31, 0},         // positions a call must hold to go key-ordered under key_order = 1 (0: the number of seed keys)

@@ -140,6 +140,14 @@ def test_a_max_hits_split_sends_the_chunk_down_the_general_path(oracle, clean):
     c.E.set_max_hits(0)
 
 
+def test_a_call_far_above_its_hit_bound_is_halved(oracle, clean):
+    """Calls are sized by the hits random sequence would collect; a call that turns out to hold more than 1.5 x option key_order_hits
+    is halved (front.hip join_front) -- down to single chunks, which stay key-ordered -- with the same vectors."""
+    t, q = synth.make_pair(300000, 33, 34, sub_rate=0.08, mask_frac=0.1, records=2, indel_every=500)
+    c, total = check_case(oracle, clean, t, q, 20000, env={"SEGALIGN_AMD_KEY_ORDER_HITS": str(1 << 20)})  # ~1.5 M hits per chunk: every multi-chunk pass splits
+    assert total > 100
+
+
 def test_list_regrowth_reruns_the_key_ordered_filter(oracle, clean):
     t, q = synth.make_pair(200000, 71, 72, sub_rate=0.08, mask_frac=0.1, records=2, indel_every=500)
     c, total = check_case(oracle, clean, t, q, 12000, env={"SEGALIGN_AMD_L2_CAP": "1024"})

@@ -83,6 +83,7 @@ def parse():
     ap.add_argument("--target-fasta", default=None, help="real target FASTA (e.g. ce11.fa[.gz]); first 500 Mbp block is used")
     ap.add_argument("--query-fasta", default=None, help="real query FASTA (e.g. cb4.fa[.gz]); first 500 Mbp block is used")
     ap.add_argument("--target-mbp", type=float, default=None, help="synthetic target size (default per workload)")
+    ap.add_argument("--query-mbp", type=float, default=None, help="human workload: query block size (default 100; the reference's block is 500)")
     ap.add_argument("--interval", type=int, default=10_000_000)
     ap.add_argument("--chunk", type=int, default=250_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -164,26 +165,13 @@ def make_workload(args, rank=0):
                     label="plumbing case (BASELINE configs[0]): 1 Mbp uniform target x 15%-substituted copy with sparse indels")
     # human: one 500 Mbp target block (4 records) of a 24 x 125 Mbp genome, and a 100 Mbp query block made of 1-10 Mbp pieces
     # of the same block, 1.2 % diverged, shuffled, every third piece inverted; own pair per rank
+    # (synth.human_block_pair: tools/human_grid.py walks a grid of such blocks)
     tlen = int((args.target_mbp or 500.0) * 1e6)
-    t = synth.random_dna(tlen, 5 + 100 * rank)
-    t = synth.soft_mask(t, 6 + 100 * rank, 0.3, 200, 2000)
-    per = tlen // 4
-    target = synth.join_records([t[i * per:(i + 1) * per] for i in range(4)])
-    del t
-    rng = np.random.default_rng(7 + rank)
-    pieces, total, i = [], 0, 0
-    qlen = min(100_000_000, tlen // 2)
-    while total < qlen:
-        n = int(rng.integers(1_000_000, 10_000_001))
-        n = min(n, qlen - total)
-        p = int(rng.integers(0, target.size - n))
-        seg = synth.mutate(target[p:p + n], 1000 + i + 100 * rank, 0.012)
-        pieces.append(synth.reverse_complement(seg) if i % 3 == 0 else seg)
-        total += n
-        i += 1
-    return dict(target=target, query=np.concatenate(pieces), transition=True, rm=False, data="synthetic",
+    qlen = int(args.query_mbp * 1e6) if args.query_mbp else min(100_000_000, tlen // 2)
+    target, query = synth.human_block_pair(tlen, qlen, rank)
+    return dict(target=target, query=query, transition=True, rm=False, data="synthetic",
                 label="human-scale block pair (BASELINE configs[2]): %.0f Mbp 4-record target block x %.0f Mbp query block of "
-                      "1.2%%-diverged shuffled 1-10 Mbp pieces, 12of19 + transitions" % (tlen / 1e6, total / 1e6))
+                      "1.2%%-diverged shuffled 1-10 Mbp pieces, 12of19 + transitions" % (tlen / 1e6, query.size / 1e6))
 
 
 CHECK_MOD = 1 << 55  # HSP checksums are summed modulo this (8 ranks x 2^55 fits the int64 all_reduce)
@@ -415,7 +403,9 @@ def main():
         # (the calls of interval 0 alone: a hit-sized call of the whole pass may span several intervals)
         first = shard.call_jobs(intervals[:1], q_block_len, args.chunk, E.lib().sa_get_chunks_per_call()) if not wl["rm"] else jobs[:1]
         res = [run_job(j) for j in first]
-        print(json.dumps({"one_interval": True, "bases": sum(r[0] for r in res), "hsps": sum(r[1] for r in res), "workload": args.workload}))
+        print(json.dumps({"one_interval": True, "bases": sum(r[0] for r in res), "hsps": sum(r[1] for r in res), "workload": args.workload,
+                          "hsp_checksum": sum(r[2] for r in res) % CHECK_MOD,
+                          "calls": [[j["a"], j["b"], bool(j["rev"]), j["chunks"]] for j in first] if not wl["rm"] else None}))
         E.ShutdownProcessor()
         return
 

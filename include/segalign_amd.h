@@ -314,6 +314,13 @@ size_t sa_device_make_seeds(uint32_t start, uint32_t end, int rev, uint32_t buff
  * run of anchors may already be merged).  Used to check the extension kernels against golden vectors. */
 size_t sa_extend_hits(const uint32_t* ref_query_pairs, size_t num_hits, int rev, uint32_t buffer, sa_segment_pair** out);
 
+/* Test entry: the ordering stage alone on `n` records as ONE dedup scope -- stable_sort(hspComp) -> unique_copy(hspEqual) ->
+ * stable_sort(hspCompLastz), src/seed_filter.cu:47-108,776-782; rm != 0: the repeat masker's five-step chain,
+ * repeat_masker_src/seed_filter.cu:45-135,819-831.  path 0 = the engine's per-segment LDS chain (rm == 0, n <= 2048), path 1 = its
+ * library-sort chain.  *out is malloc'ed (sa_free_segments); returns the number of records kept.  Held against rocThrust's own
+ * stable_sort / unique_copy in tests/test_gpu_thrust_order.py (hazard H3: unique_copy = head flags on adjacent INPUT pairs). */
+size_t sa_order_hsps(const sa_segment_pair* in, size_t n, int rm, int path, sa_segment_pair** out);
+
 const char* sa_version(void);
 
 #ifdef __cplusplus

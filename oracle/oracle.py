@@ -26,7 +26,7 @@ def build(with_ref=True):
 class _ExtendParams(C.Structure):
     _fields_ = [("ref", C.c_void_p), ("query", C.c_void_p), ("ref_len", C.c_uint32), ("query_len", C.c_uint32),
                 ("sub_mat", C.c_void_p), ("xdrop", C.c_int), ("hspthresh", C.c_int), ("noentropy", C.c_int),
-                ("log4_is_float", C.c_int)]
+                ("log4_is_float", C.c_int), ("entropy_ulps", C.c_int)]
 
 
 class _SafStats(C.Structure):
@@ -65,6 +65,12 @@ def lib():
         L.orc_seed_and_filter_rm.restype = C.c_size_t
         L.orc_seed_and_filter_rm.argtypes = [C.POINTER(_SafParams), C.c_void_p, C.c_size_t, C.c_int, C.c_uint32,
                                              C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(_SafStats)]
+        L.orc_seed_and_filter_traced.restype = C.c_size_t
+        L.orc_seed_and_filter_traced.argtypes = [C.POINTER(_SafParams), C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
+                                                 C.POINTER(C.c_void_p), C.POINTER(_SafStats), C.c_void_p]
+        L.orc_stage_trace_free.argtypes = [C.c_void_p]
+        L.orc_order_hsps.restype = C.c_size_t
+        L.orc_order_hsps.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
         L.orc_free.argtypes = [C.c_void_p]
         L.orc_rm_coverage_intervals.restype = C.c_size_t
         L.orc_rm_coverage_intervals.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
@@ -154,7 +160,7 @@ def make_seeds(qbuf, q_block_start, i, e, seed_size, kmer_size, transition):
     return out[:n].copy()
 
 
-def _ext_params(ref_codes, query_codes, sub_mat, xdrop, hspthresh, noentropy, log4_is_float=True):
+def _ext_params(ref_codes, query_codes, sub_mat, xdrop, hspthresh, noentropy, log4_is_float=True, entropy_ulps=0):
     p = _ExtendParams()
     p.ref = ref_codes.ctypes.data
     p.query = query_codes.ctypes.data
@@ -162,6 +168,7 @@ def _ext_params(ref_codes, query_codes, sub_mat, xdrop, hspthresh, noentropy, lo
     p.query_len = query_codes.size
     p.sub_mat = sub_mat.ctypes.data
     p.xdrop, p.hspthresh, p.noentropy, p.log4_is_float = xdrop, hspthresh, int(noentropy), int(log4_is_float)
+    p.entropy_ulps = int(entropy_ulps)
     return p
 
 
@@ -181,13 +188,13 @@ def extend_hit(ref_codes, query_codes, sub_mat, ref_loc, query_loc, xdrop=910, h
     return bool(ok), tuple(int(x) for x in out[0]), ex.value
 
 
-def extend_hits_pass(ref_codes, query_codes, sub_mat, pairs, xdrop=910, hspthresh=3000, noentropy=False, log4_is_float=True):
+def extend_hits_pass(ref_codes, query_codes, sub_mat, pairs, xdrop=910, hspthresh=3000, noentropy=False, log4_is_float=True, entropy_ulps=0):
     """orc_extend_hit over many anchors (pairs[:, 0] = ref_loc, pairs[:, 1] = query_loc): bool array 'the hit passes' and the
     records.  One parameter block for the whole batch (the per-call wrapper above rebuilds it every time)."""
     ref_codes = np.ascontiguousarray(ref_codes, np.uint8)
     query_codes = np.ascontiguousarray(query_codes, np.uint8)
     sub_mat = np.ascontiguousarray(sub_mat, np.int32)
-    p = _ext_params(ref_codes, query_codes, sub_mat, xdrop, hspthresh, noentropy, log4_is_float)
+    p = _ext_params(ref_codes, query_codes, sub_mat, xdrop, hspthresh, noentropy, log4_is_float, entropy_ulps)
     pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
     ok = np.zeros(pairs.shape[0], dtype=bool)
     out = np.zeros(pairs.shape[0], dtype=SEG_DTYPE)
@@ -231,6 +238,54 @@ def seed_and_filter(ref_codes, query_codes, index_table, pos_table, seeds, sub_m
     stats = dict(num_hits=st.num_hits, num_survivors=st.num_survivors, num_examined=st.num_examined,
                  num_iter=st.num_iter)
     return segs, stats
+
+
+class _StageTrace(C.Structure):
+    _fields_ = [("hits", C.c_void_p), ("ext", C.c_void_p), ("done", C.c_void_p), ("reduced", C.c_void_p),
+                ("n_hits", C.c_size_t), ("n_ext", C.c_size_t), ("n_reduced", C.c_size_t),
+                ("cap_hits", C.c_size_t), ("cap_ext", C.c_size_t), ("cap_reduced", C.c_size_t)]
+
+
+def seed_and_filter_traced(ref_codes, query_codes, index_table, pos_table, seeds, sub_mat, seed_size=19, xdrop=910, hspthresh=3000,
+                           noentropy=False, max_hits=1 << 30, rm=None):
+    """seed_and_filter with its intermediate lists (orc_seed_and_filter_traced) -> (segments, dict(hits, ext, done, reduced)):
+    the hit list as find_hits leaves it, records + done flags as find_hsps leaves them, the list compress_output writes."""
+    ref_codes = np.ascontiguousarray(ref_codes, np.uint8)
+    query_codes = np.ascontiguousarray(query_codes, np.uint8)
+    index_table = np.ascontiguousarray(index_table, np.uint32)
+    pos_table = np.ascontiguousarray(pos_table, np.uint32)
+    seeds = np.ascontiguousarray(seeds, np.uint64)
+    sub_mat = np.ascontiguousarray(sub_mat, np.int32)
+    p = _SafParams()
+    p.ext = _ext_params(ref_codes, query_codes, sub_mat, xdrop, hspthresh, noentropy, True)
+    p.index_table = index_table.ctypes.data
+    p.pos_table = pos_table.ctypes.data if pos_table.size else None
+    p.seed_size = seed_size
+    p.max_hits = max_hits
+    p.num_threads = 1
+    out = C.c_void_p()
+    st = _SafStats()
+    tr = _StageTrace()
+    rev, rs, re_ = rm if rm is not None else (0, 0, 0)
+    n = lib().orc_seed_and_filter_traced(C.byref(p), seeds.ctypes.data, seeds.size, int(rm is not None), int(rev), rs, re_, C.byref(out),
+                                         C.byref(st), C.byref(tr))
+    segs = np.frombuffer((C.c_char * (n * SEG_DTYPE.itemsize)).from_address(out.value), dtype=SEG_DTYPE).copy()
+    lib().orc_free(out)
+
+    def arr(ptr, k, dt):
+        return np.frombuffer((C.c_char * (k * dt.itemsize)).from_address(ptr), dtype=dt).copy() if k else np.zeros(0, dtype=dt)
+    res = dict(hits=arr(tr.hits, tr.n_hits, SEG_DTYPE), ext=arr(tr.ext, tr.n_ext, SEG_DTYPE),
+               done=arr(tr.done, tr.n_ext, np.dtype(np.uint8)), reduced=arr(tr.reduced, tr.n_reduced, SEG_DTYPE))
+    lib().orc_stage_trace_free(C.byref(tr))
+    return segs, res
+
+
+def order_hsps(records, rm=False):
+    """the ordering chain alone (orc_order_hsps): stable sort -> adjacent-pair unique -> stable sort on one dedup scope"""
+    h = np.ascontiguousarray(records, dtype=SEG_DTYPE)
+    out = C.c_void_p()
+    n = lib().orc_order_hsps(h.ctypes.data if h.size else None, h.size, int(bool(rm)), C.byref(out))
+    return _take(n, out, SEG_DTYPE)
 
 
 IVL_DTYPE = np.dtype([("query_start", "<u4"), ("len", "<u4")])

@@ -311,6 +311,8 @@ static int finish_hit(const orc_extend_params* p, uint32_t ref_loc, uint32_t que
             }
             double div = p->log4_is_float ? (double)logf(4.0f) : log(4.0); /* :623, hazard H2 */
             entropy = -entropy / div;
+            for (int u = 0; u < p->entropy_ulps; u++) entropy = nextafter(entropy, 2.0);   /* H13 probe, 0 by default */
+            for (int u = 0; u > p->entropy_ulps; u--) entropy = nextafter(entropy, -1.0);
         }
     }
     if (f64_to_i32_gpu(((float)total) * entropy) >= p->hspthresh) { /* :633 */
@@ -534,8 +536,24 @@ void orc_free(void* p) { free(p); }
 /* =====================================================================================================
  * SeedAndFilter -- src/seed_filter.cu:682-828 (rm = 0) / repeat_masker_src/seed_filter.cu:724-876 (rm = 1)
  * ===================================================================================================== */
+/* Stage trace (tests only: tests/test_oracle_rm_golden.py holds the oracle's intermediate lists against the reference kernels'
+ * own text executed under SIMT emulation): when a trace is attached, every iteration appends its hit list as find_hits leaves it
+ * (score 0 / -1 = the repeat masker's window flag), the records and done flags as find_hsps leaves them, and the compacted
+ * list as compress_output leaves it (rc flip included).  The concatenation over the iterations is what ONE launch over all the
+ * seeds gives: slot order and per-hit results do not depend on the iteration split. */
+static void trace_append(orc_segment** dst, size_t* n, size_t* cap, const orc_segment* src, size_t k) {
+    if (*n + k > *cap) { *cap = (*n + k) * 2 + 16; *dst = (orc_segment*)realloc(*dst, *cap * sizeof(orc_segment)); }
+    memcpy(*dst + *n, src, k * sizeof(orc_segment));
+    *n += k;
+}
+static size_t saf_impl_traced(const orc_saf_params* p, const uint64_t* seeds, size_t num_seeds_sz, int rm, int rev,
+                       uint32_t win_start, uint32_t win_end, orc_segment** out_vec, orc_saf_stats* stats, orc_stage_trace* tr);
 static size_t saf_impl(const orc_saf_params* p, const uint64_t* seeds, size_t num_seeds_sz, int rm, int rev,
                        uint32_t win_start, uint32_t win_end, orc_segment** out_vec, orc_saf_stats* stats) {
+    return saf_impl_traced(p, seeds, num_seeds_sz, rm, rev, win_start, win_end, out_vec, stats, NULL);
+}
+static size_t saf_impl_traced(const orc_saf_params* p, const uint64_t* seeds, size_t num_seeds_sz, int rm, int rev,
+                       uint32_t win_start, uint32_t win_end, orc_segment** out_vec, orc_saf_stats* stats, orc_stage_trace* tr) {
     uint32_t num_seeds = (uint32_t)num_seeds_sz;
     uint64_t num_hits = 0, total_anchors = 0, examined = 0, survivors = 0;
     orc_segment* result = (orc_segment*)malloc(sizeof(orc_segment));
@@ -605,6 +623,7 @@ static size_t saf_impl(const orc_saf_params* p, const uint64_t* seeds, size_t nu
                             hsp[slot].score = -1; /* rm :239-244 */
                     }
                 }
+                if (tr) { size_t c0 = tr->cap_hits; trace_append(&tr->hits, &tr->n_hits, &c0, hsp, (size_t)iter_num_hits); tr->cap_hits = c0; }
                 /* find_hsps :232-652 ; done flags */
                 uint8_t* done = (uint8_t*)malloc((size_t)iter_num_hits);
                 uint64_t ex_local = 0;
@@ -624,6 +643,13 @@ static size_t saf_impl(const orc_saf_params* p, const uint64_t* seeds, size_t nu
                     ex_local += ex;
                 }
                 examined += ex_local;
+                if (tr) {
+                    size_t c0 = tr->cap_ext, n0 = tr->n_ext;
+                    trace_append(&tr->ext, &tr->n_ext, &c0, hsp, (size_t)iter_num_hits);
+                    tr->cap_ext = c0;
+                    tr->done = (uint8_t*)realloc(tr->done, tr->n_ext + 1);
+                    memcpy(tr->done + n0, done, (size_t)iter_num_hits);
+                }
                 /* inclusive_scan(done) :769 + compress_output :654-680 = order-preserving compaction */
                 size_t na = 0;
 #ifdef _OPENMP
@@ -642,6 +668,7 @@ static size_t saf_impl(const orc_saf_params* p, const uint64_t* seeds, size_t nu
                                 red[k].query_start = p->ext.ref_len - 1 - (red[k].query_start + red[k].len);
                             k++;
                         }
+                    if (tr) { size_t c0 = tr->cap_reduced; trace_append(&tr->reduced, &tr->n_reduced, &c0, red, na); tr->cap_reduced = c0; }
                     size_t nu;
                     orc_segment* fin;
                     if (!rm) {
@@ -703,6 +730,42 @@ size_t orc_seed_and_filter(const orc_saf_params* p, const uint64_t* seeds, size_
 size_t orc_seed_and_filter_rm(const orc_saf_params* p, const uint64_t* seeds, size_t num_seeds, int rev,
                               uint32_t ref_start, uint32_t ref_end, orc_segment** out_vec, orc_saf_stats* stats) {
     return saf_impl(p, seeds, num_seeds, 1, rev, ref_start, ref_end, out_vec, stats);
+}
+
+/* the ordering chain alone on one dedup scope (tests/test_gpu_thrust_order.py): :776-782, or rm :819-831 */
+size_t orc_order_hsps(const orc_segment* in, size_t n, int rm, orc_segment** out) {
+    orc_segment* red = (orc_segment*)malloc((n + 1) * sizeof(orc_segment));
+    orc_segment* uni = (orc_segment*)malloc((n + 1) * sizeof(orc_segment));
+    memcpy(red, in, n * sizeof(orc_segment));
+    size_t nu;
+    orc_segment* fin;
+    if (!rm) {
+        stable_sort_seg(red, n, hsp_comp);
+        nu = unique_adjacent(red, n, uni, hsp_equal);
+        stable_sort_seg(uni, nu, hsp_comp_lastz);
+        fin = uni;
+        free(red);
+    } else {
+        stable_sort_seg(red, n, rm_hsp_comp);
+        nu = unique_adjacent(red, n, uni, rm_hsp_equal);
+        stable_sort_seg(uni, nu, rm_diag_comp);
+        nu = unique_adjacent(uni, nu, red, hsp_equal);
+        stable_sort_seg(red, nu, rm_final_comp);
+        fin = red;
+        free(uni);
+    }
+    *out = fin;
+    return nu;
+}
+
+size_t orc_seed_and_filter_traced(const orc_saf_params* p, const uint64_t* seeds, size_t num_seeds, int rm, int rev, uint32_t ref_start,
+                                  uint32_t ref_end, orc_segment** out_vec, orc_saf_stats* stats, orc_stage_trace* tr) {
+    memset(tr, 0, sizeof(*tr));
+    return saf_impl_traced(p, seeds, num_seeds, rm, rev, ref_start, ref_end, out_vec, stats, tr);
+}
+void orc_stage_trace_free(orc_stage_trace* tr) {
+    free(tr->hits); free(tr->ext); free(tr->done); free(tr->reduced);
+    memset(tr, 0, sizeof(*tr));
 }
 
 /* ---- repeat masker: coverage counting and run extraction (repeat_masker_src/seeder.cpp:57-58,153-188) ------------- */

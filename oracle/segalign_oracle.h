@@ -81,6 +81,7 @@ typedef struct {
     int hspthresh;
     int noentropy;
     int log4_is_float; /* 1 = divisor is (double)logf(4.0f) as written at seed_filter.cu:623 (default) */
+    int entropy_ulps;  /* tests (hazard H13): the entropy factor moved by this many ulps (nextafter) before :633/:637 use it */
 } orc_extend_params;
 
 /* Returns 1 if the hit passes (d_done = 1) and fills *out; 0 otherwise (out = zeroed record as at :641-647).
@@ -118,6 +119,20 @@ size_t orc_seed_and_filter(const orc_saf_params* p, const uint64_t* seeds, size_
  * encoded reverse complement (rev=1); ext.query_len == ext.ref_len. */
 size_t orc_seed_and_filter_rm(const orc_saf_params* p, const uint64_t* seeds, size_t num_seeds, int rev,
                               uint32_t ref_start, uint32_t ref_end, orc_segment** out_vec, orc_saf_stats* stats);
+
+/* The same calls with their intermediate lists kept (tests/test_oracle_rm_golden.py): hits = the hit list as find_hits leaves it
+ * (score 0, or -1 outside the repeat masker's target window), ext/done = records and flags as find_hsps leaves them, reduced = the
+ * compacted list as compress_output leaves it; each concatenated over the call's iterations.  rm = 0: src/, rm = 1: repeat masker. */
+typedef struct {
+    orc_segment* hits; orc_segment* ext; uint8_t* done; orc_segment* reduced;
+    size_t n_hits, n_ext, n_reduced, cap_hits, cap_ext, cap_reduced;
+} orc_stage_trace;
+size_t orc_seed_and_filter_traced(const orc_saf_params* p, const uint64_t* seeds, size_t num_seeds, int rm, int rev, uint32_t ref_start,
+                                  uint32_t ref_end, orc_segment** out_vec, orc_saf_stats* stats, orc_stage_trace* tr);
+void orc_stage_trace_free(orc_stage_trace* tr);
+/* The ordering chain alone on `n` records as one dedup scope: src/seed_filter.cu:776-782 (rm = 0) or
+ * repeat_masker_src/seed_filter.cu:819-831 (rm = 1).  *out is malloc'ed (orc_free); returns the records kept. */
+size_t orc_order_hsps(const orc_segment* in, size_t n, int rm, orc_segment** out);
 
 /* repeat-masker post-processing, repeat_masker_src/seeder.cpp:153-188: per-position uint8_t coverage counters
  * incremented over query_start .. query_start+len-1 of every HSP, then runs with count >= M (a run still open at the

@@ -420,6 +420,7 @@ extern uint32_t g_wga_chunk;
 extern uint32_t g_seed_size;
 extern int g_sub_mat[64];
 extern int g_xdrop, g_hspthresh, g_noentropy;
+extern int g_log4_double, g_entropy_ulps;  // options log4_double (H2), entropy_ulps (H13, tests)
 extern int64_t g_max_seeds;
 extern int64_t g_max_hits;
 extern bool g_max_hits_overridden;

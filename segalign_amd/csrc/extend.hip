@@ -1893,8 +1893,11 @@ __global__ __launch_bounds__(EXT_THREADS) void extend_entropy_kernel(ExtendArgs 
                 h += ((double)s1) / len1 * ((s1 != 0) ? log(((double)s1) / len1) : 0.0);
                 h += ((double)s2) / len1 * ((s2 != 0) ? log(((double)s2) / len1) : 0.0);
                 h += ((double)s3) / len1 * ((s3 != 0) ? log(((double)s3) / len1) : 0.0);
-                // :623 divides by log(4.0f): the FLOAT overload, i.e. (double)0x3FB17218 (hazard H2)
-                entropy = -h / (double)1.38629436492919921875f;
+                // :623 divides by log(4.0f): the FLOAT overload, i.e. (double)0x3FB17218 (hazard H2); option log4_double: log(4.0)
+                entropy = -h / (a.log4_double ? 1.3862943611198906 : (double)1.38629436492919921875f);
+                // (tests, hazard H13: device log() against the host's -- how far is any verdict or score from flipping?)
+                for (int u = 0; u < a.entropy_ulps; u++) entropy = nextafter(entropy, 2.0);
+                for (int u = 0; u > a.entropy_ulps; u--) entropy = nextafter(entropy, -1.0);
             }
             pass = f64_to_i32(((double)(float)e.total) * entropy) >= a.hspthresh;  // :633
             int sc = 0;

@@ -106,6 +106,8 @@ struct ExtendArgs {
     int xdrop;
     int hspthresh;
     int noentropy;
+    int log4_double;          // entropy divisor: 0 = (double)logf(4.0f), what the reference's `log(4.0f)` is under nvcc (hazard H2); 1 = log(4.0)
+    int entropy_ulps;         // tests (hazard H13): the entropy factor moved by this many ulps (nextafter) before it is used
     int fin_batch;            // finished lanes a wave accumulates before it finalises + refills them
     int bufs_per_wave;        // launch heuristic: 64-hit buffers each wave should own at least
     uint32_t long_cap;        // bases per side the filter walks before it forwards the hit to the exact kernel

@@ -35,7 +35,7 @@ C_ABI_SYMBOLS = [
     "sa_get_num_index", "sa_get_index_table_size", "sa_copy_ref_codes", "sa_copy_index_table", "sa_copy_pos_table",
     "sa_copy_query_codes", "sa_get_query_len", "sa_device_make_seeds", "sa_version",
     "sa_rm_mask_interval", "sa_rm_coverage_intervals", "sa_free_intervals", "sa_get_filter_mode",
-    "sa_seed_interval", "sa_seed_and_filter_chunks", "sa_max_chunks_per_call", "sa_get_chunks_per_call", "sa_extend_hits",
+    "sa_seed_interval", "sa_seed_and_filter_chunks", "sa_max_chunks_per_call", "sa_get_chunks_per_call", "sa_extend_hits", "sa_order_hsps",
     "sa_get_lookup_mode", "sa_get_neighbourhood_entries",
     "sa_seed_calls", "sa_count_call_hits", "sa_count_chunk_hits", "sa_get_wga_chunk", "sa_release_arena", "sa_set_option", "sa_reset_option", "sa_get_option", "sa_option_count", "sa_option_name", "sa_get_audit",
 ]
@@ -115,6 +115,8 @@ def lib():
     L.sa_copy_query_codes.argtypes = [C.c_int, C.c_uint32, C.c_int, C.c_void_p]
     L.sa_device_make_seeds.restype = C.c_size_t
     L.sa_device_make_seeds.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t]
+    L.sa_order_hsps.restype = C.c_size_t
+    L.sa_order_hsps.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.sa_extend_hits.restype = C.c_size_t
     L.sa_extend_hits.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]
     L.sa_get_neighbourhood_entries.restype = C.c_uint64
@@ -288,6 +290,18 @@ def SeedCalls(calls, buffer=0, threads=4, hits_out=None, devices_out=None):
     if devices_out is not None:
         devices_out.extend(int(res[i].device) for i in range(n))
     return outs, {k: getattr(st, k) for k, _ in CallStats._fields_}
+
+
+def OrderHsps(records, rm=False, path=1):
+    """The ordering stage alone on `records` (SEG_DTYPE) as one dedup scope: sort -> adjacent-pair unique -> sort (sa_order_hsps)."""
+    h = np.ascontiguousarray(records, dtype=SEG_DTYPE)
+    out = C.c_void_p()
+    n = lib().sa_order_hsps(h.ctypes.data if h.size else None, h.size, int(bool(rm)), int(path), C.byref(out))
+    if not out.value:
+        return np.zeros(0, dtype=SEG_DTYPE)
+    res = np.frombuffer((C.c_char * (n * SEG_DTYPE.itemsize)).from_address(out.value), dtype=SEG_DTYPE).copy() if n else np.zeros(0, dtype=SEG_DTYPE)
+    lib().sa_free_segments(out)
+    return res
 
 
 def ExtendHits(hits, rev, buffer):

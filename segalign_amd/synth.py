@@ -295,3 +295,34 @@ def make_realistic(target_len, seed_t=11, seed_q=12, records=7, repeat_frac=0.12
         t_recs.append(t)
         q_recs.append(q)
     return join_records(t_recs), join_records(q_recs)
+
+
+def human_target_block(tlen, idx):
+    """One target block of the human-scale stand-in (BASELINE configs[2]): `tlen` bases of uniform DNA, 30 % in soft-masked runs of
+    0.2-2 kb, as 4 records; block `idx` of a genome (its own random stream)."""
+    t = random_dna(tlen, 5 + 100 * idx)
+    t = soft_mask(t, 6 + 100 * idx, 0.3, 200, 2000)
+    per = tlen // 4
+    return join_records([t[i * per:(i + 1) * per] for i in range(4)])
+
+
+def human_query_block(target, qlen, idx):
+    """The query block that goes with target block `idx`: 1-10 Mbp pieces of it, 1.2 % diverged, shuffled, every third piece
+    inverted, `qlen` bases in all."""
+    import numpy as np
+    rng = np.random.default_rng(7 + idx)
+    pieces, total, i = [], 0, 0
+    while total < qlen:
+        n = int(rng.integers(1_000_000, 10_000_001))
+        n = min(n, qlen - total)
+        p = int(rng.integers(0, target.size - n))
+        seg = mutate(target[p:p + n], 1000 + i + 100 * idx, 0.012)
+        pieces.append(reverse_complement(seg) if i % 3 == 0 else seg)
+        total += n
+        i += 1
+    return np.concatenate(pieces)
+
+
+def human_block_pair(tlen, qlen, idx=0):
+    target = human_target_block(tlen, idx)
+    return target, human_query_block(target, qlen, idx)

@@ -119,6 +119,54 @@ def test_multi_chunk_calls_bit_exact_vs_oracle_at_full_size(full):
     assert st["num_hits"] == hits and hits > 400_000_000 and fw.size + rc.size > 500
 
 
+def test_the_bench_default_calls_bit_exact_vs_oracle_and_its_checksum(full):
+    """What bench.py times, at the size and grouping it times it: interval 0 of the pass, both strands, through sa_seed_calls at the
+    DEFAULT grouping (sa_get_chunks_per_call: two forty-chunk calls of ~520 M hits = 80 reference iterations each), every one of the
+    80 chunks against the oracle; then the same interval through `bench.py --one-interval` in a process of its own: same calls,
+    same HSP count, and a checksum equal to shard.hsp_checksum over the ORACLE's records -- the number an N-GPU run is verified by,
+    pinned to the CPU restatement at workload size."""
+    import json
+    import os
+    import subprocess
+    import sys
+    E, O, query = full["E"], full["O"], full["query"]
+    index, pos = E.copy_index_table(), E.copy_pos_table()
+    rcodes = E.copy_ref_codes()
+    qlen = query.size - 19
+    cpc = E.lib().sa_get_chunks_per_call()
+    assert cpc == 40
+    iv0 = shard.plan_intervals(query.size, 19, 10_000_000)[0]
+    jobs = shard.call_jobs([iv0], qlen, 250000, cpc)
+    assert [(j["chunks"], j["rev"]) for j in jobs] == [(40, False), (40, True)]
+    hits = []
+    outs, st = E.SeedCalls([(j["a"], j["b"], j["rev"]) for j in jobs], 0, 2, hits_out=hits)
+    chk_oracle = chk_engine = n_hsps = 0
+    for j, got in zip(jobs, outs):
+        rev = j["rev"]
+        qcodes = E.copy_query_codes(0, rev)
+        buf = query if not rev else np.frombuffer(O.rev_comp_ascii(query.tobytes(), 0, query.size), dtype=np.uint8)
+        want, o_hits = [], 0
+        for a in range(j["a"], j["b"], 250000):
+            seeds = O.make_seeds(buf.tobytes(), 0, a, min(a + 250000, j["b"]), 19, full["k"], True)
+            w, ost = O.seed_and_filter(rcodes, qcodes, index, pos, seeds, full["sub_mat"])
+            want.append(w[1:])
+            o_hits += ost["num_hits"]
+        want = np.concatenate(want)
+        assert got.shape == want.shape and np.all(got == want), rev
+        assert o_hits == hits[len(hits) - len(jobs) + jobs.index(j)] and o_hits > 400_000_000
+        chk_oracle += shard.hsp_checksum(want, rev)
+        chk_engine += shard.hsp_checksum(got, rev)
+        n_hsps += int(want.size)
+    assert n_hsps > 500 and chk_engine == chk_oracle
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--one-interval", "--no-cpu-baseline", "--no-dropin"], cwd=root,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["calls"] == [[j["a"], j["b"], bool(j["rev"]), j["chunks"]] for j in jobs]
+    assert line["hsps"] == n_hsps and line["hsp_checksum"] == chk_oracle % (1 << 55)
+
+
 # ---- BASELINE configs[3]: repeat-masker path on the same 100 Mbp target (self-alignment, neighbor_proportion 0.2, M 1) ----
 @pytest.fixture(scope="module")
 def full_rm(full):

@@ -1,0 +1,53 @@
+"""GPU: sa_rm_seed_and_filter on the inputs of tests/golden/rm_golden.json gives the vector the reference's own repeat-masker device
+code (under SIMT emulation) + comparators lead to: header (rm :857-861) and every record of `final`; and every record the engine
+returns is one compress_output wrote (`reduced`: window flag, skip and reverse-strand flip already applied by reference text)."""
+import numpy as np
+import pytest
+
+import rm_golden as G
+from helpers import Case
+
+pytestmark = pytest.mark.gpu
+
+CASES = list(G.cases())
+
+
+@pytest.fixture
+def clean(engine):
+    yield engine
+    engine.RmClearQuery()
+    engine.ShutdownProcessor()
+    engine.reset_option(None)
+
+
+@pytest.mark.parametrize("mode", ["default", "general path"])
+def test_engine_equals_the_emulated_reference_on_the_golden_inputs(oracle, clean, mode):
+    E, O = clean, oracle
+    done = 0
+    for seed in sorted({c["seed"] for c in CASES}):
+        group = [c for c in CASES if c["seed"] == seed]
+        for (hspthresh, noentropy) in sorted({(c["hspthresh"], c["noentropy"]) for c in group}):
+            E.reset_option(None)
+            if mode == "general path":
+                E.set_option("no_td", 1)
+            t = group[0]["target"]
+            case = Case(t, t, chunk=250000, hspthresh=hspthresh, noentropy=bool(noentropy), sub_mat=group[0]["sub_mat"]).oracle_setup(O).engine_setup(E)
+            E.RmSendQueryWriteRequest()
+            rc_ascii = O.rev_comp_ascii(t.tobytes(), 0, t.size)
+            for c in group:
+                if (c["hspthresh"], c["noentropy"]) != (hspthresh, noentropy):
+                    continue
+                buf = rc_ascii if c["rev"] else t.tobytes()
+                seeds = O.make_seeds(buf, 0, c["start"], c["end"], 19, case.kmer_size, True)
+                got = E.RmSeedAndFilter(seeds, c["rev"], c["win_start"], c["win_end"])
+                n_hits = int(got[0]["ref_start"]) | (int(got[0]["query_start"]) << 32)
+                assert n_hits == c["hits"].size and int(got[0]["len"]) == c["final"].size
+                body = got[1:]
+                for f in ("ref_start", "query_start", "len", "score"):
+                    assert np.array_equal(body[f], c["final"][f]), (G.case_id(c), f)
+                red = {tuple(int(x) for x in r) for r in c["reduced"].tolist()}
+                assert all(tuple(int(x) for x in r) in red for r in body.tolist())
+                done += 1
+            E.RmClearQuery()
+            E.ShutdownProcessor()
+    assert done == len(CASES)

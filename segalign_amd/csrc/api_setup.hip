@@ -217,8 +217,9 @@ static void release_device_state(DevCtx* dc) {
     // (the table arena stays mapped: it is a process-wide cache of cleared device pages that cost seconds to get; its background
     //  worker is stopped here.  Option arena_gb = 0 gives the pages back now, sa_release_arena() whenever the host wants them)
     if (g_arena_gb == 0) { arena_destroy(dc->arena); arena_destroy(dc->work_arena); }
-    dev_free(dc->bucket_start, "d_index_table");
-    dev_free(dc->pos_table, "d_pos_table");
+    dc->keep_bucket.release("d_index_table");
+    dc->keep_pos.release("d_pos_table");
+    dc->keep_nbr_start.release("nbr_start");
     dc->bucket_start = dc->pos_table = nullptr;
     dc->num_index = 0;
     for (int b = 0; b < SA_BUFFER_DEPTH; b++) {
@@ -303,9 +304,7 @@ void sa_clear_ref(void) {  // seed_filter_interface.cu:103-113
         dc->ref2.release("d_ref_seq 2-bit");
         dc->ref_host_ptr = nullptr;
         nbr_release(dc);
-        dev_free(dc->bucket_start, "d_index_table");
-        dev_free(dc->pos_table, "d_pos_table");
-        dc->bucket_start = dc->pos_table = nullptr;
+        dc->bucket_start = dc->pos_table = nullptr;  // (the tables are forgotten; their memory stays for the next block: keep_bucket, keep_pos)
         dc->num_index = 0;
     }
 }
@@ -365,23 +364,45 @@ void sa_generate_seed_pos_table(const char* ref_str, size_t start_addr, uint32_t
             codes = tmp_codes.codes;
         }
         nbr_release(dc);
-        dev_free(dc->bucket_start, "d_index_table");
-        dev_free(dc->pos_table, "d_pos_table");
-        dc->bucket_start = (uint32_t*)dev_malloc(((size_t)nkeys + 1) * sizeof(uint32_t), "index_table");
+        dc->pos_table = nullptr;
+        dc->keep_bucket.ensure((size_t)nkeys + 1, "index_table");
+        dc->bucket_start = dc->keep_bucket.p;
         uint32_t num_index = 0;
         bool built = false;
+        // Scratch of the build.  A 500 Mbp block needs ~10 GB of it (keys, four pair arrays); from hipMalloc every block paid
+        // first-touch page clearing for it inside GenerateSeedPosTable (25-60 ms per GiB: 0.25 s of a 0.37 s build).  The table
+        // arena is mapped (cleared) memory that holds nothing at this point -- the neighbourhood table it is there for is filled
+        // after the build has been synchronised -- so the scratch is carved from its base; hipMalloc only without a VMM arena.
+        uint8_t* scratch = nullptr;
+        size_t scratch_off = 0, scratch_cap = 0;
+        auto carve = [&](size_t bytes, const char* tag) -> void* {
+            bytes = (bytes + 255) & ~(size_t)255;
+            if (scratch && scratch_off + bytes <= scratch_cap) { void* p = scratch + scratch_off; scratch_off += bytes; return p; }
+            return dev_malloc(bytes, tag);
+        };
+        auto uncarve = [&](void* p, const char* tag) {
+            if (p && !(scratch && (uint8_t*)p >= scratch && (uint8_t*)p < scratch + scratch_cap)) dev_free(p, tag);
+        };
         if (table_partition_build_supported(kmer_size) && !g_table_atomic) {
             // PARTITION build (table.hip): keys + coarse histogram -> offsets of the 4096 coarse partitions -> two LDS-staged
             // partition passes -> one workgroup per partition finishes its slice of bucket_start and pos_table in LDS
             const size_t pw = table_partition_part_start_words();
-            uint32_t* keys = (uint32_t*)dev_malloc((size_t)std::max<uint32_t>(num_steps, 1) * sizeof(uint32_t), "kmer keys");
-            uint32_t* coarse = (uint32_t*)dev_malloc(3 * pw * sizeof(uint32_t) + 4096, "coarse histogram");  // hist | part_start | cursor | flags
+            const size_t fw = table_partition_fine_words(kmer_size);  // (keys above 24 bits -- 14of22 -- take a third partition level)
+            {
+                const size_t want = (size_t)std::max<uint32_t>(num_steps, 1) * sizeof(uint32_t) * 5 + 3 * pw * sizeof(uint32_t) + 4096 + fw * sizeof(uint32_t) +
+                                    scan_temp_bytes(std::max<size_t>(pw, (size_t)1 << 18)) + ((size_t)1 << 20);
+                if (g_table_scratch_arena && g_arena_gb != 0 && dc->arena.vmm && arena_wait(dc->arena, want)) {
+                    scratch = dc->arena.base;
+                    scratch_cap = want;
+                }
+            }
+            uint32_t* keys = (uint32_t*)carve((size_t)std::max<uint32_t>(num_steps, 1) * sizeof(uint32_t), "kmer keys");
+            uint32_t* coarse = (uint32_t*)carve(3 * pw * sizeof(uint32_t) + 4096, "coarse histogram");  // hist | part_start | cursor | flags
             uint32_t* part_start = coarse + pw;
             uint32_t* cursor = part_start + pw;
             uint8_t* part_unsorted = reinterpret_cast<uint8_t*>(cursor + pw);
-            const size_t fw = table_partition_fine_words(kmer_size);  // (keys above 24 bits -- 14of22 -- take a third partition level)
-            uint32_t* fine = fw ? (uint32_t*)dev_malloc(fw * sizeof(uint32_t), "fine partitions") : nullptr;
-            void* scan_tmp = dev_malloc(scan_temp_bytes(std::max<size_t>(pw, (size_t)1 << 18)), "scan temp");
+            uint32_t* fine = fw ? (uint32_t*)carve(fw * sizeof(uint32_t), "fine partitions") : nullptr;
+            void* scan_tmp = carve(scan_temp_bytes(std::max<size_t>(pw, (size_t)1 << 18)), "scan temp");
             check_memcpy(hipMemsetAsync(coarse, 0, pw * sizeof(uint32_t), st), "coarse histogram");
             launch_table_keys(codes, num_steps, start_offset, step, sh, keys, coarse, st);
             launch_exclusive_scan_u32(coarse, part_start, pw - 1, scan_tmp, st);
@@ -389,8 +410,9 @@ void sa_generate_seed_pos_table(const char* ref_str, size_t start_addr, uint32_t
             check_memcpy(hipMemcpyAsync(&num_index, part_start + (pw - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st), "num_index");
             check_sync(st, "table keys");
             const size_t np = std::max<uint32_t>(num_index, 1);
-            dc->pos_table = (uint32_t*)dev_malloc(np * sizeof(uint32_t), "pos_table");
-            uint32_t* pairs = (uint32_t*)dev_malloc(4 * np * sizeof(uint32_t), "partition pairs");  // key_a | pos_a | key_b | pos_b
+            dc->keep_pos.ensure(np + np / 32, "pos_table");  // (a little headroom: the next block of the same size fits without a new allocation)
+            dc->pos_table = dc->keep_pos.p;
+            uint32_t* pairs = (uint32_t*)carve(4 * np * sizeof(uint32_t), "partition pairs");  // key_a | pos_a | key_b | pos_b
             uint32_t* d_err = nullptr;
             uint32_t err = 0;
             launch_table_partition_build(keys, num_steps, start_offset, step, kmer_size, part_start, num_index, cursor, pairs, pairs + np,
@@ -398,14 +420,13 @@ void sa_generate_seed_pos_table(const char* ref_str, size_t start_addr, uint32_t
             check_launch("table partition");
             if (d_err) check_memcpy(hipMemcpyAsync(&err, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, st), "partition flag");
             check_sync(st, "table partition");
-            dev_free(pairs, "partition pairs");
-            dev_free(keys, "kmer keys");
-            dev_free(coarse, "coarse histogram");
-            dev_free(fine, "fine partitions");
-            dev_free(scan_tmp, "scan temp");
+            uncarve(pairs, "partition pairs");
+            uncarve(keys, "kmer keys");
+            uncarve(coarse, "coarse histogram");
+            uncarve(fine, "fine partitions");
+            uncarve(scan_tmp, "scan temp");
             built = err == 0;  // (a tile of the third level spanned too many coarse groups -- a tiny or wildly skewed table: atomic build)
             if (!built) {
-                dev_free(dc->pos_table, "d_pos_table");
                 dc->pos_table = nullptr;
                 if (opt_value("debug")) fprintf(stderr, "seed table: the partition build gave up on this table, atomic build instead\n");
             }
@@ -421,7 +442,8 @@ void sa_generate_seed_pos_table(const char* ref_str, size_t start_addr, uint32_t
             check_memcpy(hipMemcpyAsync(&num_index, dc->bucket_start + nkeys, sizeof(uint32_t), hipMemcpyDeviceToHost, st),
                          "num_index");
             check_sync(st, "table count");
-            dc->pos_table = (uint32_t*)dev_malloc((size_t)std::max<uint32_t>(num_index, 1) * sizeof(uint32_t), "pos_table");
+            dc->keep_pos.ensure((size_t)std::max<uint32_t>(num_index, 1) + num_index / 32, "pos_table");
+            dc->pos_table = dc->keep_pos.p;
             check_memcpy(hipMemsetAsync(hist, 0, ((size_t)nkeys + 1) * sizeof(uint32_t), st), "cursor");
             launch_table_fill(codes, num_steps, start_offset, step, sh, dc->bucket_start, hist, dc->pos_table, st);
             launch_table_sort_buckets(dc->bucket_start, nkeys, dc->pos_table, st);

@@ -382,6 +382,8 @@ struct DevCtx {
     SeqBuf ref_rc;                       // repeat masker
     uint32_t* bucket_start = nullptr;    // 4^k + 1
     uint32_t* pos_table = nullptr;
+    DevBuf<uint32_t> keep_bucket, keep_pos;  // their memory: kept across target blocks (g_ClearRef only forgets the tables) -- a fresh
+    DevBuf<uint64_t> keep_nbr_start;         // hipMalloc pays first-touch page clearing, 25-60 ms per GiB, inside the next block's table build
     uint32_t num_index = 0;
     uint32_t nkeys = 0;
     // sequence upload: ASCII goes through a ring of two pinned buffers into a reused device staging buffer, so the copies
@@ -420,7 +422,7 @@ extern uint32_t g_wga_chunk;
 extern uint32_t g_seed_size;
 extern int g_sub_mat[64];
 extern int g_xdrop, g_hspthresh, g_noentropy;
-extern int g_log4_double, g_entropy_ulps;  // options log4_double (H2), entropy_ulps (H13, tests)
+extern int g_log4_double, g_entropy_ulps, g_table_scratch_arena;  // options log4_double (H2), entropy_ulps (H13, tests)
 extern int64_t g_max_seeds;
 extern int64_t g_max_hits;
 extern bool g_max_hits_overridden;

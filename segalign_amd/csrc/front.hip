@@ -91,9 +91,8 @@ __global__ void widen_u32_kernel(const uint32_t* __restrict__ in, uint64_t* __re
 }
 
 void nbr_release(DevCtx* dc) {
-    dev_free(dc->nbr_start, "nbr_start");
     if (!dc->nbr_alias) dev_free(dc->nbr_pos, "nbr_pos");
-    dc->nbr_start = nullptr;
+    dc->nbr_start = nullptr;  // (its memory stays: keep_nbr_start)
     dc->nbr_pos = nullptr;
     dc->nbr_ctx = nullptr;  // (the memory stays with the arena)
     dc->nbr_alias = false;
@@ -114,15 +113,19 @@ bool ensure_nbr(DevCtx* dc) {
     dc->nbr_tmask = tmask;
     dc->nbr_state = -1;
     const uint32_t nkeys = dc->nkeys;
-    dc->nbr_start = (uint64_t*)dev_malloc(((size_t)nkeys + 1) * sizeof(uint64_t), "nbr_start");
+    dc->keep_nbr_start.ensure((size_t)nkeys + 1, "nbr_start");
+    dc->nbr_start = dc->keep_nbr_start.p;
     uint64_t total = dc->num_index;
     if (tmask == 0) {  // one word per position: the runs ARE the buckets
         hipLaunchKernelGGL(widen_u32_kernel, dim3(4096), dim3(256), 0, st, dc->bucket_start, dc->nbr_start, nkeys + 1);
         check_launch("nbr widen");
         check_sync(st, "nbr widen");
     } else {
-        uint32_t* cnt = (uint32_t*)dev_malloc(((size_t)nkeys + 1) * sizeof(uint32_t), "nbr counts");
-        void* scan_tmp = dev_malloc(scan_temp_bytes(nkeys), "scan temp");
+        // (scratch from the base of the table arena when it is mapped: it holds nothing until the fill below, and both are done by then)
+        const size_t cnt_b = (((size_t)nkeys + 1) * sizeof(uint32_t) + 255) & ~(size_t)255, scan_b = scan_temp_bytes(nkeys);
+        const bool in_arena = g_table_scratch_arena && g_arena_gb != 0 && dc->arena.vmm && arena_wait(dc->arena, cnt_b + scan_b);
+        uint32_t* cnt = in_arena ? reinterpret_cast<uint32_t*>(dc->arena.base) : (uint32_t*)dev_malloc(cnt_b, "nbr counts");
+        void* scan_tmp = in_arena ? (void*)(dc->arena.base + cnt_b) : dev_malloc(scan_b, "scan temp");
         check_memcpy(hipMemsetAsync(cnt + nkeys, 0, sizeof(uint32_t), st), "nbr overflow flag");  // cnt[nkeys] doubles as the flag
         launch_nbr_count(dc->bucket_start, nkeys, tmask, g_shape.weight, cnt, cnt + nkeys, st);
         launch_exclusive_scan_u64(cnt, dc->nbr_start, nkeys, scan_tmp, st);
@@ -131,10 +134,8 @@ bool ensure_nbr(DevCtx* dc) {
         check_memcpy(hipMemcpyAsync(&total, dc->nbr_start + nkeys, sizeof(uint64_t), hipMemcpyDeviceToHost, st), "nbr total");
         check_memcpy(hipMemcpyAsync(&overflow, cnt + nkeys, sizeof(uint32_t), hipMemcpyDeviceToHost, st), "nbr overflow");
         check_sync(st, "nbr count");
-        dev_free(cnt, "nbr counts");
-        dev_free(scan_tmp, "scan temp");
+        if (!in_arena) { dev_free(cnt, "nbr counts"); dev_free(scan_tmp, "scan temp"); }
         if (overflow) {
-            dev_free(dc->nbr_start, "nbr_start");
             dc->nbr_start = nullptr;
             return false;
         }
@@ -194,7 +195,6 @@ bool ensure_nbr(DevCtx* dc) {
         check_launch("nbr fill");
         check_sync(st, "nbr fill");
     } else {
-        dev_free(dc->nbr_start, "nbr_start");
         dc->nbr_start = nullptr;
         return false;
     }

@@ -18,6 +18,7 @@ uint32_t g_seed_size = 19;
 int g_sub_mat[64];
 int g_xdrop = 910, g_hspthresh = 3000, g_noentropy = 0;
 int g_log4_double = 0, g_entropy_ulps = 0;
+int g_table_scratch_arena = 1;  // option table_scratch_arena
 int64_t g_max_seeds = 0;
 int64_t g_max_hits = 0;
 bool g_max_hits_overridden = false;
@@ -117,6 +118,7 @@ static Option g_opts[] = {
     {"key_order_chunks", 200, 1, SA_MAX_CHUNKS, 0},    // chunks sa_get_chunks_per_call() hands to one call when key-ordered calls are on (a call's positions per key set the record reuse)
     {"key_order_hits", 3ll << 30, 1 << 20, 1ll << 34, 0},  // ... capped so that a call stays below about this many seed hits (its lists are sized by them)
     {"key_order_min_pos", 0, 0, 1ll << 31, 0},         // positions a call must hold to go key-ordered under key_order = 1 (0: the number of seed keys)
+    {"table_scratch_arena", 1, 0, 1, 0},               // scratch of the seed table build (keys, pair arrays: ~10 GB per 500 Mbp block) carved from the mapped table arena instead of fresh hipMallocs (first-touch page clearing inside every GenerateSeedPosTable)
     {"log4_double", 0, 0, 1, 0},                       // entropy divisor (src/seed_filter.cu:623, hazard H2): 0 = (double)logf(4.0f) as nvcc compiles `log(4.0f)`, 1 = log(4.0) (a host compiler without <cmath>'s float overload in scope)
     {"entropy_ulps", 0, -4, 4, 1},                     // tests (hazard H13): entropy factor moved by this many ulps before the truncating multiplies
     {"no_ctx", 0, 0, 1, 0},                            // 1: neighbourhood table without target context (lookup mode 1)
@@ -174,6 +176,7 @@ void resolve_options() {
     g_key_order_min_pos = opt_value("key_order_min_pos");
     g_call_hits = opt_value("call_hits");
     g_call_hits_max = opt_value("call_hits_max");
+    g_table_scratch_arena = (int)opt_value("table_scratch_arena");
     g_log4_double = (int)opt_value("log4_double");
     g_entropy_ulps = (int)opt_value("entropy_ulps");
     g_ctx = opt_value("no_ctx") ? 0 : 1;

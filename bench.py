@@ -359,8 +359,10 @@ def main():
     pool = ThreadPoolExecutor(inflight)  # the reference keeps one seeder body per TBB thread in flight (src/main.cpp:565-573)
 
     def step_jobs(k):
-        """strong: this rank's share of the calls of ONE pass over the query block; weak: all of them, from a rank-dependent start"""
-        return my_jobs if scaling == "strong" else rotate(jobs, rank + k)
+        """strong: this rank's share of the calls of pass k over the query block -- round-robin, the deal continuing from pass to pass
+        (pass k starts where pass k - 1 stopped: every pass deals every call exactly once, and shares that differ by one call within
+        a pass even out over the passes); weak: all of them, from a rank-dependent start"""
+        return shard.partition(jobs, rank, world, None, offset=k * len(jobs)) if scaling == "strong" else rotate(jobs, rank + k)
 
     def run_steps(ks, collect=None, threads=None):
         """The passes `ks` as ONE list of calls: the calls of consecutive passes follow each other without a drain in between, as the
@@ -496,7 +498,12 @@ def main():
             pos = {id(j): k for k, j in enumerate(jobs)}
             loads = [sum(ws[pos[id(j)]] for j in shard.partition(jobs, r, n, w_or_none)) for r in range(n)]
             return round(max(loads) / max(sum(loads) / n, 1e-9), 4)
-        imbalance = {"ranks": n_show, "calls": len(jobs), "by_hits": spread(ws, n_show), "round_robin": spread(None, n_show)}
+        def spread_over_steps(n, steps):  # the default map over the timed passes: the deal continues from pass to pass
+            pos = {id(j): k for k, j in enumerate(jobs)}
+            loads = [sum(ws[pos[id(j)]] for k in range(steps) for j in shard.partition(jobs, r, n, None, offset=k * len(jobs))) for r in range(n)]
+            return round(max(loads) / max(sum(loads) / n, 1e-9), 4)
+        imbalance = {"ranks": n_show, "calls": len(jobs), "by_hits": spread(ws, n_show), "round_robin": spread(None, n_show),
+                     "round_robin_over_the_timed_passes": spread_over_steps(n_show, max(args.steps, 1))}
         ch = np.array(list(chunk_hits.values()), dtype=np.float64)
         if ch.size and ch.sum() > 0:
             hit_spread = {"chunks": int(ch.size), "hits_per_pass": int(ch.sum()), "heaviest_chunk_over_mean": round(float(ch.max() / ch.mean()), 3),
@@ -525,7 +532,8 @@ def main():
                        "workload_key": args.workload + ("" if args.seed == "12of19" else "_" + args.seed), "seed": args.seed,
                        "parallelism": ("the %d engine calls of one pass dealt to %d rank(s) %s: every call on exactly one GPU, target + tables on every GPU, "
                                        "no collective" % (len(jobs), world, "by seed-hit count (longest first to the least loaded rank; counts from a "
-                                                          "lookup-only pass every rank runs inside the timed region, once per pass)" if by_hits else "round-robin")) if scaling == "strong" else
+                                                          "lookup-only pass every rank runs inside the timed region, once per pass)" if by_hits else
+                                                          "round-robin, the deal continuing from pass to pass (every pass deals every call once)")) if scaling == "strong" else
                                       ("every one of %d rank(s) runs all %d calls of a pass (`human`: on a block pair of its own), no collective"
                                        % (world, len(jobs))),
                        "calls_per_step": len(jobs), "calls_in_flight_per_gpu": inflight, "partition_imbalance": imbalance, "hit_spread": hit_spread,
@@ -916,7 +924,8 @@ def dry_run(args, rank, world, dist, torch, shard, scaling):
     bases, check = 0, 0
     for k in range(args.steps):
         # (strong: the real bench's default map, round-robin; --partition hits: weighted -- there by seed hits, here by the calls' lengths)
-        todo = (shard.partition(jobs, rank, world, [j["b"] - j["a"] for j in jobs] if world > 1 and args.partition == "hits" else None)
+        todo = (shard.partition(jobs, rank, world, [j["b"] - j["a"] for j in jobs] if world > 1 and args.partition == "hits" else None,
+                                offset=k * len(jobs))
                 if scaling == "strong" else rotate(jobs, rank + k))
         for i, j in enumerate(todo):
             bases += 0 if j["rev"] else j["b"] - j["a"]

@@ -59,7 +59,7 @@ void sa_copy_query_codes(int dev, uint32_t buffer, int rev, uint8_t* dst) {
 // repeat masker's chain, repeat_masker_src/seed_filter.cu:819-831.  path 0: the per-segment LDS chain (dedup_seg_kernel; plain
 // chain only, at most its 2048 records), path 1: rocprim merge sorts + the adjacent-pair unique kernels (what oversized segments
 // and the repeat masker take).  Test entry (tests/test_gpu_thrust_order.py holds both paths against rocThrust's stable_sort /
-// unique_copy and against the oracle): own buffers, device 0, default stream.  Returns the number of records in *out.
+// unique_copy and against the CPU restatement): own buffers, device 0, default stream.  Returns the number of records in *out.
 size_t sa_order_hsps(const sa_segment_pair* in, size_t n, int rm, int path, sa_segment_pair** out) {
     *out = nullptr;
     if (g_ndev <= 0) {

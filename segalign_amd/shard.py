@@ -66,14 +66,17 @@ def call_jobs(intervals, q_block_len, chunk, chunks_per_call=16):
     return jobs
 
 
-def partition(jobs, rank, world, weights=None):
+def partition(jobs, rank, world, weights=None, offset=0):
     """Strong scaling: the calls of ONE problem dealt to the ranks -- every call exactly once, no communication: every rank computes
     the same map.  Without weights: round-robin (consecutive calls -- neighbouring query regions, similar hit density -- land on
-    different ranks).  With weights (the seed hits of every call, counted by an untimed pass that every rank runs identically):
+    different ranks; `offset` continues the deal from one pass to the next).  With weights (the seed hits of every call, counted by an untimed pass that every rank runs identically):
     longest-processing-time-first -- calls in descending weight, each to the rank with the least weight so far (ties: lowest rank)
     -- which bounds the imbalance by one call's weight.  A rank's calls keep their original order."""
     if weights is None or world <= 1:
-        return [j for k, j in enumerate(jobs) if k % world == rank]
+        # offset: how many calls have been dealt before this list -- the deal of pass k continues where pass k - 1 stopped (a host
+        # that walks query block after query block keeps dealing; 20 calls on 8 ranks are 3/3/3/3/2/2/2/2 in one pass and even
+        # over two), like the reference's dynamic device pool (src/seed_filter.cu:699-706)
+        return [j for k, j in enumerate(jobs) if (k + offset) % world == rank]
     assert len(weights) == len(jobs)
     load = [0] * world
     owner = [0] * len(jobs)

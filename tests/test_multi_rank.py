@@ -114,6 +114,22 @@ def test_call_list_partition_covers_every_call_exactly_once():
         assert max(loads) - min(loads) <= max(w)
 
 
+def test_the_deal_continues_from_pass_to_pass_and_evens_out():
+    """20 calls on 8 ranks are 3/3/3/3/2/2/2/2 in one pass; with the deal continuing (offset = calls dealt so far) every pass still
+    deals every call exactly once and the shares are even over two passes -- the default map of the timed region."""
+    jobs = [dict(a=i, b=i + 1, rev=False, chunks=1, interval=0) for i in range(20)]
+    total = [0] * 8
+    for k in range(4):
+        parts = [shard.partition(jobs, r, 8, None, offset=k * len(jobs)) for r in range(8)]
+        assert sorted(j["a"] for p in parts for j in p) == list(range(20))      # every call exactly once per pass
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) == 1
+        for r in range(8):
+            total[r] += len(parts[r])
+        if k % 2 == 1:
+            assert max(total) == min(total)                                       # even after every second pass
+    assert shard.partition(jobs, 3, 8, None) == shard.partition(jobs, 3, 8, None, offset=0)
+
+
 def test_strong_scaling_partition_keeps_the_checksum_for_world_1_2_3():
     """The strong-scaling map: total work fixed, every call on exactly one rank, so bases and the stub checksum of a pass do not
     depend on the number of ranks -- and equal the independent model."""

@@ -17,15 +17,15 @@ src/main.cpp:617-629).
 Other workloads (--workload): `notransition` = configs[4] (--notransition --step=1), `rm` = configs[3] (repeat-masker
 path: the target self-aligned through sa_rm_mask_interval over the reference's interval plan), `human` = one block pair
 of configs[2] (a 500 Mbp target block, the size at which the reference closes a block, x a 100 Mbp query block of 1.2
-%-diverged shuffled pieces.  --scaling strong, the default: the SAME block pair on every rank, its calls dealt to the ranks by
-seed hits -- the sharding BASELINE configs[2] names; --scaling weak: every rank on a block pair of its own, as the 6 x 6 block
+%-diverged shuffled pieces; --query-mbp 500 for the reference's block size.  --scaling strong, the default: the SAME block pair on every
+rank, its calls dealt to the ranks round-robin -- the sharding BASELINE configs[2] names; tools/human_grid.py walks the whole block grid; --scaling weak: every rank on a block pair of its own, as the 6 x 6 block
 pairs of a 3 Gbp x 3 Gbp run are independent), `plumbing` = configs[0] (1 Mbp x 1 Mbp).
 
 Multi-GPU: the unit of work is one engine CALL (consecutive 250 kbp chunks of one strand; forty by default -- one call per
 strand of a 10 Mbp interval, 20 calls per pass of the default workload -- more when the resident target's seed hits are sparse, up to
 sa_max_chunks_per_call(); the SAME grain at every N); calls are independent and their output position is fixed by the host loop.
-Default `--scaling strong`: the calls of ONE pass are dealt to the N ranks round-robin, like the reference's dynamic pool with no
-weighting pass (src/seed_filter.cu:699-706,798-803) -- every call on exactly one GPU, total work fixed, `value` = query bases of the
+Default `--scaling strong`: the calls of ONE pass are dealt to the N ranks round-robin (the deal continues from pass to pass), like the
+reference's dynamic pool with no weighting pass (src/seed_filter.cu:699-706,798-803) -- every call on exactly one GPU, total work fixed, `value` = query bases of the
 block / max-rank time, and the order-independent HSP checksum of the pass must equal the 1-GPU checksum.  `--partition hits` deals by
 seed hits instead; the lookup-only pass that counts them then runs INSIDE the timed region, once per pass on every rank.  `--scaling weak`: every rank runs the whole pass (rank-dependent start).  Every rank holds target + tables; there is
 NO data-path collective (torch.distributed only carries the barrier and the max / sum of the timing and counts).

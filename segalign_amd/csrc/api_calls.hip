@@ -71,9 +71,9 @@ size_t sa_seed_and_filter_range(uint32_t start, uint32_t end, int rev, uint32_t 
 // iteration plan, dedup scope and return vector -- bit for bit what one sa_seed_and_filter_range call per chunk returns.
 int sa_max_chunks_per_call(void) { return SA_MAX_CHUNKS; }
 // What the interval entries hand to one call, and what a host that builds its own call lists should use: option chunks_per_call
-// (default 20), raised for the RESIDENT target when its seed hits are sparse -- a call is sized by hits, not by chunks: option
+// (default 40), raised for the RESIDENT target when its seed hits are sparse -- a call is sized by hits, not by chunks: option
 // call_hits (default 128 M: beyond that a call no longer gets cheaper per hit, and a pass has too few calls to fill the slots) / (table entries per key x wga_chunk positions), at most sa_max_chunks_per_call().  With
-// --notransition one 250 kbp chunk holds ~1.5 M hits instead of ~19 M: twenty-chunk calls would spend two thirds of their time in
+// --notransition one 250 kbp chunk holds ~1.5 M hits instead of ~13 M: forty-chunk calls would spend two thirds of their time in
 // per-call fixed costs.
 int sa_get_chunks_per_call(void) {
     int k = g_chunks_per_call;

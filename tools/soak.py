@@ -63,7 +63,12 @@ def one_case(seed, s14):
               noentropy=bool(rng.random() < 0.3), chunk=int(rng.choice([8000, 25000, 60000, 250000])))
     if shape:
         kw["shape"] = shape
+    E.reset_option(None)
+    ko = bool(rng.random() < 0.3)   # the multi-chunk calls of (2) key-ordered (option key_order = 2: join.hip, extend.hip 1e)
+    if ko:
+        E.set_option("key_order", 2)
     c = Case(t, q, **kw).oracle_setup(O).engine_setup(E)
+    kw["key_order"] = ko
     hsps = hits = 0
     try:
         q_len = c.query.size - c.seed_size
@@ -115,7 +120,7 @@ def main():
             sys.exit(1)
         print("seed %d %-9s %7d bp step %d %s chunk %6d xdrop %4d thresh %4d %s%s: %d hits, %d HSPs ok" % (
             seed, kind, size, kw["step"], "tr" if kw["transition"] else "no-tr", kw["chunk"], kw["xdrop"], kw["hspthresh"],
-            "noentropy " if kw["noentropy"] else "", "14of22" if "shape" in kw else "12of19", hits, hsps), flush=True)
+            "noentropy " if kw["noentropy"] else "", ("14of22" if "shape" in kw else "12of19") + (" key-ordered" if kw.get("key_order") else ""), hits, hsps), flush=True)
         n += 1
         tot_hits += hits
         tot_hsps += hsps

@@ -7,7 +7,8 @@ on the CPU takes longer than the whole GPU suite)."""
 import numpy as np
 import pytest
 
-from segalign_amd import synth
+from helpers import Case, seg_equal
+from segalign_amd import shard, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -124,3 +125,40 @@ def test_block_that_does_not_fit_falls_back_to_positions_and_recovers(oracle, en
         E.ShutdownProcessor()
         E.reset_option("arena_gb")
         E.reset_option("work_gb")
+
+
+def test_work_regions_survive_a_reinitialisation_with_another_layout(oracle, engine):
+    """InitializeProcessor again WITHOUT a ShutdownProcessor in between, with another work-arena share per slot (option work_gb) and
+    another slot count: slots that exist already are torn down and set up again before they are re-based (round 4's advisor: their
+    buffers pointed into the old layout, where a neighbour's new region carved over them).  Multi-chunk calls on several host
+    threads before and after, against the oracle."""
+    E = engine
+    t, q = synth.make_pair(600000, 71, 72, sub_rate=0.08, mask_frac=0.1, records=2, indel_every=600)
+    c = Case(t, q, chunk=50000)
+    c.oracle_setup(oracle)
+    want = {}
+    q_len = q.size - 19
+    for rev in (False, True):
+        exp = []
+        for (s, e) in shard.chunks_of((0, q_len), 50000, q_len, rev):
+            seeds = c.host_seeds(s, e, rev)
+            if seeds.size:
+                exp.append(c.oracle_saf(seeds, rev)[0][1:])
+        want[rev] = np.concatenate(exp)
+    try:
+        for (work_gb, slots) in ((3, 4), (1, 6), (2, 2), (0, 4)):
+            E.set_option("work_gb", work_gb)
+            E.set_option("slots", slots)
+            if work_gb == 3:
+                c.engine_setup(E)
+            else:   # the reference's order after a parameter change: processor, target, table, query -- no shutdown
+                E.InitializeProcessor(True, 50000, 19, c.sub_mat, 910, 3000, False)
+                keep = E.SendRefWriteRequest(t, 0, t.size)
+                E.GenerateSeedPosTable(keep, 0, t.size, 1, 19, c.kmer_size)
+                E.SendQueryWriteRequest(q, 0, q.size, 0)
+            for rep in range(2):
+                fw, rc, tot = E.SeedInterval(0, q_len, q_len, E.STRAND_BOTH, 0, 3)
+                assert seg_equal(fw, want[False]) and seg_equal(rc, want[True]), (work_gb, slots, rep)
+    finally:
+        E.ShutdownProcessor()
+        E.reset_option(None)

@@ -123,3 +123,23 @@ def test_crowded_buckets_keep_the_windows_of_one_diagonal_apart(oracle, engine):
     assert all(np.array_equal(a, b) for a, b in zip(base, few))
     assert s_base * 5 < s_off          # the shortcut is worth something on this input at all ...
     assert s_few <= 1.25 * s_base + 64  # ... and crowding the buckets costs next to nothing (interleaved windows: thousands)
+
+
+@pytest.mark.parametrize("threads", [64, 128, 512])
+def test_chain_sort_and_link_with_any_workgroup_size(oracle, engine, threads):
+    """Option chain_sort_threads (64..512): the fused sort + link kernel stages its 128-entry score table with a strided loop, so a
+    64-thread workgroup fills the terminator half too (round 4's advisor: with `threadIdx.x < 128` it stayed uninitialised, link
+    tests misfired and run members were dropped), and chain_group_max = 4096 announces its 78 KB of dynamic LDS.  Same vectors as
+    the default, the oracle's, and about as few extensions."""
+    t1, q1 = synth.make_pair(60000, 41, 42, sub_rate=0.03, invert_frac=0.0)
+    base, s_base = run(engine, oracle, t1, q1, True, chunk=30000)
+    os.environ["SEGALIGN_AMD_CHAIN_SORT_THREADS"] = str(threads)
+    os.environ["SEGALIGN_AMD_CHAIN_GROUP_MAX"] = "4096"
+    os.environ["SEGALIGN_AMD_CHAIN_BUCKETS"] = "128"
+    try:
+        got, s_got = run(engine, oracle, t1, q1, True, chunk=30000)   # (run() holds every vector against the oracle)
+    finally:
+        for k in ("SEGALIGN_AMD_CHAIN_SORT_THREADS", "SEGALIGN_AMD_CHAIN_GROUP_MAX", "SEGALIGN_AMD_CHAIN_BUCKETS"):
+            os.environ.pop(k, None)
+    assert all(np.array_equal(a, b) for a, b in zip(base, got))
+    assert s_got <= 1.25 * s_base + 64

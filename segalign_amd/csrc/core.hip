@@ -206,6 +206,7 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                 ea.xdrop = g_xdrop;
                 ea.hspthresh = g_hspthresh;
                 ea.noentropy = g_noentropy;
+                ea.left_skip = dc->nbr_left_skip;
                 ea.log4_double = g_log4_double;
                 ea.entropy_ulps = g_entropy_ulps;
                 ea.num_hits = bh;

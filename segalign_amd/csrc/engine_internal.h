@@ -397,6 +397,7 @@ struct DevCtx {
     std::mutex nbr_mu;
     uint64_t* nbr_start = nullptr;       // nkeys + 1
     uint32_t* nbr_pos = nullptr;         // == pos_table when no transition word exists (nbr_alias); null when nbr_ctx is built
+    uint32_t nbr_left_skip = 0;          // what the records of nbr_ctx were cut with (CtxRec): seed_size, or 0 under option ctx_skip_seed = 0
     CtxRec* nbr_ctx = nullptr;           // the runs WITH their target context: 32-byte records in the arena (class filter, extend.hip 1d)
     Arena& work_arena;                   // cleared device memory for the slots' work buffers (WorkRegion), mapped in the background like `arena`
     Arena& arena;                        // memory of the context table: outlives target blocks AND engine contexts (a process-wide
@@ -422,7 +423,7 @@ extern uint32_t g_wga_chunk;
 extern uint32_t g_seed_size;
 extern int g_sub_mat[64];
 extern int g_xdrop, g_hspthresh, g_noentropy;
-extern int g_log4_double, g_entropy_ulps, g_table_scratch_arena;  // options log4_double (H2), entropy_ulps (H13, tests)
+extern int g_log4_double, g_entropy_ulps, g_table_scratch_arena, g_ctx_skip_seed;  // options log4_double (H2), entropy_ulps (H13, tests)
 extern int64_t g_max_seeds;
 extern int64_t g_max_hits;
 extern bool g_max_hits_overridden;

@@ -830,10 +830,10 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
                         bestR = (int)mine_known;
                         best = (int)mine_tm;
                         phase = PH_FIN;
-                    } else if (SRC == SRC_CAND && mine_flags == 2u) {  // right side settled; the left walk continues after 64 bases
-                        bestR = (int)mine_known;
+                    } else if (SRC == SRC_CAND && mine_flags == 2u) {  // right side settled; the left walk continues behind level 1's context:
+                        bestR = (int)mine_known;                          // the seed window (bounded there) + the 64 bases in front of it
                         phase = PH_LEFT;
-                        walked = 64;
+                        walked = 64u + a.left_skip;
                         const short t16 = (short)(mine_tm & 0xFFFFu), m16 = (short)(mine_tm >> 16);
                         T = (s16x2){t16, t16};
                         M = (s16x2){m16, m16};
@@ -961,6 +961,17 @@ __device__ __forceinline__ void cls_step(const uint32_t* __restrict__ s_tab, uin
     }
 }
 
+// The left walk crosses the seed window first (anchor - 1 is its last base).  Every base there is bounded by the largest class score
+// -- exact for the care positions of the k-mer's own seed word, an upper bound for a transition or a don't-care position --, so the
+// walk enters the record's left context with T = seed_size x that score and N = 0 (a run of non-negative steps ends at its own
+// best): the same pointwise-upper-bound argument as for the class scores themselves, at no lookup.  What it costs: the bound on
+// bestL is looser by what the seed window really scores below that (about 1000 for 12of19), which only matters for the verdict
+// bestR + bestL >= hspthresh of hits with both sides dropped: 1e-4 of the hits.
+__device__ __forceinline__ uint32_t cls_seed_state(const ExtendArgs& a) {
+    const int cmax = max(max(a.cls[0], a.cls[1]), max(a.cls[2], a.cls[3]));
+    return (uint32_t)((int)a.left_skip * max(cmax, 0)) << 16;
+}
+
 // ONE_COPY: the query windows come out of the UNSHIFTED 2-bit copy of either strand (copy 0 of the sixteen) with funnel shifts, instead
 // of aligned dwords of the copy that starts at the position's phase.  With ~78 hits per query position a 64-hit buffer holds about
 // one position and the sixteen copies cost nothing; with ~5 hits per position (--notransition, small targets) it holds 13 positions
@@ -980,6 +991,7 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(E
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     const int xdrop = a.xdrop;
     const uint4* __restrict__ ctx = reinterpret_cast<const uint4*>(a.td_ctx);
+    const uint32_t seed_state = cls_seed_state(a);  // the left walk's {T : N} behind the seed window
 
     // a wave takes a contiguous range of TD_CHUNK_HITS-hit chunks (64 buffers each); the record that holds a chunk's first hit
     // was noted by the probe (td_chunk), so no wave has to search for its starting point
@@ -1035,7 +1047,8 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(E
         S.query_loc = query_loc;
         // copy (pos & 3, (pos >> 2) & 3) = copy number pos & 15, dword pos >> 4 (encode.hip); strides are multiples of 16 bytes, so
         // the offset is ONE 32-bit value next to a scalar base
-        const uint32_t lp = a.query_len - query_loc;  // the left walk = the other strand's forward window at len - anchor (CtxRec)
+        // the left context starts in front of the seed (CtxRec): the other strand's forward window at len - anchor + seed_size
+        const uint32_t lp = a.query_len - query_loc + a.left_skip;
         if (ONE_COPY) {
             // copy 0: dword j holds bases [16 j, 16 j + 16), base 16 j + k in bits 2k, 2k + 1; the window at position p is the bit string
             // from bit 2 (p & 15) of dword p >> 4 on: one more dword per side and a funnel shift per dword
@@ -1086,8 +1099,8 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(E
         // alive: never more than xdrop below its best at a field end (:374; without W: at the end of the context)
         const bool r_alive = (int)(short)((CLS_TRACK_DROP ? Wd : P) & 0xFFFFu) >= -xdrop;
         const int bestR = ((int)P >> 16) - (int)(short)(P & 0xFFFFu);  // best = T - N
-        // ---- left side (:478-604): 64 bases = 10 fields + a four-base tail ----
-        P = 0; Wd = 0;
+        // ---- left side (:478-604): the seed window bounded by seed_bound (no lookup), then 64 bases = 10 fields + a four-base tail ----
+        P = seed_state; Wd = 0;
         cls_step(s_cls, cls_field_addr<0>(y0, y1), P, Wd);
         cls_step(s_cls, cls_field_addr<12>(y0, y1), P, Wd);
         cls_step(s_cls, cls_field_addr<24>(y0, y1), P, Wd);
@@ -1200,6 +1213,7 @@ __global__ __launch_bounds__(JOIN_THREADS, 8) void join_filter_kernel(ExtendArgs
     uint32_t* __restrict__ my_count = a.l2_count + my_sub * L2_CNT_STRIDE;
     const JoinHead* __restrict__ H = jn.head;
     const unsigned long long work_total = H->work_total;
+    const uint32_t seed_state = cls_seed_state(a);  // (1d: the left walk enters its context behind the seed window)
 
     for (;;) {
         // claim JOIN_GRAIN work units (a unit = one 64-hit step of one tile)
@@ -1281,7 +1295,7 @@ __global__ __launch_bounds__(JOIN_THREADS, 8) void join_filter_kernel(ExtendArgs
                         const uint4 t4 = reinterpret_cast<const uint4*>(qp)[k];
                         q[4 * k] = t4.x; q[4 * k + 1] = t4.y; q[4 * k + 2] = t4.z; q[4 * k + 3] = t4.w;
                     }
-                    uint32_t PR = 0, WR = 0, PL = 0, WL = 0;
+                    uint32_t PR = 0, WR = 0, PL = seed_state, WL = 0;
 #pragma unroll
                     for (int k = 0; k < JOIN_NFL; k++) {
                         if (k < JOIN_NFR) cls_step(s_cls, tf[k] ^ q[1 + k], PR, WR);

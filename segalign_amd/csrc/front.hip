@@ -167,8 +167,9 @@ bool ensure_nbr(DevCtx* dc) {
             dc->nbr_ctx = reinterpret_cast<CtxRec*>(arena);
             if (dbg) fprintf(stderr, "neighbourhood table: %.1f M entries, waited %.1f ms for %.1f GB of arena\n", total / 1e6, now() - t_a, need / 1e9);
             const double t_b = now();
+            dc->nbr_left_skip = g_ctx_skip_seed ? g_seed_size : 0u;
             launch_nbr_fill_ctx(dc->bucket_start, dc->pos_table, nkeys, tmask, g_shape.weight, dc->nbr_start, dc->ref2.base, dc->ref2.stride,
-                                g_seed_size, dc->nbr_ctx, two_stage ? reinterpret_cast<CtxRec*>(arena + rec_b) : nullptr, (uint32_t)dc->num_index, st);
+                                g_seed_size, dc->nbr_left_skip, dc->nbr_ctx, two_stage ? reinterpret_cast<CtxRec*>(arena + rec_b) : nullptr, (uint32_t)dc->num_index, st);
             check_launch("nbr fill ctx");
             check_sync(st, "nbr fill ctx");
             if (dbg) fprintf(stderr, "neighbourhood table: context fill (%s) took %.1f ms\n", two_stage ? "two-stage" : "one-stage", now() - t_b);
@@ -394,7 +395,7 @@ uint32_t join_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, uint32_t qlen, 
     }
     {
         ProfScope p(sl, "join_qx");
-        launch_join_qx(sl->jq_start.p, nkeys, sl->jq_pos.p, q2_own->base, q2_other->base, qlen, g_seed_size, sl->jq_qx.p, st);
+        launch_join_qx(sl->jq_start.p, nkeys, sl->jq_pos.p, q2_own->base, q2_other->base, qlen, g_seed_size, dc->nbr_left_skip, sl->jq_qx.p, st);
     }
     check_launch("join entries");
     check_sync(st, "join plan");

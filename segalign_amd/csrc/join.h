@@ -66,7 +66,7 @@ void launch_join_entries(const uint32_t* qk_start, const uint64_t* nbr_start, ui
                          hipStream_t s);  // count -> layout -> scatter; head->cls_count must be zero on entry, ent_nt zero-filled
 void launch_join_finish(JoinHead* head, const unsigned long long* vstart, hipStream_t s);
 void launch_join_qx(const uint32_t* qk_start, uint32_t nkeys, const uint32_t* qpos, const uint8_t* q2_own, const uint8_t* q2_other, uint32_t query_len,
-                    uint32_t seed_size, uint32_t* qx, hipStream_t s);
+                    uint32_t seed_size, uint32_t left_skip, uint32_t* qx, hipStream_t s);
 struct ExtendArgs;
 void launch_join_filter(const ExtendArgs& a, const JoinArgs& j, hipStream_t s);  // extend.hip 1e
 

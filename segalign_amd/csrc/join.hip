@@ -197,20 +197,20 @@ __device__ __forceinline__ uint4 jload16(const uint8_t* p) {
 
 __global__ __launch_bounds__(256) void join_qx_kernel(const uint32_t* __restrict__ qk_start, uint32_t nkeys, const uint32_t* __restrict__ qpos,
                                                       const uint8_t* __restrict__ q2_own, const uint8_t* __restrict__ q2_other, uint32_t query_len,
-                                                      uint32_t seed_size, uint32_t* __restrict__ qx) {
+                                                      uint32_t seed_size, uint32_t left_skip, uint32_t* __restrict__ qx) {
     const uint32_t n = qk_start[nkeys];  // valid positions of the call
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t p = qpos[i];
         const uint32_t query_loc = p + seed_size;  // :204
         // the windows out of the unshifted 2-bit copies (extend.hip 1d, ONE_COPY): 48 bases from query_loc on this strand, 64 bases from
-        // len - query_loc on the other strand (= the bases left of the anchor in walking order, complemented: CtxRec)
+        // len - query_loc + seed_size on the other strand (= the bases left of the SEED in walking order, complemented: CtxRec)
         const uint4 t = jload16(q2_own + ((query_loc >> 4) << 2));
         const uint32_t sr = (query_loc & 15u) << 1;
         uint32_t r[3];
         r[0] = __builtin_amdgcn_alignbit(t.y, t.x, sr);
         r[1] = __builtin_amdgcn_alignbit(t.z, t.y, sr);
         r[2] = __builtin_amdgcn_alignbit(t.w, t.z, sr);
-        const uint32_t lp = query_len - query_loc;
+        const uint32_t lp = query_len - query_loc + left_skip;  // (the left context starts in front of the seed: CtxRec)
         const uint8_t* lpp = q2_other + ((lp >> 4) << 2);
         const uint4 u = jload16(lpp);
         uint32_t u4;
@@ -255,8 +255,8 @@ void launch_join_finish(JoinHead* head, const unsigned long long* vstart, hipStr
     hipLaunchKernelGGL(join_finish_kernel, dim3(1), dim3(64), 0, s, head, vstart);
 }
 void launch_join_qx(const uint32_t* qk_start, uint32_t nkeys, const uint32_t* qpos, const uint8_t* q2_own, const uint8_t* q2_other, uint32_t query_len,
-                    uint32_t seed_size, uint32_t* qx, hipStream_t s) {
-    hipLaunchKernelGGL(join_qx_kernel, dim3(8192), dim3(256), 0, s, qk_start, nkeys, qpos, q2_own, q2_other, query_len, seed_size, qx);
+                    uint32_t seed_size, uint32_t left_skip, uint32_t* qx, hipStream_t s) {
+    hipLaunchKernelGGL(join_qx_kernel, dim3(8192), dim3(256), 0, s, qk_start, nkeys, qpos, q2_own, q2_other, query_len, seed_size, left_skip, qx);
 }
 
 }  // namespace sa

@@ -83,10 +83,15 @@ struct TdRec {                // table-direct lookup (probe.hip): a non-empty qu
 // any query-side reversal.  32 bytes, 16-byte aligned: two aligned 16-byte loads per hit and a shift for the address (a 28-byte
 // record with the position in a side array was measured: its 64-bit multiply-by-28 and the extra gather for the ~4 % of
 // forwarded hits cost more VALU issue and wait time than the 4 bytes save in a kernel that is not bound by bytes).
+// The left context does NOT hold the seed window itself (round 5): the left walk starts at anchor - 1 = the last base of the seed
+// window and crosses its seed_size bases first.  Those carry next to no information -- the care positions match by construction --
+// so the class filter bounds them by seed_size x (largest class score), a valid upper bound that costs no lookup, and the record's
+// 64 left bases are the ones IN FRONT of the seed: pos - 1, pos - 2, ...  With 45 flank bases (64 minus the 19 of 12of19) 2.5 % of
+// random hits were still alive at the end of the left context; with 64: 0.23 % (half as many hits forwarded to the second level).
 struct CtxRec {
     uint32_t pos;             // seed START position in the target (+ seed_size = anchor)
     uint32_t r[3];            // 48 bases right of the anchor (anchor+k in bits 2k..2k+1 of the 96-bit string)
-    uint32_t l[4];            // ~(64 bases left of the anchor, base anchor-1-k in bits 2k..2k+1 of the 128-bit string)
+    uint32_t l[4];            // ~(64 bases left of the SEED START, base pos-1-k in bits 2k..2k+1 of the 128-bit string)
 };
 static_assert(sizeof(CtxRec) == 32, "CtxRec is a 32-byte record");
 
@@ -106,6 +111,7 @@ struct ExtendArgs {
     int xdrop;
     int hspthresh;
     int noentropy;
+    uint32_t left_skip;       // bases of the seed window the class filter bounds instead of walking (CtxRec): seed_size, or 0 (option ctx_skip_seed = 0: round 4's layout)
     int log4_double;          // entropy divisor: 0 = (double)logf(4.0f), what the reference's `log(4.0f)` is under nvcc (hazard H2); 1 = log(4.0)
     int entropy_ulps;         // tests (hazard H13): the entropy factor moved by this many ulps (nextafter) before it is used
     int fin_batch;            // finished lanes a wave accumulates before it finalises + refills them

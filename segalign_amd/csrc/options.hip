@@ -19,6 +19,7 @@ int g_sub_mat[64];
 int g_xdrop = 910, g_hspthresh = 3000, g_noentropy = 0;
 int g_log4_double = 0, g_entropy_ulps = 0;
 int g_table_scratch_arena = 1;  // option table_scratch_arena
+int g_ctx_skip_seed = 1;        // option ctx_skip_seed
 int64_t g_max_seeds = 0;
 int64_t g_max_hits = 0;
 bool g_max_hits_overridden = false;
@@ -118,6 +119,7 @@ static Option g_opts[] = {
     {"key_order_chunks", 200, 1, SA_MAX_CHUNKS, 0},    // chunks sa_get_chunks_per_call() hands to one call when key-ordered calls are on (a call's positions per key set the record reuse)
     {"key_order_hits", 3ll << 30, 1 << 20, 1ll << 34, 0},  // ... capped so that a call stays below about this many seed hits (its lists are sized by them)
     {"key_order_min_pos", 0, 0, 1ll << 31, 0},         // positions a call must hold to go key-ordered under key_order = 1 (0: the number of seed keys)
+    {"ctx_skip_seed", 1, 0, 1, 0},                     // context records hold the 64 bases in FRONT of the seed window, which the class filter bounds by seed_size x the largest class score (kernels.h CtxRec); 0: round 4's layout, the 64 bases left of the anchor (A/B)
     {"table_scratch_arena", 1, 0, 1, 0},               // scratch of the seed table build (keys, pair arrays: ~10 GB per 500 Mbp block) carved from the mapped table arena instead of fresh hipMallocs (first-touch page clearing inside every GenerateSeedPosTable)
     {"log4_double", 0, 0, 1, 0},                       // entropy divisor (src/seed_filter.cu:623, hazard H2): 0 = (double)logf(4.0f) as nvcc compiles `log(4.0f)`, 1 = log(4.0) (a host compiler without <cmath>'s float overload in scope)
     {"entropy_ulps", 0, -4, 4, 1},                     // tests (hazard H13): entropy factor moved by this many ulps before the truncating multiplies
@@ -177,6 +179,7 @@ void resolve_options() {
     g_call_hits = opt_value("call_hits");
     g_call_hits_max = opt_value("call_hits_max");
     g_table_scratch_arena = (int)opt_value("table_scratch_arena");
+    g_ctx_skip_seed = (int)opt_value("ctx_skip_seed");
     g_log4_double = (int)opt_value("log4_double");
     g_entropy_ulps = (int)opt_value("entropy_ulps");
     g_ctx = opt_value("no_ctx") ? 0 : 1;

@@ -38,7 +38,7 @@ void launch_nbr_fill(const uint32_t* bucket_start, const uint32_t* pos_table, ui
 // the table as context records (kernels.h CtxRec); scratch: room for num_index records (nullptr: every entry cuts its context out
 // of the target itself)
 void launch_nbr_fill_ctx(const uint32_t* bucket_start, const uint32_t* pos_table, uint32_t nkeys, uint32_t tmask, int weight,
-                         const uint64_t* nbr_start, const uint8_t* ref2, size_t ref2_stride, uint32_t seed_size, CtxRec* ctx,
+                         const uint64_t* nbr_start, const uint8_t* ref2, size_t ref2_stride, uint32_t seed_size, uint32_t left_skip, CtxRec* ctx,
                          CtxRec* scratch, uint32_t num_index, hipStream_t s);
 
 // position probe of n = end - start query positions; t_off/t_cnt: n entries of scratch; c_rec: n + 1 records

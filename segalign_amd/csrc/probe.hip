@@ -74,24 +74,29 @@ __device__ __forceinline__ uint32_t fieldrev16(uint32_t v) {
     const uint32_t r = __builtin_bitreverse32(v);
     return ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
 }
-// the anchor's [-64, +64) bases are 32 contiguous bytes of ONE overlapped line of copy `anchor & 3` of the 2-bit target (encode.hip)
-__device__ __forceinline__ void cut_ctx(const uint8_t* __restrict__ ref2, size_t ref2_stride, uint32_t pos, uint32_t seed_size, uint4& c0, uint4& c1) {
+// the 48 bases from the anchor on are 12 bytes of copy `anchor & 3` of the 2-bit target, the 64 bases in front of the seed start 16
+// bytes of copy `pos & 3` (encode.hip: a window that starts or ends at ANY base is byte aligned in the copy of its phase; a span of
+// up to 32 bytes lies inside the overlapped line chosen for its first byte)
+__device__ __forceinline__ void cut_ctx(const uint8_t* __restrict__ ref2, size_t ref2_stride, uint32_t pos, uint32_t seed_size, uint32_t left_skip, uint4& c0, uint4& c1) {
     const uint32_t anchor = pos + seed_size;                    // :220
     const uint32_t jj0 = (anchor >> 2) + (uint32_t)PACK2_BIAS;  // logical byte of the anchor's 4-base group in copy anchor & 3
-    const uint32_t line = (jj0 - 16u) / (uint32_t)PACK2_PAYLOAD;
-    const uint8_t* tp = ref2 + (size_t)(anchor & 3u) * ref2_stride + (jj0 + 32u * line);
-    const uint4 rw = load16u(tp), lw = load16u(tp - 16);
+    const uint8_t* tp = ref2 + (size_t)(anchor & 3u) * ref2_stride + (jj0 + 32u * (jj0 / (uint32_t)PACK2_PAYLOAD));
+    const uint4 rw = load16u(tp);
+    const uint32_t lend = anchor - left_skip;  // the left context ends in front of this base: the seed start (left_skip = seed_size), or the anchor (0)
+    const uint32_t jjl = (lend >> 2) + (uint32_t)PACK2_BIAS - 16u;  // first of the 16 bytes below its group in copy lend & 3
+    const uint8_t* lp = ref2 + (size_t)(lend & 3u) * ref2_stride + (jjl + 32u * (jjl / (uint32_t)PACK2_PAYLOAD));
+    const uint4 lw = load16u(lp);
     c0 = make_uint4(pos, rw.x, rw.y, rw.z);
-    // bases anchor-1 .. anchor-64 in walking order, complemented (CtxRec)
+    // bases lend-1 .. lend-64 in walking order, complemented (CtxRec)
     c1 = make_uint4(~fieldrev16(lw.w), ~fieldrev16(lw.z), ~fieldrev16(lw.y), ~fieldrev16(lw.x));
 }
 // stage 1: the context of every seed position ONCE, in pos_table order (one random target line per position)
 __global__ __launch_bounds__(256) void ctx_by_index_kernel(const uint32_t* __restrict__ pos_table, uint32_t num_index,
-                                                           const uint8_t* __restrict__ ref2, size_t ref2_stride, uint32_t seed_size,
+                                                           const uint8_t* __restrict__ ref2, size_t ref2_stride, uint32_t seed_size, uint32_t left_skip,
                                                            uint4* __restrict__ out /* 2 x uint4 per position */) {
     for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < num_index; id += gridDim.x * blockDim.x) {
         uint4 c0, c1;
-        cut_ctx(ref2, ref2_stride, pos_table[id], seed_size, c0, c1);
+        cut_ctx(ref2, ref2_stride, pos_table[id], seed_size, left_skip, c0, c1);
         out[2 * (size_t)id] = c0;
         out[2 * (size_t)id + 1] = c1;
     }
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(256) void nbr_copy_ctx_sparse_kernel(const uint32_t
 // one-stage form (no scratch): every table entry cuts its own context out of the target
 __global__ __launch_bounds__(256) void nbr_fill_ctx_kernel(const uint32_t* __restrict__ bucket_start, const uint32_t* __restrict__ pos_table,
                                                            uint32_t nkeys, uint32_t tmask, int weight, const uint64_t* __restrict__ nbr_start,
-                                                           const uint8_t* __restrict__ ref2, size_t ref2_stride, uint32_t seed_size,
+                                                           const uint8_t* __restrict__ ref2, size_t ref2_stride, uint32_t seed_size, uint32_t left_skip,
                                                            uint4* __restrict__ ctx) {
     const uint32_t gl = threadIdx.x & (NBR_GROUP - 1);
     const uint32_t groups = gridDim.x * (blockDim.x / NBR_GROUP);
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(256) void nbr_fill_ctx_kernel(const uint32_t* __res
             const uint32_t b = bucket_start[kk], n = bucket_start[kk + 1] - b;
             for (uint32_t i = gl; i < n; i += NBR_GROUP) {
                 uint4 c0, c1;
-                cut_ctx(ref2, ref2_stride, pos_table[b + i], seed_size, c0, c1);
+                cut_ctx(ref2, ref2_stride, pos_table[b + i], seed_size, left_skip, c0, c1);
                 ctx[2 * (o + i)] = c0;
                 ctx[2 * (o + i) + 1] = c1;
             }
@@ -192,10 +197,10 @@ __global__ __launch_bounds__(256) void nbr_fill_ctx_kernel(const uint32_t* __res
 }
 
 void launch_nbr_fill_ctx(const uint32_t* bucket_start, const uint32_t* pos_table, uint32_t nkeys, uint32_t tmask, int weight,
-                         const uint64_t* nbr_start, const uint8_t* ref2, size_t ref2_stride, uint32_t seed_size, CtxRec* ctx,
+                         const uint64_t* nbr_start, const uint8_t* ref2, size_t ref2_stride, uint32_t seed_size, uint32_t left_skip, CtxRec* ctx,
                          CtxRec* scratch, uint32_t num_index, hipStream_t s) {
     if (scratch) {
-        hipLaunchKernelGGL(ctx_by_index_kernel, dim3(8192), dim3(256), 0, s, pos_table, num_index, ref2, ref2_stride, seed_size,
+        hipLaunchKernelGGL(ctx_by_index_kernel, dim3(8192), dim3(256), 0, s, pos_table, num_index, ref2, ref2_stride, seed_size, left_skip,
                            reinterpret_cast<uint4*>(scratch));
         if (num_index < nkeys)  // (less than one position per bucket: a lane per key)
             hipLaunchKernelGGL(nbr_copy_ctx_sparse_kernel, dim3(8192), dim3(256), 0, s, bucket_start, nkeys, tmask, weight, nbr_start,
@@ -206,7 +211,7 @@ void launch_nbr_fill_ctx(const uint32_t* bucket_start, const uint32_t* pos_table
         return;
     }
     hipLaunchKernelGGL(nbr_fill_ctx_kernel, dim3(8192), dim3(256), 0, s, bucket_start, pos_table, nkeys, tmask, weight, nbr_start, ref2,
-                       ref2_stride, seed_size, reinterpret_cast<uint4*>(ctx));
+                       ref2_stride, seed_size, left_skip, reinterpret_cast<uint4*>(ctx));
 }
 
 void launch_nbr_count(const uint32_t* bucket_start, uint32_t nkeys, uint32_t tmask, int weight, uint32_t* cnt, uint32_t* overflow,

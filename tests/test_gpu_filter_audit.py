@@ -73,3 +73,41 @@ def test_filters_on_a_multi_chunk_call_with_iupac_and_low_thresholds(oracle, aud
     c = Case(t, q, chunk=8000, xdrop=500, hspthresh=2200).oracle_setup(oracle).engine_setup(audited)
     n = audit_case(oracle, audited, c, chunks_per_call=16, strands=(False,) if in_query else (False, True))
     assert n > 5000
+
+
+def test_both_context_layouts_reject_nothing_that_passes(oracle, audited):
+    """Round 5's context records hold the 64 bases in FRONT of the seed window, which the class filter bounds by seed_size x the
+    largest class score instead of walking it (kernels.h CtxRec); option ctx_skip_seed = 0 is round 4's layout (the 64 bases left of
+    the anchor, seed window included).  Same vectors, every rejected hit audited under both -- near the block start too, where the
+    longer reach of the new left context runs into the pad --, with other seed sizes (14of22: a 22-base window), and the new layout
+    never forwards more hits to the second level (on a 100 Mbp target, where chance hits dominate: half as many, profiles/r05)."""
+    t, q = synth.make_pair(240000, 91, 92, sub_rate=0.10, mask_frac=0.15, records=2, indel_every=200, n_runs=2)
+    q = q.copy()
+    q[:400] = t[:400]            # homology that touches position 0 of both blocks: left walks end at the block edge
+    fwd = {}
+    for skip in (1, 0):
+        audited.ShutdownProcessor()
+        audited.set_option("ctx_skip_seed", skip)
+        c = Case(t, q, chunk=60000).oracle_setup(oracle).engine_setup(audited)
+        assert audited.lookup_mode() == 2
+        n = audit_case(oracle, audited, c, chunks_per_call=2)
+        assert n > 50000
+        tot_f = tot_h = 0
+        for rev in (False, True):
+            for (s, e) in c.chunks():
+                audited.SeedAndFilterRange(s, e, rev, 0)
+                st = audited.last_call_stats()
+                tot_f += st["num_forwarded"]
+                tot_h += st["num_hits"]
+        fwd[skip] = tot_f / max(tot_h, 1)
+    assert fwd[1] <= fwd[0], fwd  # (a 240 kbp target: most hits are homologous and forwarded under either layout)
+    # another seed window: 14of22 (src/main.cpp:164-167), transitions on
+    import re
+    src = open(__file__.replace("test_gpu_filter_audit.py", "test_gpu_edge_cases.py")).read()
+    shape22 = re.search(r'"([T0]{22})"', src).group(1)
+    audited.ShutdownProcessor()
+    audited.set_option("ctx_skip_seed", 1)
+    t2, q2 = synth.make_pair(120000, 93, 94, sub_rate=0.08, mask_frac=0.1, indel_every=300)
+    c = Case(t2, q2, chunk=60000, shape=shape22).oracle_setup(oracle).engine_setup(audited)
+    if audited.lookup_mode() == 2:
+        assert audit_case(oracle, audited, c) > 1000

@@ -1041,8 +1041,18 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(E
         // (lanes past the call's last hit stay on the last record and run up to 63 entries past its run: still inside the table
         //  allocation -- the engine keeps a page of slack behind it -- and their verdict is discarded)
         const uint64_t entry = hnext.off + (uint64_t)((uint32_t)(b << 6) + (uint32_t)lane - hnext.prefix);  // run offset + index inside the run
+#ifdef SA_EXP_REC28  // EXPERIMENT (tools/r05_exp28.sh; timing only, the bytes read are not a record): what would 28-byte records buy?
+        {
+            const uint8_t* rp = reinterpret_cast<const uint8_t*>(ctx) + entry * 28ull;
+            __builtin_memcpy(&S.c0, __builtin_assume_aligned(rp, 4), 16);
+            uint3 t3;
+            __builtin_memcpy(&t3, __builtin_assume_aligned(rp + 16, 4), 12);
+            S.tl = make_uint4(t3.x, t3.y, t3.z, 0u);
+        }
+#else
         S.c0 = ctx[2 * entry];  // two aligned 16-byte loads: the stream of the kernel
         S.tl = ctx[2 * entry + 1];
+#endif
         const uint32_t query_loc = hnext.qpos + a.seed_size;  // :204
         S.query_loc = query_loc;
         // copy (pos & 3, (pos >> 2) & 3) = copy number pos & 15, dword pos >> 4 (encode.hip); strides are multiples of 16 bytes, so

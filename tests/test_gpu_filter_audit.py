@@ -36,6 +36,8 @@ def audit_case(O, E, c, chunks_per_call=1, strands=(False, True)):
                 outs = E.SeedAndFilterChunks(grp[0][0], grp[-1][1], rev, 0)
             for got, want in zip(outs, wants):
                 assert seg_equal(got, want)
+            if int(E.last_call_stats()["num_hits"]) == 0:
+                continue  # (a call without hits never starts the filter: the audit list still holds the previous call's)
             pairs, n = E.get_audit()
             assert n == pairs.shape[0], "audit list overflowed: raise audit_cap"
             assert n <= int(E.last_call_stats()["num_hits"])

@@ -833,7 +833,7 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
                     } else if (SRC == SRC_CAND && mine_flags == 2u) {  // right side settled; the left walk continues behind level 1's context:
                         bestR = (int)mine_known;                          // the seed window (bounded there) + the 64 bases in front of it
                         phase = PH_LEFT;
-                        walked = 64u + a.left_skip;
+                        walked = (uint32_t)CTX_L_BASES + a.left_skip;
                         const short t16 = (short)(mine_tm & 0xFFFFu), m16 = (short)(mine_tm >> 16);
                         T = (s16x2){t16, t16};
                         M = (s16x2){m16, m16};
@@ -1025,9 +1025,17 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(E
         return idx;
     };
     struct Stage {
-        uint4 c0, tl, ql;  // c0 = {seed position, right context}, tl = left context (CtxRec); ql = the query's left window
-        uint32_t qr0, qr1, qr2;
+        uint4 c0, tl;      // the record (CtxRec): c0.x = seed position, c0.y .. tl.w = its 224-bit context string
+        uint32_t q[7];     // the query's side of that string: 54 bases of this strand from the anchor on, then 58 of the other strand
         uint32_t query_loc;
+    };
+    // the query string out of the two windows: qr = 4 dwords from the anchor on (this strand), ql = 4 dwords of the other strand's window
+    auto merge_q = [&](Stage& S, uint32_t qr0, uint32_t qr1, uint32_t qr2, uint32_t qr3, uint32_t ql0, uint32_t ql1, uint32_t ql2, uint32_t ql3) {
+        S.q[0] = qr0; S.q[1] = qr1; S.q[2] = qr2;
+        S.q[3] = (qr3 & 0xFFFu) | (ql0 << 12);  // bits 96..107: right bases 48..53; from bit 108 on: the left window
+        S.q[4] = __builtin_amdgcn_alignbit(ql1, ql0, 20);
+        S.q[5] = __builtin_amdgcn_alignbit(ql2, ql1, 20);
+        S.q[6] = __builtin_amdgcn_alignbit(ql3, ql2, 20);
     };
     uint64_t w0, w1, w2;  // head words of the buffers one, two and three ahead of the one being requested
     TdRec hnext;          // TdRec of this lane's hit in the NEXT buffer to be requested
@@ -1063,28 +1071,27 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(E
             // copy 0: dword j holds bases [16 j, 16 j + 16), base 16 j + k in bits 2k, 2k + 1; the window at position p is the bit string
             // from bit 2 (p & 15) of dword p >> 4 on: one more dword per side and a funnel shift per dword
             uint4 t;
-            __builtin_memcpy(&t, __builtin_assume_aligned(a.q2_own + ((query_loc >> 4) << 2), 4), 16);
+            uint32_t t4;
+            const uint8_t* rpp = a.q2_own + ((query_loc >> 4) << 2);
+            __builtin_memcpy(&t, __builtin_assume_aligned(rpp, 4), 16);
+            __builtin_memcpy(&t4, __builtin_assume_aligned(rpp + 16, 4), 4);
             const uint32_t sr = (query_loc & 15u) << 1;
-            S.qr0 = __builtin_amdgcn_alignbit(t.y, t.x, sr);
-            S.qr1 = __builtin_amdgcn_alignbit(t.z, t.y, sr);
-            S.qr2 = __builtin_amdgcn_alignbit(t.w, t.z, sr);
             uint4 u;
             uint32_t u4;
             const uint8_t* lpp = a.q2_other + ((lp >> 4) << 2);
             __builtin_memcpy(&u, __builtin_assume_aligned(lpp, 4), 16);
             __builtin_memcpy(&u4, __builtin_assume_aligned(lpp + 16, 4), 4);
             const uint32_t sl = (lp & 15u) << 1;
-            S.ql.x = __builtin_amdgcn_alignbit(u.y, u.x, sl);
-            S.ql.y = __builtin_amdgcn_alignbit(u.z, u.y, sl);
-            S.ql.z = __builtin_amdgcn_alignbit(u.w, u.z, sl);
-            S.ql.w = __builtin_amdgcn_alignbit(u4, u.w, sl);
+            merge_q(S, __builtin_amdgcn_alignbit(t.y, t.x, sr), __builtin_amdgcn_alignbit(t.z, t.y, sr), __builtin_amdgcn_alignbit(t.w, t.z, sr),
+                    __builtin_amdgcn_alignbit(t4, t.w, sr), __builtin_amdgcn_alignbit(u.y, u.x, sl), __builtin_amdgcn_alignbit(u.z, u.y, sl),
+                    __builtin_amdgcn_alignbit(u.w, u.z, sl), __builtin_amdgcn_alignbit(u4, u.w, sl));
         } else {
             const uint32_t po = (mul24(query_loc & 15u, stride16) << 4) + ((query_loc >> 4) << 2);
-            uint3 t;
-            __builtin_memcpy(&t, __builtin_assume_aligned(a.q2_own + po, 4), 12);
-            S.qr0 = t.x; S.qr1 = t.y; S.qr2 = t.z;
+            uint4 t, u;
+            __builtin_memcpy(&t, __builtin_assume_aligned(a.q2_own + po, 4), 16);
             const uint32_t qo = (mul24(lp & 15u, stride16) << 4) + ((lp >> 4) << 2);
-            __builtin_memcpy(&S.ql, __builtin_assume_aligned(a.q2_other + qo, 4), 16);
+            __builtin_memcpy(&u, __builtin_assume_aligned(a.q2_other + qo, 4), 16);
+            merge_q(S, t.x, t.y, t.z, t.w, u.x, u.y, u.z, u.w);
         }
     };
     auto score = [&](uint64_t b, const Stage& S) {
@@ -1093,10 +1100,10 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(E
         const uint32_t ref_loc = S.c0.x + a.seed_size;  // :220
         bool skip = !valid;
         if (a.rm) skip = skip || !(ref_loc >= a.rm_win_start && ref_loc <= a.rm_win_end);  // rm :239-244,:305-333: total stays 0
-        // ---- class strings ----
-        const uint32_t x0 = S.c0.y ^ S.qr0, x1 = S.c0.z ^ S.qr1, x2 = S.c0.w ^ S.qr2;
-        const uint32_t y0 = S.tl.x ^ S.ql.x, y1 = S.tl.y ^ S.ql.y, y2 = S.tl.z ^ S.ql.z, y3 = S.tl.w ^ S.ql.w;
-        // ---- right side (:326-453): 48 bases = 8 fields ----
+        // ---- the class string: 18 six-base fields (9 right, 9 left) and the left side's four-base tail ----
+        const uint32_t x0 = S.c0.y ^ S.q[0], x1 = S.c0.z ^ S.q[1], x2 = S.c0.w ^ S.q[2], x3 = S.tl.x ^ S.q[3], x4 = S.tl.y ^ S.q[4],
+                       x5 = S.tl.z ^ S.q[5], x6 = S.tl.w ^ S.q[6];
+        // ---- right side (:326-453): 54 bases = 9 fields ----
         uint32_t P = 0, Wd = 0;
         cls_step(s_cls, cls_field_addr<0>(x0, x1), P, Wd);
         cls_step(s_cls, cls_field_addr<12>(x0, x1), P, Wd);
@@ -1104,24 +1111,24 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(E
         cls_step(s_cls, cls_field_addr<4>(x1, x2), P, Wd);
         cls_step(s_cls, cls_field_addr<16>(x1, x2), P, Wd);
         cls_step(s_cls, cls_field_addr<28>(x1, x2), P, Wd);
-        cls_step(s_cls, cls_field_addr<8>(x2, 0u), P, Wd);
-        cls_step(s_cls, cls_field_addr<20>(x2, 0u), P, Wd);
+        cls_step(s_cls, cls_field_addr<8>(x2, x3), P, Wd);
+        cls_step(s_cls, cls_field_addr<20>(x2, x3), P, Wd);
+        cls_step(s_cls, cls_field_addr<0>(x3, x4), P, Wd);
         // alive: never more than xdrop below its best at a field end (:374; without W: at the end of the context)
         const bool r_alive = (int)(short)((CLS_TRACK_DROP ? Wd : P) & 0xFFFFu) >= -xdrop;
         const int bestR = ((int)P >> 16) - (int)(short)(P & 0xFFFFu);  // best = T - N
-        // ---- left side (:478-604): the seed window bounded by seed_bound (no lookup), then 64 bases = 10 fields + a four-base tail ----
+        // ---- left side (:478-604): the seed window bounded by seed_state (no lookup), then 58 bases = 9 fields + a four-base tail ----
         P = seed_state; Wd = 0;
-        cls_step(s_cls, cls_field_addr<0>(y0, y1), P, Wd);
-        cls_step(s_cls, cls_field_addr<12>(y0, y1), P, Wd);
-        cls_step(s_cls, cls_field_addr<24>(y0, y1), P, Wd);
-        cls_step(s_cls, cls_field_addr<4>(y1, y2), P, Wd);
-        cls_step(s_cls, cls_field_addr<16>(y1, y2), P, Wd);
-        cls_step(s_cls, cls_field_addr<28>(y1, y2), P, Wd);
-        cls_step(s_cls, cls_field_addr<8>(y2, y3), P, Wd);
-        cls_step(s_cls, cls_field_addr<20>(y2, y3), P, Wd);
-        cls_step(s_cls, cls_field_addr<0>(y3, 0u), P, Wd);
-        cls_step(s_cls, cls_field_addr<12>(y3, 0u), P, Wd);
-        cls_step(s_tail, (y3 >> 22) & 0x3FCu, P, Wd);
+        cls_step(s_cls, cls_field_addr<12>(x3, x4), P, Wd);
+        cls_step(s_cls, cls_field_addr<24>(x3, x4), P, Wd);
+        cls_step(s_cls, cls_field_addr<4>(x4, x5), P, Wd);
+        cls_step(s_cls, cls_field_addr<16>(x4, x5), P, Wd);
+        cls_step(s_cls, cls_field_addr<28>(x4, x5), P, Wd);
+        cls_step(s_cls, cls_field_addr<8>(x5, x6), P, Wd);
+        cls_step(s_cls, cls_field_addr<20>(x5, x6), P, Wd);
+        cls_step(s_cls, cls_field_addr<0>(x6, 0u), P, Wd);
+        cls_step(s_cls, cls_field_addr<12>(x6, 0u), P, Wd);
+        cls_step(s_tail, (x6 >> 22) & 0x3FCu, P, Wd);
         const bool l_alive = (int)(short)((CLS_TRACK_DROP ? Wd : P) & 0xFFFFu) >= -xdrop;  // (:523)
         const int bestL = ((int)P >> 16) - (int)(short)(P & 0xFFFFu);
         const bool fwd = !skip && (r_alive || l_alive || classify(a, bestR + bestL) != 0);
@@ -1204,7 +1211,7 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(E
 // Table, walk state, verdicts and the L2Rec hand-over are those of 1d (the four-base tail table included), so both forms forward the
 // same hits with the same state; L2Rec::hidx is the hit's entry index inside its run (ExtendArgs::join).
 constexpr int JOIN_THREADS = 1024;
-constexpr int JOIN_NFR = 8, JOIN_NFL = 11;  // lookups of the right / left walk (the left one ends with the tail field)
+constexpr int JOIN_NFR = 9, JOIN_NFL = 10;  // lookups of the right / left walk (the left one ends with the tail field): CtxRec's cut
 
 __global__ __launch_bounds__(JOIN_THREADS, 8) void join_filter_kernel(ExtendArgs a, JoinArgs jn) {
     __shared__ __attribute__((aligned(16))) uint32_t s_cls[CLS_LDS_DWORDS];
@@ -1282,20 +1289,14 @@ __global__ __launch_bounds__(JOIN_THREADS, 8) void join_filter_kernel(ExtendArgs
                 // the record's field words, once per tile
                 uint32_t tf[JOIN_NFR + JOIN_NFL];
                 {
-                    const uint32_t r[3] = {c0.y, c0.z, c0.w}, l[4] = {tl.x, tl.y, tl.z, tl.w};
+                    const uint32_t w[7] = {c0.y, c0.z, c0.w, tl.x, tl.y, tl.z, tl.w};  // the 224-bit context string (CtxRec)
 #pragma unroll
-                    for (int k = 0; k < JOIN_NFR; k++) {
+                    for (int k = 0; k < JOIN_NFR + JOIN_NFL - 1; k++) {
                         const int bit = 12 * k, d = bit >> 5, o = bit & 31;
-                        const uint64_t two = (uint64_t)r[d] | ((uint64_t)(d + 1 < 3 ? r[d + 1 < 3 ? d + 1 : d] : 0u) << 32);
+                        const uint64_t two = (uint64_t)w[d] | ((uint64_t)(d + 1 < 7 ? w[d + 1 < 7 ? d + 1 : d] : 0u) << 32);
                         tf[k] = (uint32_t)((two >> o) << 2) & 0x3FFCu;
                     }
-#pragma unroll
-                    for (int k = 0; k < JOIN_NFL - 1; k++) {
-                        const int bit = 12 * k, d = bit >> 5, o = bit & 31;
-                        const uint64_t two = (uint64_t)l[d] | ((uint64_t)(d + 1 < 4 ? l[d + 1 < 4 ? d + 1 : d] : 0u) << 32);
-                        tf[JOIN_NFR + k] = (uint32_t)((two >> o) << 2) & 0x3FFCu;
-                    }
-                    tf[JOIN_NFR + JOIN_NFL - 1] = ((l[3] >> 22) & 0x3FCu) | JOIN_TAIL_OFF;
+                    tf[JOIN_NFR + JOIN_NFL - 1] = ((w[6] >> 22) & 0x3FCu) | JOIN_TAIL_OFF;
                 }
                 const uint32_t* __restrict__ qp = jn.qx + (size_t)en.z * JOIN_QX_DW;
                 for (int qi = 0; qi < c; qi++, qp += JOIN_QX_DW) {
@@ -1307,7 +1308,7 @@ __global__ __launch_bounds__(JOIN_THREADS, 8) void join_filter_kernel(ExtendArgs
                     }
                     uint32_t PR = 0, WR = 0, PL = seed_state, WL = 0;
 #pragma unroll
-                    for (int k = 0; k < JOIN_NFL; k++) {
+                    for (int k = 0; k < JOIN_NFL; k++) {  // (the two walks interleaved: independent dependency chains)
                         if (k < JOIN_NFR) cls_step(s_cls, tf[k] ^ q[1 + k], PR, WR);
                         cls_step(s_cls, tf[JOIN_NFR + k] ^ q[1 + JOIN_NFR + k], PL, WL);
                     }

@@ -204,30 +204,29 @@ __global__ __launch_bounds__(256) void join_qx_kernel(const uint32_t* __restrict
         const uint32_t query_loc = p + seed_size;  // :204
         // the windows out of the unshifted 2-bit copies (extend.hip 1d, ONE_COPY): 48 bases from query_loc on this strand, 64 bases from
         // len - query_loc + seed_size on the other strand (= the bases left of the SEED in walking order, complemented: CtxRec)
-        const uint4 t = jload16(q2_own + ((query_loc >> 4) << 2));
+        const uint8_t* rpp = q2_own + ((query_loc >> 4) << 2);
+        const uint4 t = jload16(rpp);
+        uint32_t t4;
+        __builtin_memcpy(&t4, __builtin_assume_aligned(rpp + 16, 4), 4);
         const uint32_t sr = (query_loc & 15u) << 1;
-        uint32_t r[3];
-        r[0] = __builtin_amdgcn_alignbit(t.y, t.x, sr);
-        r[1] = __builtin_amdgcn_alignbit(t.z, t.y, sr);
-        r[2] = __builtin_amdgcn_alignbit(t.w, t.z, sr);
+        const uint32_t r0 = __builtin_amdgcn_alignbit(t.y, t.x, sr), r1 = __builtin_amdgcn_alignbit(t.z, t.y, sr), r2 = __builtin_amdgcn_alignbit(t.w, t.z, sr),
+                       r3 = __builtin_amdgcn_alignbit(t4, t.w, sr);
         const uint32_t lp = query_len - query_loc + left_skip;  // (the left context starts in front of the seed: CtxRec)
         const uint8_t* lpp = q2_other + ((lp >> 4) << 2);
         const uint4 u = jload16(lpp);
         uint32_t u4;
         __builtin_memcpy(&u4, __builtin_assume_aligned(lpp + 16, 4), 4);
         const uint32_t sl = (lp & 15u) << 1;
-        uint32_t l[4];
-        l[0] = __builtin_amdgcn_alignbit(u.y, u.x, sl);
-        l[1] = __builtin_amdgcn_alignbit(u.z, u.y, sl);
-        l[2] = __builtin_amdgcn_alignbit(u.w, u.z, sl);
-        l[3] = __builtin_amdgcn_alignbit(u4, u.w, sl);
+        const uint32_t l0 = __builtin_amdgcn_alignbit(u.y, u.x, sl), l1 = __builtin_amdgcn_alignbit(u.z, u.y, sl), l2 = __builtin_amdgcn_alignbit(u.w, u.z, sl),
+                       l3 = __builtin_amdgcn_alignbit(u4, u.w, sl);
+        // the query's side of the record's 224-bit string (CtxRec: 54 bases of this strand, then 58 of the other), and its field words
+        const uint32_t w[7] = {r0, r1, r2, (r3 & 0xFFFu) | (l0 << 12), __builtin_amdgcn_alignbit(l1, l0, 20), __builtin_amdgcn_alignbit(l2, l1, 20),
+                               __builtin_amdgcn_alignbit(l3, l2, 20)};
         uint32_t o[JOIN_QX_DW];
         o[0] = p;
 #pragma unroll
-        for (int k = 0; k < 8; k++) o[1 + k] = jfield6(r, 3, 12 * k);
-#pragma unroll
-        for (int k = 0; k < 10; k++) o[9 + k] = jfield6(l, 4, 12 * k);
-        o[19] = (l[3] >> 22) & 0x3FCu;  // the four-base tail field (its table offset is on the record side)
+        for (int k = 0; k < 18; k++) o[1 + k] = jfield6(w, 7, 12 * k);
+        o[19] = (w[6] >> 22) & 0x3FCu;  // the four-base tail field (its table offset is on the record side)
         uint4* dst = reinterpret_cast<uint4*>(qx + (size_t)i * JOIN_QX_DW);
 #pragma unroll
         for (int k = 0; k < JOIN_QX_DW / 4; k++) dst[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);

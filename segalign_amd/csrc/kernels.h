@@ -88,10 +88,15 @@ struct TdRec {                // table-direct lookup (probe.hip): a non-empty qu
 // so the class filter bounds them by seed_size x (largest class score), a valid upper bound that costs no lookup, and the record's
 // 64 left bases are the ones IN FRONT of the seed: pos - 1, pos - 2, ...  With 45 flank bases (64 minus the 19 of 12of19) 2.5 % of
 // random hits were still alive at the end of the left context; with 64: 0.23 % (half as many hits forwarded to the second level).
+// The 112 context bases are cut 54 right + 58 left (round 5; rounds 2-4: 48 + 64): with the seed window out of the left context both
+// sides walk pure flank, the share of random hits still alive after n flank bases falls steeply and convexly in n (48: 1.8 %, 54:
+// 0.84 %, 58: 0.48 %, 64: 0.22 %), so an even split forwards least -- 54 + 58 keeps whole six-base fields: nine on the right, nine
+// and the four-base tail on the left, one 224-bit string of eighteen 12-bit fields and an 8-bit tail.
+constexpr int CTX_R_BASES = 54, CTX_L_BASES = 58;
 struct CtxRec {
     uint32_t pos;             // seed START position in the target (+ seed_size = anchor)
-    uint32_t r[3];            // 48 bases right of the anchor (anchor+k in bits 2k..2k+1 of the 96-bit string)
-    uint32_t l[4];            // ~(64 bases left of the SEED START, base pos-1-k in bits 2k..2k+1 of the 128-bit string)
+    uint32_t w[7];            // bits 0..107: the 54 bases from the anchor on (anchor+k in bits 2k, 2k+1); bits 108..223: ~(the 58 bases in
+                              // front of the seed start, base pos-1-k in bits 108+2k, 108+2k+1)
 };
 static_assert(sizeof(CtxRec) == 32, "CtxRec is a 32-byte record");
 

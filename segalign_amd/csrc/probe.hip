@@ -86,9 +86,13 @@ __device__ __forceinline__ void cut_ctx(const uint8_t* __restrict__ ref2, size_t
     const uint32_t jjl = (lend >> 2) + (uint32_t)PACK2_BIAS - 16u;  // first of the 16 bytes below its group in copy lend & 3
     const uint8_t* lp = ref2 + (size_t)(lend & 3u) * ref2_stride + (jjl + 32u * (jjl / (uint32_t)PACK2_PAYLOAD));
     const uint4 lw = load16u(lp);
+    // bases lend-1 .. lend-64 in walking order, complemented; the record takes the first CTX_L_BASES of them behind the CTX_R_BASES
+    // right bases: one 224-bit string (CtxRec)
+    const uint32_t l0 = ~fieldrev16(lw.w), l1 = ~fieldrev16(lw.z), l2 = ~fieldrev16(lw.y), l3 = ~fieldrev16(lw.x);
+    static_assert(CTX_R_BASES == 54 && CTX_L_BASES == 58, "the record's cut: 108 + 116 bits");
     c0 = make_uint4(pos, rw.x, rw.y, rw.z);
-    // bases lend-1 .. lend-64 in walking order, complemented (CtxRec)
-    c1 = make_uint4(~fieldrev16(lw.w), ~fieldrev16(lw.z), ~fieldrev16(lw.y), ~fieldrev16(lw.x));
+    c1 = make_uint4((rw.w & 0xFFFu) | (l0 << 12), __builtin_amdgcn_alignbit(l1, l0, 20), __builtin_amdgcn_alignbit(l2, l1, 20),
+                    __builtin_amdgcn_alignbit(l3, l2, 20));
 }
 // stage 1: the context of every seed position ONCE, in pos_table order (one random target line per position)
 __global__ __launch_bounds__(256) void ctx_by_index_kernel(const uint32_t* __restrict__ pos_table, uint32_t num_index,

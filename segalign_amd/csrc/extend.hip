@@ -831,7 +831,7 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
                         best = (int)mine_tm;
                         phase = PH_FIN;
                     } else if (SRC == SRC_CAND && mine_flags == 2u) {  // right side settled; the left walk continues behind level 1's context:
-                        bestR = (int)mine_known;                          // the seed window (bounded there) + the 64 bases in front of it
+                        bestR = (int)mine_known;                          // the seed window (bounded there) + the 58 bases in front of it
                         phase = PH_LEFT;
                         walked = (uint32_t)CTX_L_BASES + a.left_skip;
                         const short t16 = (short)(mine_tm & 0xFFFFu), m16 = (short)(mine_tm >> 16);
@@ -865,7 +865,7 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
 // A filter that fetches the target per hit is priced in random 128-byte lines: one per hit, ~57 G lines/s on the whole chip
 // (tools/micro/gather_bw.hip) -- 173 M hits of a call cannot take less than ~3 ms however little arithmetic they need.  With
 // 288 GB of HBM the neighbourhood table (probe.hip) carries, next to every seed position, the 2-bit target bases the filter looks
-// at: 48 to the right of the anchor and 64 to the left (CtxRec, 32 bytes).  The hits of a call are then ONE SEQUENTIAL STREAM of
+// at: 54 from the anchor on and the 58 in front of the seed window (CtxRec, 32 bytes; rounds 2-4: 48 + the 64 left of the anchor).  The hits of a call are then ONE SEQUENTIAL STREAM of
 // records, the query windows of a wave's 64 hits are a couple of L1-resident lines, and the filter is an arithmetic kernel: every
 // hit costs the same, a wave walks its contiguous range of 64-hit buffers in lockstep, straight-line code.
 // The round-2 form of this kernel scored two bases per LDS lookup with exact pair scores: ~39 VALU + 8 LDS per 16 bases, 365 VALU
@@ -900,7 +900,7 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
 // occur in the two blocks (engine.hip).
 // Verdicts (all conservative):
 //   both sides dropped inside the context and bestR + bestL cannot pass (:608-633)   -> rejected here (~96 % of all hits)
-//   a side still alive at the end of its context (1.8 % right, 2.5 % left on random hits), or the bound passes
+//   a side still alive at the end of its context (0.8 % right, 0.5 % left on random hits; rounds 2-4: 1.8 % / 2.5 %), or the bound passes
 //        -> L2Rec (kernels.h) to the second level: kernel 1b on that list (SRC_CAND), which walks only what is still open with exact
 //           pair scores and decides between reject and the exact kernels.
 constexpr int CTX_THREADS = 1024;      // two workgroups per CU = 8 waves per SIMD; the class table is built once per 16 waves

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void join_qx_kernel(const uint32_t* __restrict
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t p = qpos[i];
         const uint32_t query_loc = p + seed_size;  // :204
-        // the windows out of the unshifted 2-bit copies (extend.hip 1d, ONE_COPY): 48 bases from query_loc on this strand, 64 bases from
+        // the windows out of the unshifted 2-bit copies (extend.hip 1d, ONE_COPY): 54 bases from query_loc on this strand, 58 bases from
         // len - query_loc + seed_size on the other strand (= the bases left of the SEED in walking order, complemented: CtxRec)
         const uint8_t* rpp = q2_own + ((query_loc >> 4) << 2);
         const uint4 t = jload16(rpp);

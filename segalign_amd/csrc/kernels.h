@@ -44,11 +44,11 @@ struct CandRec {              // a hit the X-drop filter could not reject: exten
 
 // What the class filter (level 1) hands to the second level: the anchor plus what level 1 already knows, so that level 2 walks only
 // the side(s) that were still alive at the end of the 48 + 64 context bases.  20 bytes:
-//   state: the packed (score : drop) register of level 1's LEFT walk after 64 bases (extend.hip cls_table_init)
+//   state: the packed (score : drop) register of level 1's LEFT walk at the end of its context (seed window + CTX_L_BASES; extend.hip 1d)
 //   meta : known (16 bits) | flags (2 bits) << 16
 //     flags bit 0: right side undecided, bit 1: left side undecided
 //     flags 1: known = bestL (the left side is settled), the right side is walked from the anchor
-//     flags 2: known = bestR, the left walk continues after 64 bases from `state`
+//     flags 2: known = bestR, the left walk continues behind level 1's context from `state`
 //     flags 3: both sides from the anchor (also: both settled but the bound passes -- the exact pair scores of level 2 get a say)
 struct L2Rec {
     uint32_t ref_loc, query_loc;

@@ -74,7 +74,7 @@ __device__ __forceinline__ uint32_t fieldrev16(uint32_t v) {
     const uint32_t r = __builtin_bitreverse32(v);
     return ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
 }
-// the 48 bases from the anchor on are 12 bytes of copy `anchor & 3` of the 2-bit target, the 64 bases in front of the seed start 16
+// the 54 bases from the anchor on lie in 16 bytes of copy `anchor & 3` of the 2-bit target, the 58 bases in front of the seed start in 16
 // bytes of copy `pos & 3` (encode.hip: a window that starts or ends at ANY base is byte aligned in the copy of its phase; a span of
 // up to 32 bytes lies inside the overlapped line chosen for its first byte)
 __device__ __forceinline__ void cut_ctx(const uint8_t* __restrict__ ref2, size_t ref2_stride, uint32_t pos, uint32_t seed_size, uint32_t left_skip, uint4& c0, uint4& c1) {

@@ -1,6 +1,8 @@
 #!/bin/bash
 # round 5: this tree against ab_exp/libsegalign_hip_old.so (the commit before, built here), tests first, then interleaved bench runs on one box
 #   tools/r05_ab_lib.sh <tag> [tests to run first]
+# The old library: git stash (or check out the other commit) && python -c 'from segalign_amd.build import build_lib; build_lib(force=True)' &&
+#   mkdir -p ab_exp && cp segalign_amd/lib/libsegalign_hip.so ab_exp/libsegalign_hip_old.so, then come back and rebuild (ab_exp/ is git-ignored).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 out=$R/gpurun_out/${1:-r05ab}; mkdir -p $out; shift

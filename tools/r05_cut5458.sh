@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5: context cut 54 + 58 (this tree) against 48 + 64 (ab_exp/libsegalign_hip_4864.so = the commit before), tests first, then the same-box A/B
+# round 5: context cut 54 + 58 (this tree) against 48 + 64 (ab_exp/libsegalign_hip_4864.so = a library built from the commit before, see tools/r05_ab_lib.sh), tests first, then the same-box A/B
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 out=$R/gpurun_out/${1:-r05z}; mkdir -p $out

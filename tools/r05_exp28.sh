@@ -1,6 +1,9 @@
 #!/bin/bash
 # round 5 EXPERIMENT (timing only): the class filter reading its records at a 28-byte stride (ab_exp/libsegalign_hip.so = the same
-# tree with extend.hip compiled with -DSA_EXP_REC28) against the real 32-byte records, interleaved on one box
+# tree with extend.hip compiled with -DSA_EXP_REC28) against the real 32-byte records, interleaved on one box.  Build the variant here first:
+#   mkdir -p ab_exp && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -DSA_EXP_REC28 -c segalign_amd/csrc/extend.hip -o ab_exp/extend_exp.o && \
+#   hipcc --offload-arch=gfx950 -shared -fPIC -o ab_exp/libsegalign_hip.so $(ls segalign_amd/lib/obj/*.o | grep -v extend.o) ab_exp/extend_exp.o
+# (ab_exp/ is git-ignored and travels with the gpurun snapshot.)  Result: profiles/r05/exp_rec28.txt
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/r05x; mkdir -p $out
 rm -rf /tmp/exp; mkdir -p /tmp/exp; cp -r $R/segalign_amd $R/bench.py $R/oracle $R/profiles $R/tests /tmp/exp/ 2>/dev/null

@@ -67,9 +67,16 @@ def one_case(seed, s14):
     ko = bool(rng.random() < 0.3)   # the multi-chunk calls of (2) key-ordered (option key_order = 2: join.hip, extend.hip 1e)
     if ko:
         E.set_option("key_order", 2)
+    audit = bool(rng.random() < 0.3)  # every hit the filter levels REJECT in the per-chunk calls of (1) extended by the oracle: none may pass
+    if audit:
+        E.set_option("audit_cap", 1 << 22)
+    if rng.random() < 0.15:
+        E.set_option("ctx_skip_seed", 0)  # (the context layout with the seed window inside the record)
     c = Case(t, q, **kw).oracle_setup(O).engine_setup(E)
     kw["key_order"] = ko
+    kw["audit"] = audit
     hsps = hits = 0
+    audited = [0]
     try:
         q_len = c.query.size - c.seed_size
         # (1) drop-in entry + device seeder, chunk by chunk
@@ -88,6 +95,14 @@ def one_case(seed, s14):
                 if seeds.size <= (13 if c.transition else 1) * c.chunk:
                     assert seg_equal(E.SeedAndFilter(seeds, rev, 0), w), ("drop-in", rev, s, e)
                 assert seg_equal(E.SeedAndFilterRange(s, e, rev, 0), w), ("range", rev, s, e)
+                if audit and st["num_hits"] > 0 and E.last_call_stats()["lookup_path"] != 0:
+                    pairs, n = E.get_audit()
+                    assert n == pairs.shape[0], "audit list overflowed"
+                    if n:
+                        ok, _ = O.extend_hits_pass(c.o_ref, c.o_qrc if rev else c.o_q, c.sub_mat, pairs, xdrop=c.xdrop, hspthresh=c.hspthresh,
+                                                   noentropy=c.noentropy)
+                        assert not ok.any(), ("a filter level rejected a passing hit", rev, s, e, pairs[np.nonzero(ok)[0][:3]].tolist())
+                        audited[0] += int(n)
         # (2) the interval entry over the whole block (multi-chunk table-direct calls), against the same oracle vectors
         for threads in (int(rng.integers(1, 4)),):
             fw, rc, tot = E.SeedInterval(0, q_len, q_len, E.STRAND_BOTH, 0, threads)
@@ -101,6 +116,7 @@ def one_case(seed, s14):
                 assert seg_equal(got, exp), ("interval", rev, threads, got.size, exp.size)
     finally:
         E.ShutdownProcessor()
+    kw["audited"] = audited[0]
     return kind, kw, t.size, hits, hsps
 
 
@@ -120,7 +136,7 @@ def main():
             sys.exit(1)
         print("seed %d %-9s %7d bp step %d %s chunk %6d xdrop %4d thresh %4d %s%s: %d hits, %d HSPs ok" % (
             seed, kind, size, kw["step"], "tr" if kw["transition"] else "no-tr", kw["chunk"], kw["xdrop"], kw["hspthresh"],
-            "noentropy " if kw["noentropy"] else "", ("14of22" if "shape" in kw else "12of19") + (" key-ordered" if kw.get("key_order") else ""), hits, hsps), flush=True)
+            "noentropy " if kw["noentropy"] else "", ("14of22" if "shape" in kw else "12of19") + (" key-ordered" if kw.get("key_order") else "") + (" audited %d" % kw["audited"] if kw.get("audit") else ""), hits, hsps), flush=True)
         n += 1
         tot_hits += hits
         tot_hsps += hsps

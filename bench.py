@@ -764,6 +764,13 @@ def roofline(args, E, wl, prof, busy, call_stats, run_step, run_job, jobs, elaps
         "table_direct": table_direct,
         # the kernel north_star names: seed lookup.  Table-direct: probe_kernel -- one probe per query POSITION into the neighbourhood table
         "seed_lookup": first_class(lookup_scope, lookup_scope, 16.0 * S, 16.0 * sS, "16*S"),
+        # SURVEY 8(d)'s figure for the reference's FUSED lookup (find_num_hits + find_hits: 8 B seed word + 8 B extent per seed word, 4 B position
+        # per hit) against the time of the two kernels that do that work here -- the position probe and the class filter, which reads the run
+        # entries in place: an equivalence like `algorithmic_equiv`, quoted because the round-4 verdict asked for it next to the moved-byte frac
+        "fused_lookup_equiv": ({"bytes": "16*S + 4*H", "over": [lookup_scope, "extend_filter"],
+                                "frac": frac(rate(16.0 * S + 4.0 * H, ms_of(prof, [lookup_scope, "extend_filter"]))),
+                                "single_stream_frac": frac(rate(16.0 * sS + 4.0 * sH2, ms_of(solo, [lookup_scope, "extend_filter"]))) if solo else None}
+                               if (table_direct and ctx_filter) else None),
         "kernels": kernels,
     }
 

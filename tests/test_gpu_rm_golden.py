@@ -51,3 +51,33 @@ def test_engine_equals_the_emulated_reference_on_the_golden_inputs(oracle, clean
             E.RmClearQuery()
             E.ShutdownProcessor()
     assert done == len(CASES)
+
+
+def test_src_engine_equals_the_emulated_reference_on_the_golden_inputs(oracle, engine):
+    """the src/ binary's golden set (tests/golden/src_golden.json): the drop-in entry on the host's seed words and the device-seeded
+    entry both return the emulated reference's vector -- header {anchors, num_hits} and every record of `final`"""
+    import src_golden as S
+    E, O = engine, oracle
+    cases = list(S.cases())
+    done = 0
+    try:
+        for seed in sorted({c["seed"] for c in cases}):
+            for key in sorted({(c["hspthresh"], c["noentropy"], c["transition"]) for c in cases if c["seed"] == seed}):
+                group = [c for c in cases if c["seed"] == seed and (c["hspthresh"], c["noentropy"], c["transition"]) == key]
+                t, q = group[0]["target"], group[0]["query"]
+                E.reset_option(None)
+                case = Case(t, q, chunk=250000, hspthresh=key[0], noentropy=bool(key[1]), transition=bool(key[2]), sub_mat=group[0]["sub_mat"]).oracle_setup(O).engine_setup(E)
+                assert np.array_equal(E.copy_ref_codes(), group[0]["t_codes"])
+                assert np.array_equal(E.copy_query_codes(0, False), group[0]["q_codes"]) and np.array_equal(E.copy_query_codes(0, True), group[0]["q_rc_codes"])
+                for c in group:
+                    seeds = case.host_seeds(c["start"], c["end"], bool(c["rev"]))
+                    for got in (E.SeedAndFilter(seeds, bool(c["rev"]), 0), E.SeedAndFilterRange(c["start"], c["end"], bool(c["rev"]), 0)):
+                        assert int(got[0]["len"]) == c["final"].size and int(got[0]["score"]) == c["hits"].size
+                        for f in ("ref_start", "query_start", "len", "score"):
+                            assert np.array_equal(got[1:][f], c["final"][f]), (S.case_id(c), f)
+                    done += 1
+                E.ShutdownProcessor()
+    finally:
+        E.ShutdownProcessor()
+        E.reset_option(None)
+    assert done == len(cases)

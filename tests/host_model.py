@@ -66,6 +66,44 @@ class Arena:
             self.block_names.pop()
 
 
+def segment_files(R, Q, rb, rs, qb, qs, index, fw_hsps, rc_hsps, gapped=True, data_folder="./", output_format="maf-", ydrop=9430,
+                  gappedthresh=3000, ambiguous="", notrivial=False, scoring_file=""):
+    """segment_printer_body::operator() (src/segment_printer.cpp:11-175) for one interval: the .segments files of the two strands and the
+    lastz command lines.  R / Q: objects with chr_name / chr_start (and rc_name / rc_start for the query's minus strand); rb / qb block
+    indices (rb = the printer's r_index - 1), rs / qs block starts in the arenas, index = num_invoked.  HSPs as (ref_start, query_start,
+    len, score).  Held against the real printer by tests/test_printer_golden.py."""
+    files, cmds = {}, []
+    for rev in (False, True):  # segment_printer.cpp:70-168
+        hs = rc_hsps if rev else fw_hsps
+        if not hs:
+            continue
+        base = "tmp%d.block%d.r%d.%s" % (index, qb, rs, "minus" if rev else "plus")
+        names = Q.rc_name if rev else Q.chr_name
+        starts = Q.rc_start if rev else Q.chr_start
+        lines = []
+        for (r0, q0, ln, sc) in (reversed(hs) if rev else hs):
+            seg_r, seg_q = r0 + rs, q0 + qs
+            ri = bisect.bisect_right(R.chr_start, seg_r) - 1
+            qi = bisect.bisect_right(starts, seg_q) - 1
+            lines.append("%s\t%d\t%d\t%s\t%d\t%d\t%s\t%d\n" % (
+                R.chr_name[ri], seg_r + 1 - R.chr_start[ri], seg_r + ln + 1 - R.chr_start[ri], names[qi],
+                seg_q + 1 - starts[qi], seg_q + ln + 1 - starts[qi], "-" if rev else "+", sc))
+        files[base + ".segments"] = "".join(lines)
+        if gapped:
+            cmd = ("lastz %sref.2bit[nameparse=darkspace][multiple][subset=ref_block%d.name] "
+                   "%squery.2bit[nameparse=darkspace][subset=query_block%d.name] --format=%s --ydrop=%d "
+                   "--gappedthresh=%d --strand=%s" % (data_folder, rb, data_folder, qb, output_format, ydrop, gappedthresh,
+                                                      "minus" if rev else "plus"))
+            if ambiguous != "":
+                cmd += " --ambiguous=" + ambiguous
+            if notrivial:
+                cmd += " --notrivial"
+            if scoring_file != "":
+                cmd += " --scoring=" + scoring_file
+            cmds.append(cmd + " --segments=%s.segments --output=%s.%s 2> %s.err" % (base, base, output_format, base))
+    return files, cmds
+
+
 def expected_outputs(O, target_records, query_records, shape="TTT0T00TT00T0T0TTTT", transition=True, step=1, xdrop=910,
                      hspthresh=3000, noentropy=False, chunk=250000, interval=10000000, seq_block_size=500000000,
                      gapped=True, data_folder="./", output_format="maf-", ydrop=9430, strand="both"):
@@ -101,27 +139,10 @@ def expected_outputs(O, target_records, query_records, shape="TTT0T00TT00T0T0TTT
                         segs, _ = O.seed_and_filter(ref_codes, qrc_codes if rev else q_codes, index, pos, seeds, sub_mat,
                                                     seed_size=seed_size, xdrop=xdrop, hspthresh=hspthresh, noentropy=noentropy)
                         hs[rev].extend(segs[1:].tolist())
-                for rev in (False, True):  # segment_printer.cpp:70-168
-                    if not hs[rev]:
-                        continue
-                    base = "tmp%d.block%d.r%d.%s" % (i + 1, qb, rs, "minus" if rev else "plus")
-                    names = Q.rc_name if rev else Q.chr_name
-                    starts = Q.rc_start if rev else Q.chr_start
-                    lines = []
-                    for (r0, q0, ln, sc) in (reversed(hs[rev]) if rev else hs[rev]):
-                        seg_r, seg_q = r0 + rs, q0 + qs
-                        ri = bisect.bisect_right(R.chr_start, seg_r) - 1
-                        qi = bisect.bisect_right(starts, seg_q) - 1
-                        lines.append("%s\t%d\t%d\t%s\t%d\t%d\t%s\t%d\n" % (
-                            R.chr_name[ri], seg_r + 1 - R.chr_start[ri], seg_r + ln + 1 - R.chr_start[ri], names[qi],
-                            seg_q + 1 - starts[qi], seg_q + ln + 1 - starts[qi], "-" if rev else "+", sc))
-                    files[base + ".segments"] = "".join(lines)
-                    if gapped:
-                        cmds.append("lastz %sref.2bit[nameparse=darkspace][multiple][subset=ref_block%d.name] "
-                                    "%squery.2bit[nameparse=darkspace][subset=query_block%d.name] --format=%s --ydrop=%d "
-                                    "--gappedthresh=%d --strand=%s --segments=%s.segments --output=%s.%s 2> %s.err" % (
-                                        data_folder, rb, data_folder, qb, output_format, ydrop, hspthresh,
-                                        "minus" if rev else "plus", base, base, output_format, base))
+                f2, c2 = segment_files(R, Q, rb, rs, qb, qs, i + 1, hs[False], hs[True], gapped=gapped, data_folder=data_folder,
+                                       output_format=output_format, ydrop=ydrop, gappedthresh=hspthresh)
+                files.update(f2)
+                cmds.extend(c2)
     return files, cmds
 
 

@@ -147,6 +147,36 @@ def expected_outputs(O, target_records, query_records, shape="TTT0T00TT00T0T0TTT
 
 
 # ---- repeat masker host (repeat_masker_src/main.cpp:283-436, seeder.cpp:28-195, segment_printer.cpp:8-65) -------------
+def rm_chunk_calls(start_pos, end_pos, block_len, chunk, strands):
+    """The seed ranges [s0, s1) the repeat masker's seeder hands g_SeedAndFilter for one interval, in call order (repeat_masker_src/
+    seeder.cpp:73-146): per wga_chunk piece of [start_pos, end_pos) the plus-strand piece, then a minus-strand piece derived from the
+    plus piece's END (:118-119).  Held against the real seeder by tests/test_rm_host_golden.py."""
+    end_pos_rc = block_len - 1 - start_pos
+    for i in range(start_pos, end_pos, chunk):
+        start, end = i, min(i + chunk, end_pos)
+        for rev in (False, True):
+            if not (strands & (2 if rev else 1)):
+                continue
+            if rev:
+                s0 = block_len - 1 - end
+                yield True, s0, min(s0 + chunk, end_pos_rc)
+            else:
+                yield False, start, end
+
+
+def rm_interval_lines(chr_name, chr_start, block_start, intervals, markend=False):
+    """interval_printer_body::operator() (repeat_masker_src/segment_printer.cpp:8-65): the lines of tmp<i>.block<b>.intervals for the
+    (query_start, len) pairs of one interval task"""
+    lines = []
+    for (qs, ln) in intervals:
+        q = block_start + int(qs)
+        c = bisect.bisect_right(chr_start, q) - 1
+        lines.append("%s\t%d\t%d\n" % (chr_name[c], q - chr_start[c], q + int(ln) + 1 - chr_start[c]))
+    if markend:
+        lines.append("# segalign_repeat_masker end-of-file\n")
+    return lines
+
+
 def rm_mask_interval(O, blk, ctx, start_pos, end_pos, ref_start, ref_end, strands, M, chunk, seed_size, kmer_size, transition,
                      saf_kwargs):
     """seeder_body::operator() of the repeat masker for one interval of block `blk` (ASCII bytes); ctx caches the
@@ -158,18 +188,10 @@ def rm_mask_interval(O, blk, ctx, start_pos, end_pos, ref_start, ref_end, strand
         ctx["rc"] = O.rev_comp_codes(ctx["ref"])
         ctx["index"], ctx["pos"] = O.generate_seed_pos_table(blk, 0, L, saf_kwargs.get("step", 1), seed_size, kmer_size)
     kw = {k: v for k, v in saf_kwargs.items() if k != "step"}
-    end_pos_rc = L - 1 - start_pos
     hsps = []
     tot = dict(num_seeds=0, num_hits=0, num_hsps=0)
-    for i in range(start_pos, end_pos, chunk):
-        start, end = i, min(i + chunk, end_pos)
-        for rev in (False, True):
-            if not (strands & (2 if rev else 1)):
-                continue
-            s0, s1 = start, end
-            if rev:  # seeder.cpp:118-119: derived from the plus-strand chunk END
-                s0 = L - 1 - end
-                s1 = min(s0 + chunk, end_pos_rc)
+    for (rev, s0, s1) in rm_chunk_calls(start_pos, end_pos, L, chunk, strands):
+        if True:
             s1 = min(s1, L - seed_size + 1)
             seeds = O.make_seeds(ctx["rc_ascii"] if rev else blk, 0, s0, s1, seed_size, kmer_size, transition)
             if seeds.size == 0:
@@ -215,12 +237,6 @@ def rm_expected_outputs(O, records, shape="TTT0T00TT00T0T0TTTT", transition=True
                                   dict(sub_mat=sub_mat, xdrop=xdrop, hspthresh=hspthresh, noentropy=noentropy, step=step))
         if ivs.size == 0:
             continue
-        lines = []
-        for iv in ivs:  # segment_printer.cpp:43-57
-            q = bs + int(iv["query_start"])
-            c = bisect.bisect_right(chr_start, q) - 1
-            lines.append("%s\t%d\t%d\n" % (chr_name[c], q - chr_start[c], q + int(iv["len"]) + 1 - chr_start[c]))
-        if markend:
-            lines.append("# segalign_repeat_masker end-of-file\n")
+        lines = rm_interval_lines(chr_name, chr_start, bs, [(int(iv["query_start"]), int(iv["len"])) for iv in ivs], markend)
         files["tmp%d.block%d.intervals" % (counters[b], b)] = "".join(lines)
     return files

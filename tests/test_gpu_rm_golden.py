@@ -81,3 +81,22 @@ def test_src_engine_equals_the_emulated_reference_on_the_golden_inputs(oracle, e
         E.ShutdownProcessor()
         E.reset_option(None)
     assert done == len(cases)
+
+
+def test_device_coverage_runs_equal_the_reference_seeders(engine):
+    """sa_rm_coverage_intervals (coverage.hip: difference array + scans, depth mod 256) on the HSPs the reference's own seeder was handed
+    (tests/golden/rm_host_golden.json: repeat_masker_src/seeder.cpp compiled as it lies) gives the runs that seeder returned -- the uint8
+    wrap under piles of 300 HSPs and the dropped open run at the block end included"""
+    import json
+    import os
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rm_host_golden.json")))["cases"]
+    engine.InitializeInterface(1)
+    n = 0
+    for c in cases:
+        for t in c["tasks"]:
+            hs = [G._rows(g["hsps"], G.SEG) for g in t["calls"]]
+            allh = np.concatenate(hs) if hs else np.zeros(0, dtype=G.SEG)
+            got = engine.RmCoverageIntervals(allh, c["block_len"], c["M"])
+            assert [[int(r["query_start"]), int(r["len"])] for r in got] == t["runs"]
+            n += len(t["runs"])
+    assert n > 30

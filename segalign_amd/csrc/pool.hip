@@ -6,6 +6,10 @@ namespace sa {
 
 // ---- token pool ------------------------------------------------------------------------------------------------------
 Slot* acquire_slot() {  // src/seed_filter.cu:699-708
+    if (!g_proc_init) {  // (the pool is filled by InitializeProcessor: without it a caller would wait for a token for ever)
+        fprintf(stderr, "Error: an engine call that needs a device slot before InitializeProcessor\n");
+        exit(1);
+    }
     std::unique_lock<std::mutex> lk(g_mu);
     g_cv.wait(lk, [] { return !g_tokens.empty(); });
     auto t = g_tokens.back();

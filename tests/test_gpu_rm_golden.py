@@ -91,6 +91,8 @@ def test_device_coverage_runs_equal_the_reference_seeders(engine):
     import os
     cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rm_host_golden.json")))["cases"]
     engine.InitializeInterface(1)
+    engine.GenerateShapePos(G.SHAPE)
+    engine.InitializeProcessor(True, 250000, 19, np.array(cases[0].get("sub_mat") or list(CASES[0]["sub_mat"]), dtype=np.int32), 910, 3000, False)
     n = 0
     for c in cases:
         for t in c["tasks"]:
@@ -99,4 +101,5 @@ def test_device_coverage_runs_equal_the_reference_seeders(engine):
             got = engine.RmCoverageIntervals(allh, c["block_len"], c["M"])
             assert [[int(r["query_start"]), int(r["len"])] for r in got] == t["runs"]
             n += len(t["runs"])
+    engine.ShutdownProcessor()
     assert n > 30

@@ -132,6 +132,12 @@ static size_t coverage_finish(Slot* sl, uint32_t block_len, uint32_t M, uint64_t
             }
             check_memcpy(hipMemcpyAsync(res, sl->cov_pairs.p, n_out * sizeof(sa_interval), hipMemcpyDeviceToHost, st), "intervals");
             check_sync(st, "intervals");
+            // A run is written when the first uncovered position AFTER it is seen, and the reference's loop ends at block_len - 1
+            // (seeder.cpp:166-186, no flush behind it): a run that covers the block's last position is never written.  Real HSPs
+            // cannot produce one (their last base is not counted); HSPs handed to sa_rm_coverage_intervals can
+            // (tests/golden/rm_host_golden.json)
+            if ((uint64_t)res[n_out - 1].query_start + res[n_out - 1].len >= block_len) n_out--;
+            if (n_out == 0) { free(res); res = nullptr; }
             *out = res;
         }
     }

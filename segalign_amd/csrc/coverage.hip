@@ -9,8 +9,8 @@
 //   * the counters are uint8_t, so the depth compared with M is the true depth mod 256;
 //   * `len` is bases-1, so an HSP covers query_start .. query_start+len-1 (its last base is not counted);
 //   * a run is emitted when the first uncovered position AFTER it is seen (:177-184), so a run that reaches the end
-//     of the block is never written.  With M >= 1 no run can reach the end (coverage is 0 from the largest
-//     query_start+len on); with M == 0 the whole block is one unterminated run and nothing is written.
+//     of the block is never written: the host drops a last run that ends at block_len (api_rm.hip coverage_finish; only
+//     HSPs with query_start + len == block_len make one); with M == 0 the whole block is one unterminated run and nothing is written.
 #include "kernels.h"
 
 namespace sa {

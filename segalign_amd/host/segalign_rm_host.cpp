@@ -217,12 +217,14 @@ static void usage() {
             "  --strand=plus|minus|both --neighbor_proportion=F --seed=12of19|14of22|<0/1 pattern> --step=N --notransition\n"
             "  --xdrop=N --hspthresh=N --noentropy --M=N --markend --ambiguous=x|n|iupac[,reward,penalty] --scoring=FILE\n"
             "  --wga_chunk_size=N --lastz_interval_size=N --seq_block_size=N --num_gpu=N --num_threads=N --outdir=DIR\n"
-            "  --host-loop (seeds, HSPs and the chunk loop on the host like repeat_masker_src/seeder.cpp) --debug\n");
+            "  --host-loop (seeds, HSPs and the chunk loop on the host like repeat_masker_src/seeder.cpp) --debug\n"
+            "  --plan-only=SEQ_LEN (print the block / interval plan for a sequence of that length and leave)\n");
 }
 
 int main(int argc, char** argv) {
     setenv("GPU_MAX_HW_QUEUES", "8", 0);  // the host's own choice, before the first HIP call: one hardware queue per engine slot
     std::vector<std::string> pos;
+    unsigned long long plan_only = 0;
     for (int i = 1; i < argc; i++) {
         std::string v;
         const char* a = argv[i];
@@ -246,9 +248,17 @@ int main(int argc, char** argv) {
         else if (opt(a, "--num_gpu", v)) cfg.num_gpu = atoi(v.c_str());
         else if (opt(a, "--num_threads", v)) cfg.num_threads = atoi(v.c_str());
         else if (opt(a, "--outdir", v)) cfg.outdir = v;
+        else if (opt(a, "--plan-only", v)) plan_only = strtoull(v.c_str(), nullptr, 10);  // print the plan for a sequence of this length and leave (no engine, no GPU)
         else if (!strcmp(a, "--host-loop")) cfg.host_loop = true;
         else if (!strcmp(a, "--debug")) cfg.debug = true;
         else { fprintf(stderr, "unknown option %s\n", a); usage(); return 1; }
+    }
+    if (plan_only) {  // the plan alone (tests/test_rm_plan_golden.py holds it against the reference's own text): block index, start, length,
+        if (cfg.seed_shape == "14of22") cfg.seed_size = 22;  // seed range, target window per interval task
+        else if (cfg.seed_shape != "12of19") cfg.seed_size = (uint32_t)cfg.seed_shape.size();
+        for (const Task& t : make_plan((size_t)plan_only))
+            printf("%d %zu %u %u %u %u %u\n", t.block_index, t.block_start, t.block_len, t.start, t.end, t.ref_start, t.ref_end);
+        return 0;
     }
     if (pos.size() < 1) {
         fprintf(stderr, "You must specify a sequence file \n");

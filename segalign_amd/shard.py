@@ -125,7 +125,7 @@ def rm_plan(seq_len, seq_block_size=1000000000, lastz_interval_size=10000000, pr
         if l + seq_block_size + right_overlap > seq_len:
             block_len = seq_len - block_start
         else:
-            block_len = l - block_start + seq_block_size + right_overlap
+            block_len = (((l - block_start + seq_block_size) & 0xFFFFFFFF) + right_overlap) & 0xFFFFFFFF  # (:358: unsigned int arithmetic)
         start_pos = l - block_start
         if block_len < seq_block_size:
             end_pos = start_pos + block_len - (l - block_start) - seed_size
@@ -134,7 +134,7 @@ def rm_plan(seq_len, seq_block_size=1000000000, lastz_interval_size=10000000, pr
         while start_pos < end_pos:                                         # :367
             end = min(end_pos, start_pos + lastz_interval_size)
             left_limit = start_pos < left_overlap
-            right_limit = end + right_overlap > block_len
+            right_limit = ((end + right_overlap) & 0xFFFFFFFF) > block_len       # (:385: uint32 -- wraps with neighbor_proportion 0)
             if left_limit:
                 ref_start = 0
                 ref_end = block_len if right_limit else min(max_interval_seq_len, block_len)
@@ -142,7 +142,7 @@ def rm_plan(seq_len, seq_block_size=1000000000, lastz_interval_size=10000000, pr
                 ref_end = block_len
                 ref_start = 0 if block_len < max_interval_seq_len else block_len - max_interval_seq_len
             else:
-                ref_start, ref_end = start_pos - left_overlap, end + right_overlap
+                ref_start, ref_end = (start_pos - left_overlap) & 0xFFFFFFFF, (end + right_overlap) & 0xFFFFFFFF
             tasks.append(dict(block_index=block_index, block_start=block_start, block_len=block_len, start=start_pos, end=end,
                               ref_start=ref_start, ref_end=ref_end))
             start_pos += lastz_interval_size

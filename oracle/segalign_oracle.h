@@ -14,6 +14,11 @@
  *     compiled here (no nvcc / CUDA headers / TBB).  Each function below follows the cited reference lines;
  *     the scalar X-drop form is cross-checked against an independent tile-by-tile restatement of the
  *     32-lane kernel (orc_extend_hit_tiled) in tests/test_oracle_extend.py.
+ *     Second routes (none a pin: each needs stand-ins for what the image lacks): the reference's kernels and
+ *     host files compiled as they lie with the CUDA runtime / thrust / TBB stood in for and the kernels under SIMT emulation --
+ *     stage by stage (tests/golden/make_*_golden.py) and the five hot-path files as ONE program end to end
+ *     (tests/golden/make_path_golden.py: every g_SeedAndFilter return, iteration plans over a small MAX_HITS included);
+ *     this restatement returns all of those vectors.
  *
  * Every function cites the /root/reference file:line it restates.
  */

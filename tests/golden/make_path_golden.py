@@ -354,7 +354,8 @@ def main():
             (S19,     1,    3,   1200, 1,   9000,  5000,  0,      0,      1 << 16, 910,  3000,     0,        12,    2400),   # MAX_HITS 256: calls in several iterations
             (S19,     0,    3,   800,  1,   7000,  4000,  150,    90,     1 << 15, 910,  3000,     1,        8,     4000),   # MAX_HITS 128, arenas that start elsewhere, --noentropy
             (S19,     1,    1,   700,  2,   8000,  4200,  0,      0,      1 << 17, 500,  2200,     0,        20,    2100),   # step 2, plus strand, other thresholds
-            (shape22, 1,    2,   1000, 1,   8000,  4000,  0,      0,      1 << 16, 910,  3000,     0,        12,    4000))   # 14of22, minus strand
+            (shape22, 1,    2,   1000, 1,   8000,  4000,  0,      0,      1 << 16, 910,  3000,     0,        12,    4000),   # 14of22, minus strand
+            (S19,     1,    3,   5000, 1,   60000, 30000, 0,      0,      1 << 22, 910,  3000,     0,        25,    15000))  # six-chunk intervals, 65 k seed words per call, MAX_HITS 16384
     for ci, (shape, trans, strand, chunk, step, t_len, q_len, t_start, q_start, mem, xdrop, hspthresh, noentropy, copies, ivlen) in enumerate(plan):
         ql = q_len - len(shape)
         ivs = [(s, min(s + ivlen, ql)) for s in range(0, ql, ivlen)]

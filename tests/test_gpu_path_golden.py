@@ -1,6 +1,7 @@
 """GPU: the engine against what the reference's OWN FILES return when they run end to end (tests/golden/path_golden.json, generator
 tests/golden/make_path_golden.py): every g_SeedAndFilter call of the run -- header and HSPs in the reference's order -- through the drop-in
-entry (the seed vector of the host loop) and through the device-seeded entry (table-direct lookup), with MAX_HITS set to what the reference's
+entry (the seed vector of the host loop), through the device-seeded entry (table-direct lookup) and through the grouped entry
+(sa_seed_calls: an interval's chunks in one pass), with MAX_HITS set to what the reference's
 arithmetic gives the generator's small "GPU" (sa_set_max_hits: calls in several iterations).  A second route, not a pin."""
 import numpy as np
 import pytest
@@ -42,6 +43,18 @@ def test_engine_returns_what_the_reference_files_return(oracle, engine, c):
                 assert (int(got[0]["len"]), int(got[0]["score"])) == (g["n_hsps"], g["num_hits"]), where
                 assert np.array_equal(got[1:], g["hsps"]), where
         assert next(calls, None) is None
+        # the grouped entry the bench and the hosts use: one call per interval and strand, its wga_chunk pieces sharing one pass over the kernels
+        q_blk = ql - span
+        for kk, (s, e) in enumerate(c["intervals"]):
+            for rev in (False, True):
+                if not (c["strand"] & (2 if rev else 1)):
+                    continue
+                a, b = (q_blk - e, q_blk - s) if rev else (s, e)
+                hits = []
+                outs, _ = E.SeedCalls([(a, b, rev)], 0, 2, hits_out=hits)
+                want = [g for g in c["calls"] if g["interval"] == kk and g["rev"] == int(rev)]
+                assert np.array_equal(outs[0], np.concatenate([g["hsps"] for g in want])), (G.case_id(c), "grouped", kk, rev)
+                assert hits[0] == sum(g["num_hits"] for g in want)
     finally:
         E.set_max_hits(0)
         E.ShutdownProcessor()

@@ -3,7 +3,8 @@ sort / unique / sort chain -- against what the reference's OWN FILES return when
 src/seed_filter.cu, common/seed_filter_interface.cu, common/seed_pos_table.cu, common/ntcoding.cpp and src/seeder.cpp compiled as they lie,
 CUDA runtime / thrust / TBB stood in for, kernels under SIMT emulation; tests/golden/make_path_golden.py).  Every g_SeedAndFilter call of
 the run: the header (HSPs, seed hits) and every HSP in the reference's order; MAX_HITS from the reference's own arithmetic on a 32-128 KiB
-"GPU", so that most calls of cases 1-4 run in several iterations (src/seed_filter.cu:720-744).  A second route, not a pin."""
+"GPU", so that most calls of cases 1-4 run in several iterations (src/seed_filter.cu:720-744); case 5 is a 60 kbp x 30 kbp pair with 5000-base chunks
+(65 k seed words per call, six chunks per interval and strand).  A second route, not a pin."""
 import numpy as np
 import pytest
 
@@ -39,7 +40,7 @@ def test_the_oracles_path_returns_what_the_reference_files_return(oracle, c):
         assert np.array_equal(segs[1:], g["hsps"]), (G.case_id(c), kk, rev, a, b)
         split += g["num_hits"] >= c["max_hits"]
     assert next(calls, None) is None
-    if c["max_hits"] < 1 << 20:
+    if c["max_hits"] <= 512:
         assert split > 0                                                             # calls that took the several-iteration plan
 
 

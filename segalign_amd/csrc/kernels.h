@@ -43,7 +43,7 @@ struct CandRec {              // a hit the X-drop filter could not reject: exten
 };
 
 // What the class filter (level 1) hands to the second level: the anchor plus what level 1 already knows, so that level 2 walks only
-// the side(s) that were still alive at the end of the 48 + 64 context bases.  20 bytes:
+// the side(s) that were still alive at the end of the context bases (54 right, seed window + 58 left; rounds 2-4: 48 + 64).  20 bytes:
 //   state: the packed (score : drop) register of level 1's LEFT walk at the end of its context (seed window + CTX_L_BASES; extend.hip 1d)
 //   meta : known (16 bits) | flags (2 bits) << 16
 //     flags bit 0: right side undecided, bit 1: left side undecided

@@ -355,8 +355,14 @@ def main():
             (S19,     0,    3,   800,  1,   7000,  4000,  150,    90,     1 << 15, 910,  3000,     1,        8,     4000),   # MAX_HITS 128, arenas that start elsewhere, --noentropy
             (S19,     1,    1,   700,  2,   8000,  4200,  0,      0,      1 << 17, 500,  2200,     0,        20,    2100),   # step 2, plus strand, other thresholds
             (shape22, 1,    2,   1000, 1,   8000,  4000,  0,      0,      1 << 16, 910,  3000,     0,        12,    4000),   # 14of22, minus strand
-            (S19,     1,    3,   5000, 1,   60000, 30000, 0,      0,      1 << 22, 910,  3000,     0,        25,    15000))  # six-chunk intervals, 65 k seed words per call, MAX_HITS 16384
+            (S19,     1,    3,   5000, 1,   60000, 30000, 0,      0,      1 << 22, 910,  3000,     0,        25,    15000),  # six-chunk intervals, 65 k seed words per call, MAX_HITS 16384
+            (S19,     1,    3,   25000, 1,  300000, 150000, 0,    0,      1 << 22, 910,  3000,     0,        60,    75000))  # 325 k seed words and ~50 k hits per call against MAX_HITS 16384
+    only = [int(x) for x in os.environ.get("SA_PATH_ONLY", "").split(",") if x]   # regenerate these cases only, keep the others of the committed file
+    if only:
+        cases = json.load(open(OUT))["cases"]
     for ci, (shape, trans, strand, chunk, step, t_len, q_len, t_start, q_start, mem, xdrop, hspthresh, noentropy, copies, ivlen) in enumerate(plan):
+        if only and ci not in only:
+            continue
         ql = q_len - len(shape)
         ivs = [(s, min(s + ivlen, ql)) for s in range(0, ql, ivlen)]
         mat = hoxd70(xdrop)
@@ -395,9 +401,13 @@ def main():
         max_hits = int(np.float32(4194304) * np.float32(mem / 1073741824.0))
         print("case %d: %d calls, %d HSPs, %d seed hits, MAX_HITS %d, calls above it: %d" %
               (ci, len(calls), sum(c["n_hsps"] for c in calls), sum(c["num_hits"] for c in calls), max_hits, sum(c["num_hits"] >= max_hits for c in calls)), flush=True)
-        cases.append(dict(shape=shape, transition=trans, strand=strand, chunk=chunk, step=step, t_start=t_start, q_start=q_start, t_len=t_len, q_len=q_len,
-                          total_global_mem=mem, max_hits=max_hits, xdrop=xdrop, hspthresh=hspthresh, noentropy=noentropy, sub_mat=mat.tolist(),
-                          target_arena=t_arena.tobytes().decode("ascii"), query_arena=q_arena.tobytes().decode("ascii"), intervals=ivs, calls=calls))
+        case = dict(shape=shape, transition=trans, strand=strand, chunk=chunk, step=step, t_start=t_start, q_start=q_start, t_len=t_len, q_len=q_len,
+                    total_global_mem=mem, max_hits=max_hits, xdrop=xdrop, hspthresh=hspthresh, noentropy=noentropy, sub_mat=mat.tolist(),
+                    target_arena=t_arena.tobytes().decode("ascii"), query_arena=q_arena.tobytes().decode("ascii"), intervals=ivs, calls=calls)
+        if only and ci < len(cases):
+            cases[ci] = case
+        else:
+            cases.append(case)
     json.dump(dict(note="every g_SeedAndFilter return of the reference's own files run end to end (tests/golden/make_path_golden.py: src/seed_filter.cu, "
                         "common/seed_filter_interface.cu, common/seed_pos_table.cu, common/ntcoding.cpp, src/seeder.cpp; CUDA runtime / thrust / TBB stood in for, "
                         "kernels under SIMT emulation).  Arenas are the DRAM buffers from 0 (t_start / q_start bases of another block in front); the query block "

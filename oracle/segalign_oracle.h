@@ -9,6 +9,9 @@
  *   - k-mer / shape / transition / RevComp functions: PINNED against the real reference object
  *     oracle/_ref/libntcoding_ref.so (g++ on /root/reference/common/ntcoding.cpp as it lies) and against
  *     the golden vectors generated from it (tests/golden/ntcoding_golden.json).
+ *   - the FASTA reader the hosts use (segalign_amd/fasta.py, segalign_amd/host/host_common.hpp -- not part of this library): PINNED against
+ *     oracle/_ref/kseq_dump (the reference's vendored common/kseq.h compiled as it lies, door oracle/kseq_ref.cpp) and
+ *     tests/golden/kseq_golden.json generated from it.
  *   - everything else (table build, find_hsps, SeedAndFilter orchestration): PARITY UNPINNED by the
  *     reference -- the reference ships no tests, golden vectors or fixtures, and its .cu files cannot be
  *     compiled here (no nvcc / CUDA headers / TBB).  Each function below follows the cited reference lines;

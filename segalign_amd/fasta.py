@@ -18,7 +18,7 @@ def kseq_records(buf):
     line filter: the first '>' or '@' ANYWHERE opens the first header; the name ends at the first isspace(); a sequence runs until a LINE that
     starts with '>', '@' or '+'; empty lines are skipped; one trailing CR is taken off the accumulated sequence after every line (when it is
     longer than one character, :141); '+' opens a quality block that swallows lines until it is as long as the sequence, and a block of another
-    length ends the whole read.  Pinned to the real header by tests/golden/kseq_golden.json (oracle/_ref/kseq_dump)."""
+    length ends the whole read.  Pinned to the real header by tests/golden/kseq_golden.json (the header itself compiled as it lies: tests/test_fasta_kseq.py)."""
     n, p, last, out = len(buf), 0, 0, []
     while True:
         if last == 0:   # jump to the next header character (:182-186)

@@ -21,7 +21,7 @@ static void die(int code, const char* fmt, const char* a = "") {
 //      first isspace(), the sequence runs until a LINE that starts with '>', '@' or '+', empty lines are skipped, one trailing CR is taken off the
 //      accumulated sequence after every line (when it is longer than one character, :141), '+' opens a quality block that swallows lines until it
 //      is as long as the sequence, a block of another length ends the whole read.  Pinned to the real header: tests/golden/kseq_golden.json
-//      (oracle/_ref/kseq_dump) and a fuzz against that binary (tests/test_fasta_kseq.py). ----
+//      (the header itself compiled as it lies) and a fuzz against that binary (tests/test_fasta_kseq.py). ----
 struct GzChars {
     gzFile f;
     unsigned char buf[1 << 16];

@@ -10,17 +10,18 @@ namespace sa {
 // default workload with 8 queues).  The runtime reads the variable when it initialises, i.e. at the first HIP call of the process.
 // A library has no business changing its host's environment (rounds 2-4 did, from a load-time constructor): the requirement is
 // documented (export GPU_MAX_HW_QUEUES=8, as bench.py and the C++ hosts do for themselves), and
-// InitializeProcessor says so ONCE on stderr when more than four slots per device meet an unset or smaller value.
+// InitializeProcessor says so ONCE on stderr whenever the slots of a device PLUS its upload stream outnumber the hardware queues --
+// which includes the default case, four slots on an unset variable (four queues): that is the configuration measured at -6 %.
 static void report_hw_queues(bool debug) {
     const char* v = getenv("GPU_MAX_HW_QUEUES");
     const int have = v ? atoi(v) : 4;
     static bool warned = false;
     if (debug)
         fprintf(stderr, "engine: %d slot(s) per device, GPU_MAX_HW_QUEUES=%s\n", SLOTS_PER_DEVICE, v ? v : "unset (the runtime's default is 4)");
-    if (!warned && have < 8 && SLOTS_PER_DEVICE > have) {
+    if (!warned && have < 8 && SLOTS_PER_DEVICE + 1 > have) {  // (+ 1: the upload stream shares the queues)
         warned = true;
-        fprintf(stderr, "segalign_amd: %d engine slots per device on %d hardware queues: calls in flight run pairwise one after the other; "
-                        "export GPU_MAX_HW_QUEUES=8 before the process initialises HIP (INTEGRATION.md)\n", SLOTS_PER_DEVICE, have);
+        fprintf(stderr, "segalign_amd: %d engine slots per device + the upload stream on %d hardware queues: streams that share a queue run one "
+                        "after the other; export GPU_MAX_HW_QUEUES=8 before the process initialises HIP (INTEGRATION.md)\n", SLOTS_PER_DEVICE, have);
     }
 }
 
@@ -304,8 +305,16 @@ void sa_clear_ref(void) {  // seed_filter_interface.cu:103-113
         dc->ref2.release("d_ref_seq 2-bit");
         dc->ref_host_ptr = nullptr;
         nbr_release(dc);
-        dc->bucket_start = dc->pos_table = nullptr;  // (the tables are forgotten; their memory stays for the next block: keep_bucket, keep_pos)
+        // The tables are forgotten; their MEMORY stays for the next block (keep_bucket, keep_pos, keep_nbr_start: a fresh allocation pays
+        // first-touch page clearing inside the next GenerateSeedPosTable, 0.37 -> 0.11 s per 500 Mbp block).  That departs from the
+        // reference, whose clearRef frees both tables: option clear_ref_frees = 1 restores it; ShutdownProcessor frees them either way.
+        dc->bucket_start = dc->pos_table = nullptr;
         dc->num_index = 0;
+        if (opt_value("clear_ref_frees")) {
+            dc->keep_bucket.release("d_index_table");
+            dc->keep_pos.release("d_pos_table");
+            dc->keep_nbr_start.release("nbr_start");
+        }
     }
 }
 

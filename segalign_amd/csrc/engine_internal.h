@@ -98,6 +98,11 @@ struct DevBuf {  // grow-only device buffer
     void ensure(size_t n, const char* tag, bool keep = false, hipStream_t s = 0) {
         if (n <= cap) return;
         size_t ncap = std::max(n, cap + cap / 2);
+        if (!keep && p && !in_region) {  // nothing to carry over: give the old buffer back FIRST (peak = max(old, new), not old + new)
+            dev_free(p, tag);
+            p = nullptr;
+            cap = 0;
+        }
         T* np = region ? (T*)region->take(ncap * sizeof(T)) : nullptr;
         const bool nr = np != nullptr;
         if (!np) np = (T*)dev_malloc(ncap * sizeof(T), tag);
@@ -237,6 +242,8 @@ constexpr int MAX_SLOTS_PER_DEVICE = 8;
 extern uint32_t SPEC_RECS;        // records of the speculative output copy (256 KB); option spec_recs (tests)
 extern uint32_t g_dedup_seg_max;  // option dedup_seg_max: records per segment the LDS chain accepts (0 = its LDS capacity; tests)
 constexpr int SA_MAX_CHUNKS = 256;  // chunks one multi-chunk call may carry: 2 reference iterations each = MAX_SEGS segments
+static_assert(SA_MAX_CHUNKS == (int)JOIN_SEG_FIRST && 2 * SA_MAX_CHUNKS <= MAX_SEGS,
+              "a call's chunks x 2 reference iterations = MAX_SEGS segments (d_seg_end holds MAX_SEGS u64); the join path's segment table (join.h) is cut at SA_MAX_CHUNKS");
 constexpr int SA_MAX_CHUNKS_GENERAL = 32;  // ... when it takes the general path (per-chunk iteration plans of up to 1000 iterations each)
 constexpr int SA_DEFAULT_CHUNKS = 40;  // ... and what the interval entries hand to one call: the 40 chunks of a strand of a 10 Mbp interval
 extern int SLOTS_PER_DEVICE;  // calls in flight per device (the reference allows one: token == device); option slots

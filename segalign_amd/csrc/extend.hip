@@ -34,6 +34,7 @@
 //     Address = one SDWA byte-select shift.
 //   * Integer DP only (no MFMA).  Survivors are appended with wave-aggregated atomics.  Append order is arbitrary;
 //     the dedup stage sorts on a total order, so the output is deterministic.
+#include <atomic>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -117,12 +118,12 @@ __device__ __forceinline__ void chunk8_exact(const int* __restrict__ s_tab, uint
 __device__ __forceinline__ uint32_t seg_of(const ExtendArgs& a, const uint64_t* __restrict__ s_seg, uint64_t local_idx, uint32_t query_loc) {
     if (a.join) {
         // key-ordered call (join.h): no hit indices.  `local_idx` is the hit's entry index inside its key's run, s_seg holds per chunk
-        // {p_last : e_thr} and, 256 entries further on, the chunk's first segment: second iteration of the chunk iff the hit sits at the
+        // {p_last : e_thr} and, JOIN_SEG_FIRST (= SA_MAX_CHUNKS) entries further on, the chunk's first segment: second iteration of the chunk iff the hit sits at the
         // chunk's last non-empty position at or behind the last hit-bearing seed word (src/seed_filter.cu:732-741)
         const uint32_t p = query_loc - a.seed_size;
         const uint32_t c = (p - a.join_q_lo) / a.join_chunk;
         const uint64_t w = s_seg[c];
-        return (uint32_t)s_seg[256u + c] + ((p == (uint32_t)w && (uint32_t)local_idx >= (uint32_t)(w >> 32)) ? 1u : 0u);
+        return (uint32_t)s_seg[(uint32_t)JOIN_SEG_FIRST + c] + ((p == (uint32_t)w && (uint32_t)local_idx >= (uint32_t)(w >> 32)) ? 1u : 0u);
     }
     const uint64_t g = a.hit_base + local_idx;
     uint32_t lo = 0, hi = (uint32_t)a.num_segs - 1u;  // answer in [lo, hi]; a hit beyond the last end belongs to the last segment
@@ -1049,18 +1050,8 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(E
         // (lanes past the call's last hit stay on the last record and run up to 63 entries past its run: still inside the table
         //  allocation -- the engine keeps a page of slack behind it -- and their verdict is discarded)
         const uint64_t entry = hnext.off + (uint64_t)((uint32_t)(b << 6) + (uint32_t)lane - hnext.prefix);  // run offset + index inside the run
-#ifdef SA_EXP_REC28  // EXPERIMENT (tools/r05_exp28.sh; timing only, the bytes read are not a record): what would 28-byte records buy?
-        {
-            const uint8_t* rp = reinterpret_cast<const uint8_t*>(ctx) + entry * 28ull;
-            __builtin_memcpy(&S.c0, __builtin_assume_aligned(rp, 4), 16);
-            uint3 t3;
-            __builtin_memcpy(&t3, __builtin_assume_aligned(rp + 16, 4), 12);
-            S.tl = make_uint4(t3.x, t3.y, t3.z, 0u);
-        }
-#else
         S.c0 = ctx[2 * entry];  // two aligned 16-byte loads: the stream of the kernel
-        S.tl = ctx[2 * entry + 1];
-#endif
+        S.tl = ctx[2 * entry + 1];  // (28-byte records were measured in round 5 and lost: profiles/r05/exp_rec28.txt)
         const uint32_t query_loc = hnext.qpos + a.seed_size;  // :204
         S.query_loc = query_loc;
         // copy (pos & 3, (pos >> 2) & 3) = copy number pos & 15, dword pos >> 4 (encode.hip); strides are multiples of 16 bytes, so
@@ -1989,12 +1980,13 @@ void launch_chain_group(const ExtendArgs& a, hipStream_t s) {  // chain_bucket_c
     hipLaunchKernelGGL(chain_scatter_kernel, dim3(1024), dim3(256), 0, s, a);
     // (chain_group_max = 4096 asks for 72 KB of dynamic LDS next to ~4.6 KB static: above the 64 KB a launch gets without being asked)
     const size_t sort_lds = (size_t)a.chain_group_max * (sizeof(uint32_t) + sizeof(CandRec) + sizeof(uint16_t)) + 4 * CHAIN_SORT_GROUP * sizeof(uint32_t);
-    static size_t sort_lds_set[64] = {0};  // per device ordinal: the attribute is per device
-    int dev = 0;
+    static std::atomic<size_t> sort_lds_set[64];  // per device ordinal (the attribute is per device); slot threads of a device race here:
+    int dev = 0;                                  // a stale read only repeats an idempotent hipFuncSetAttribute
     (void)hipGetDevice(&dev);
-    if (sort_lds > 48 * 1024 && dev >= 0 && dev < 64 && sort_lds_set[dev] < sort_lds) {
+    if (sort_lds > 48 * 1024 && dev >= 0 && dev < 64 && sort_lds_set[dev].load(std::memory_order_acquire) < sort_lds) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_sort_link_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds);
-        sort_lds_set[dev] = sort_lds;
+        size_t seen = sort_lds_set[dev].load(std::memory_order_relaxed);
+        while (seen < sort_lds && !sort_lds_set[dev].compare_exchange_weak(seen, sort_lds, std::memory_order_release)) {}
     }
     hipLaunchKernelGGL((chain_sort_link_kernel<true>), dim3(a.chain_sort_blocks ? a.chain_sort_blocks : 4096), dim3(a.chain_sort_threads ? a.chain_sort_threads : 256),
                        sort_lds, s, a);

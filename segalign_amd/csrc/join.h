@@ -16,6 +16,11 @@ constexpr int JOIN_CMAX = 16;        // query positions one entry pairs a run wi
 constexpr int JOIN_QX_DW = 20;       // dwords of a QRecX: query position + 8 right + 10 left field words + the left tail field
 constexpr uint32_t JOIN_TAIL_OFF = 16384u;  // byte offset of the four-base tail table behind the 4096 six-base entries (extend.hip cls_table_init)
 constexpr uint32_t JOIN_GRAIN = 256;        // work units (64-hit steps) a wave claims at a time
+// The segment table of a key-ordered call (ExtendArgs::seg_end, staged in LDS by SEG_TABLE(), read by seg_of): {p_last : e_thr} for chunk
+// c at [c], the chunk's first segment id at [JOIN_SEG_FIRST + c].  One call carries at most SA_MAX_CHUNKS = JOIN_SEG_FIRST chunks, two
+// segments each: the table fills the MAX_SEGS u64 the candidate stages stage (engine_internal.h asserts SA_MAX_CHUNKS against it).
+constexpr uint32_t JOIN_SEG_FIRST = 256;
+static_assert(2 * JOIN_SEG_FIRST <= (uint32_t)MAX_SEGS, "join segment table: {p_last, e_thr} x chunks | first segment x chunks must fit MAX_SEGS entries");
 
 // Per chunk of the call (device; the host reads them with the call's one synchronisation).  Only what the reference's iteration plan
 // needs: for num_hits < MAX_HITS the plan is "everything before the last hit-bearing seed word / that word's hits"
@@ -61,7 +66,7 @@ struct JoinArgs {             // what the filter (extend.hip 1e) needs on top of
 void launch_join_stats(const uint32_t* qk_start, const uint32_t* qpos, const uint64_t* nbr_start, uint32_t nkeys, uint32_t start, uint32_t chunk, int K,
                        unsigned long long* hits, uint32_t* valid, uint32_t* last1, hipStream_t s);
 void launch_join_plan(const uint8_t* query, SeedShape sh, uint32_t tmask, const uint32_t* bucket_start, const unsigned long long* hits, const uint32_t* valid,
-                      const uint32_t* last1, int K, JoinChunk* plan, uint64_t* seg_table /* [512]: {p_last, e_thr} x 256 | seg0 x 256 */, JoinHead* head, hipStream_t s);
+                      const uint32_t* last1, int K, JoinChunk* plan, uint64_t* seg_table /* [2 * JOIN_SEG_FIRST]: {p_last, e_thr} per chunk | seg0 per chunk */, JoinHead* head, hipStream_t s);
 void launch_join_entries(const uint32_t* qk_start, const uint64_t* nbr_start, uint32_t nkeys, JoinHead* head, uint4* ent, uint32_t* ent_nt, uint32_t ent_cap,
                          hipStream_t s);  // count -> layout -> scatter; head->cls_count must be zero on entry, ent_nt zero-filled
 void launch_join_finish(JoinHead* head, const unsigned long long* vstart, hipStream_t s);

@@ -20,7 +20,7 @@ namespace sa {
 
 constexpr int JS_THREADS = 1024;
 constexpr int JS_KEYS = 4;        // keys per thread
-constexpr int JS_MAXCH = 256;     // chunks of a call (SA_MAX_CHUNKS)
+constexpr int JS_MAXCH = (int)JOIN_SEG_FIRST;  // chunks of a call (= SA_MAX_CHUNKS, asserted in engine_internal.h)
 
 // ---- per-chunk statistics, from the key-sorted list: a key's run length is read once per key (sequentially), not once per position ----
 __global__ __launch_bounds__(JS_THREADS) void join_stats_kernel(const uint32_t* __restrict__ qk_start, const uint32_t* __restrict__ qpos,
@@ -41,6 +41,7 @@ __global__ __launch_bounds__(JS_THREADS) void join_stats_kernel(const uint32_t* 
         for (uint32_t i = qa; i < qb; i++) {
             const uint32_t p = qpos[i];
             const uint32_t c = (p - start) / chunk;
+            if (c >= (uint32_t)K) continue;  // (cannot happen: the front sorts exactly the positions of the call's K chunks)
             atomicAdd(&s_valid[c], 1u);
             if (n_t) {
                 atomicAdd(&s_hits[c], (unsigned long long)n_t);

@@ -120,6 +120,7 @@ static Option g_opts[] = {
     {"key_order_hits", 3ll << 30, 1 << 20, 1ll << 34, 0},  // ... capped so that a call stays below about this many seed hits (its lists are sized by them)
     {"key_order_min_pos", 0, 0, 1ll << 31, 0},         // positions a call must hold to go key-ordered under key_order = 1 (0: the number of seed keys)
     {"ctx_skip_seed", 1, 0, 1, 0},                     // context records hold the 58 bases in FRONT of the seed window, which the class filter bounds by seed_size x the largest class score (kernels.h CtxRec); 0: the bases left of the anchor, seed window included (A/B)
+    {"clear_ref_frees", 0, 0, 1, 0},                   // 1: g_ClearRef hipFrees the index / position / extent tables like the reference (seed_filter_interface.cu:103-113); 0 (default): it forgets the tables and KEEPS their buffers for the next target block (a fresh allocation pays first-touch page clearing inside the next GenerateSeedPosTable); ShutdownProcessor frees them either way
     {"table_scratch_arena", 1, 0, 1, 0},               // scratch of the seed table build (keys, pair arrays: ~10 GB per 500 Mbp block) carved from the mapped table arena instead of fresh hipMallocs (first-touch page clearing inside every GenerateSeedPosTable)
     {"log4_double", 0, 0, 1, 0},                       // entropy divisor (src/seed_filter.cu:623, hazard H2): 0 = (double)logf(4.0f) as nvcc compiles `log(4.0f)`, 1 = log(4.0) (a host compiler without <cmath>'s float overload in scope)
     {"entropy_ulps", 0, -4, 4, 1},                     // tests (hazard H13): entropy factor moved by this many ulps before the truncating multiplies

@@ -924,11 +924,11 @@ def dry_run(args, rank, world, dist, torch, shard, scaling):
     qlen = int((args.target_mbp or 100.0) * 1e6)
     seed_size = len(SHAPE)
     items = shard.plan_intervals(qlen, seed_size, args.interval)
-    jobs = shard.call_jobs(items, qlen - seed_size, args.chunk, 16)
+    jobs = shard.call_jobs(items, qlen - seed_size, args.chunk, args.chunks_per_call or 16)
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    bases, check = 0, 0
+    bases, check, my_chunks = 0, 0, 0
     for k in range(args.steps):
         # (strong: the real bench's default map, round-robin; --partition hits: weighted -- there by seed hits, here by the calls' lengths)
         todo = (shard.partition(jobs, rank, world, [j["b"] - j["a"] for j in jobs] if world > 1 and args.partition == "hits" else None,
@@ -939,6 +939,7 @@ def dry_run(args, rank, world, dist, torch, shard, scaling):
             w = 1 if scaling == "strong" else (i + 1)  # (weak: weighted by the walk position, so the walk order is checked too)
             for a in range(j["a"], j["b"], args.chunk):  # the stub engine: a checksum of the chunk bounds of the call
                 check += w * ((a * 31 + min(a + args.chunk, j["b"]) * 17 + int(j["rev"])) % 1000003)
+                my_chunks += 1
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -949,11 +950,19 @@ def dry_run(args, rank, world, dist, torch, shard, scaling):
         tb = torch.tensor([bases, check], dtype=torch.int64)
         dist.all_reduce(tb, op=dist.ReduceOp.SUM)
         bases, check = int(tb[0].item()), int(tb[1].item())
+    # the heaviest rank's share of the timed passes over the mean share, in chunks (the dry run has no hit counts)
+    mx = torch.tensor([my_chunks], dtype=torch.int64)
+    sm = torch.tensor([my_chunks], dtype=torch.int64)
+    if dist is not None:
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+    imbalance = float(mx.item()) * world / max(float(sm.item()), 1.0)
     if rank == 0:
         print(json.dumps({"metric": "Gbp query seeded+filtered+extended per sec", "value": bases / max(elapsed, 1e-9) / 1e9,
                           "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True, "scaling": scaling,
-                          "vs_baseline": None, "dtype": "int32", "data": "dry-run", "config": {"workload": "dry-run", "calls_per_step": len(jobs)},
+                          "vs_baseline": None, "dtype": "int32", "data": "dry-run", "config": {"workload": "dry-run", "calls_per_step": len(jobs),
+                                                                                                          "partition_imbalance": round(imbalance, 4)},
                           "bases": bases, "checksum": check}))
     if dist is not None:
         dist.destroy_process_group()

@@ -97,6 +97,46 @@ def test_configs2_block_chunks_bit_exact_vs_oracle(human_block, rev):
     assert np.array_equal(outs[1], E.SeedAndFilterRange(250000, 500000, rev, 0))
 
 
+# MAX_HITS of the GPUs the reference was run on (README.md:27; src/seed_filter.cu:832-841): 33.5 M on an 8 GiB M60, 66.2 M on a 16 GB V100,
+# against > 60 M hits per 250 kbp chunk of a 500 Mbp block -- see tests/test_gpu_config_lumpy.py.
+@pytest.mark.parametrize("name,mem", [("M60_8GiB", 8 << 30), ("V100_16GB", 16945512448)], ids=["M60_8GiB", "V100_16GB"])
+def test_configs2_heaviest_chunks_under_the_reference_gpus_max_hits(human_block, name, mem):
+    """The heaviest chunk of each strand of the query block and its two neighbours under the reference GPUs' MAX_HITS: single-chunk
+    device-seeded calls and the grouped entry against the oracle with the same MAX_HITS (iteration plans of :718-745 at human density)."""
+    E, O, query = human_block["E"], human_block["O"], human_block["query"]
+    mh = E.max_hits_for_mem(mem)
+    assert mh == O.max_hits_for_mem(mem)
+    end_pos = query.size - 19
+    E.set_max_hits(mh)
+    try:
+        split = 0
+        for rev in (False, True):
+            ch = [(a, min(a + 250000, end_pos), rev) for a in range(0, end_pos, 250000)]
+            hits = np.array(E.CountCallHits(ch, 0, 4), dtype=np.int64)
+            i = int(np.argmax(hits))
+            lo = max(0, min(i - 1, len(ch) - 3))
+            group = ch[lo:lo + 3]
+            qcodes = E.copy_query_codes(0, rev)
+            buf = query if not rev else np.frombuffer(O.rev_comp_ascii(query.tobytes(), 0, query.size), dtype=np.uint8)
+            want = []
+            for j, (a, b, _) in enumerate(group):
+                seeds = O.make_seeds(buf.tobytes(), 0, a, b, 19, human_block["k"], True)
+                w, ost = O.seed_and_filter(human_block["rcodes"], qcodes, human_block["index"], human_block["pos"], seeds, human_block["sub_mat"],
+                                           max_hits=mh)
+                assert ost["num_hits"] == hits[lo + j]
+                got = E.SeedAndFilterRange(a, b, rev, 0)
+                st = E.last_call_stats()
+                assert got.shape == w.shape and np.all(got == w), (name, rev, a, b, got.size, w.size)
+                split += int(ost["num_hits"] >= mh)
+                want.append(w[1:])
+            outs, _ = E.SeedCalls([(group[0][0], group[-1][1], rev)], 0, 1)
+            w_all = np.concatenate(want)
+            assert outs[0].shape == w_all.shape and np.all(outs[0] == w_all), (name, "grouped", rev)
+        assert (split == 6) if mem == 8 << 30 else (split < 6), (name, split)
+    finally:
+        E.set_max_hits(0)
+
+
 def test_configs2_block_multi_chunk_call_bit_exact_vs_oracle(human_block):
     """ONE call over sixteen chunks of the plus strand at human-scale hit density (~0.5 G hits, > 1 M chain candidates, tens
     of thousands of survivors in 32 dedup segments): every chunk's vector against the oracle."""

@@ -102,6 +102,54 @@ def test_twenty_chunk_call_around_the_heaviest_chunk_against_the_oracle(lumpy):
         assert outs[j].shape == want.shape and np.all(outs[j] == want), (rev, j, a, b, outs[j].size, want.size)
 
 
+# What the reference's TESTED hardware does with these chunks (README.md:27: AWS G3 = Tesla M60, 8 GiB; AWS P3 = V100, 16 GB):
+# MAX_HITS = (int)(4194304 x GiB of device 0) (src/seed_filter.cu:832-841) is 33.5 M / 66.2 M there, against ~43 M hits per chunk of this
+# workload (heaviest ~51 M): on the M60 nearly every call takes the `num_hits >= MAX_HITS` branch (:718-745) and runs its sort / unique /
+# sort per sub-iteration, on the V100 none does.  The MI355X's own MAX_HITS (1.2 G) never splits, so without these cases the engine's
+# parity at workload density is parity with a GPU the reference never ran on.
+REF_GPU_MEM = [("M60_8GiB", 8 << 30), ("V100_16GB", 16945512448)]
+
+
+@pytest.mark.parametrize("name,mem", REF_GPU_MEM, ids=[n for n, _ in REF_GPU_MEM])
+def test_heaviest_chunks_under_the_reference_gpus_max_hits(lumpy, name, mem):
+    """The heaviest chunk of each strand and its two neighbours with MAX_HITS of the reference's GPUs: the device-seeded single-chunk
+    entry and the grouped entry (sa_seed_calls: the three chunks in one pass) against the oracle run with the same MAX_HITS."""
+    E, O = lumpy["E"], lumpy["O"]
+    mh = E.max_hits_for_mem(mem)
+    assert mh == O.max_hits_for_mem(mem) == int(4194304 * np.float32(mem / 1073741824.0))
+    E.set_max_hits(mh)
+    try:
+        split = 0
+        for rev in (False, True):
+            ch, hits = chunk_hits(lumpy, rev)
+            i = int(np.argmax(hits))
+            lo = max(0, min(i - 1, len(ch) - 3))
+            group = ch[lo:lo + 3]
+            buf = lumpy["rc_ascii"] if rev else lumpy["query"]
+            qcodes = E.copy_query_codes(0, rev)
+            want = []
+            for j, (a, b, _) in enumerate(group):
+                seeds = O.make_seeds(buf.tobytes(), 0, a, b, 19, lumpy["k"], True)
+                w, ost = O.seed_and_filter(lumpy["rcodes"], qcodes, lumpy["index"], lumpy["pos"], seeds, lumpy["sub_mat"], max_hits=mh)
+                assert ost["num_hits"] == hits[lo + j]
+                got = E.SeedAndFilterRange(a, b, rev, 0)
+                st = E.last_call_stats()
+                assert got.shape == w.shape and np.all(got == w), (name, rev, a, b, got.size, w.size)
+                if ost["num_hits"] >= mh:
+                    split += 1
+                    assert st["path_flags"] & E.PATH_GENERAL_FALLBACK     # the reference-shaped plan ran (seeds.hip plan_kernel)
+                else:
+                    assert st["lookup_path"] == 2
+                want.append(w[1:])
+            outs, _ = E.SeedCalls([(group[0][0], group[-1][1], rev)], 0, 1)
+            w_all = np.concatenate(want)
+            assert outs[0].shape == w_all.shape and np.all(outs[0] == w_all), (name, "grouped", rev, outs[0].size, w_all.size)
+        # the M60 splits every one of these calls; the V100 none (heaviest chunk 51 M < 66.2 M)
+        assert split == (6 if mem == 8 << 30 else 0), (name, split)
+    finally:
+        E.set_max_hits(0)
+
+
 def test_the_rare_branches_were_taken(lumpy):
     """(runs after the calls above) what a skewed k-mer spectrum reaches at workload size, by sa_call_stats.path_flags: a dedup segment
     above the LDS chain's 2048 records (library sorts + the tiled unique) and a head-bit map regrown for a call denser than 128 hits

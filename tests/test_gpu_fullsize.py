@@ -1,10 +1,13 @@
 """GPU, BASELINE.json full size (configs[1] stand-in: 100 Mbp target, 250 kbp chunks): the oracle cannot run the
 whole workload in seconds, so parity is checked through size-independent properties on a few calls, plus bit-exact
-oracle agreement on one full chunk-call per strand (the table is copied from the device for the oracle)."""
+oracle agreement on full chunk calls, forty-chunk calls and repeat-masker intervals.  The oracle borrows NOTHING from the
+device here: it builds its own seed position table from the ASCII target (orc_generate_seed_pos_table,
+common/seed_pos_table.cu:49-109) and encodes both sequences itself (common/seed_filter_interface.cu:18-47,
+src/seed_filter.cu:110-155); the device's tables and codes are held against those first."""
 import numpy as np
 import pytest
 
-from helpers import check_seed_table_properties
+from helpers import canonical_pos_table, check_seed_table_properties
 from segalign_amd import shard, synth
 
 pytestmark = pytest.mark.gpu
@@ -24,8 +27,25 @@ def full(oracle, engine, standin_100mbp):
     keep = E.SendRefWriteRequest(target, 0, target.size)
     E.GenerateSeedPosTable(keep, 0, target.size, 1, 19, k)
     E.SendQueryWriteRequest(query, 0, query.size, 0)
-    yield dict(E=E, O=O, target=target, query=query, sub_mat=sub_mat, k=k)
+    # the oracle's OWN table and codes, from the ASCII (serial counting sort: ~20 s for 100 Mbp)
+    o_index, o_pos = O.generate_seed_pos_table(target.tobytes(), 0, target.size, 1, 19, k)
+    o_rcodes = O.encode(target.tobytes())
+    o_q, o_qrc = O.encode_rev_comp(query.tobytes())
+    yield dict(E=E, O=O, target=target, query=query, sub_mat=sub_mat, k=k, o_index=o_index, o_pos=o_pos, o_rcodes=o_rcodes, o_q=o_q, o_qrc=o_qrc)
     E.ShutdownProcessor()
+
+
+def test_device_table_and_codes_equal_the_oracles_own_at_full_size(full):
+    """a-5 / a-3 at workload size without properties standing in for equality: bucket ends word for word, positions bucket by bucket
+    (canonical order inside a bucket, hazard H7), target codes, query codes of both strands."""
+    E = full["E"]
+    index, pos = E.copy_index_table(), E.copy_pos_table()
+    assert index.size == full["o_index"].size == 1 << 24 and np.array_equal(index, full["o_index"])
+    assert pos.size == full["o_pos"].size > 80_000_000
+    if not np.array_equal(pos, full["o_pos"]):      # (the oracle's buckets ascend; the device sorts every bucket the LDS holds)
+        assert np.array_equal(canonical_pos_table(index, pos), canonical_pos_table(full["o_index"], full["o_pos"]))
+    assert np.array_equal(E.copy_ref_codes(), full["o_rcodes"])
+    assert np.array_equal(E.copy_query_codes(0, False), full["o_q"]) and np.array_equal(E.copy_query_codes(0, True), full["o_qrc"])
 
 
 def test_table_is_a_permutation_of_valid_positions(full):
@@ -83,8 +103,8 @@ def test_hsp_invariants_at_full_size(full):
 @pytest.mark.parametrize("rev", [False, True])
 def test_one_full_chunk_bit_exact_vs_oracle(full, rev):
     E, O, query = full["E"], full["O"], full["query"]
-    index, pos = E.copy_index_table(), E.copy_pos_table()
-    rcodes, qcodes = E.copy_ref_codes(), E.copy_query_codes(0, rev)
+    index, pos = full["o_index"], full["o_pos"]
+    rcodes, qcodes = full["o_rcodes"], full["o_qrc"] if rev else full["o_q"]
     buf = query if not rev else np.frombuffer(O.rev_comp_ascii(query.tobytes(), 0, query.size), dtype=np.uint8)
     a, b = 70_000_000, 70_250_000
     seeds = O.make_seeds(buf.tobytes(), 0, a, b, 19, full["k"], True)
@@ -99,14 +119,14 @@ def test_multi_chunk_calls_bit_exact_vs_oracle_at_full_size(full):
     against the oracle: the multi-chunk machinery (40 reference iterations in one pass, relative chain keys, per-segment LDS
     chains, speculative output copy) at the workload's real hit density."""
     E, O, query = full["E"], full["O"], full["query"]
-    index, pos = E.copy_index_table(), E.copy_pos_table()
-    rcodes = E.copy_ref_codes()
+    index, pos = full["o_index"], full["o_pos"]
+    rcodes = full["o_rcodes"]
     qlen = query.size - 19
     iv = (40_000_000, 45_000_000)
     fw, rc, st = E.SeedInterval(iv[0], iv[1], qlen, E.STRAND_BOTH, 0, 2)
     hits = 0
     for rev, got in ((False, fw), (True, rc)):
-        qcodes = E.copy_query_codes(0, rev)
+        qcodes = full["o_qrc"] if rev else full["o_q"]
         buf = query if not rev else np.frombuffer(O.rev_comp_ascii(query.tobytes(), 0, query.size), dtype=np.uint8)
         want = []
         for (a, b) in shard.chunks_of(iv, 250000, qlen, rev):
@@ -130,8 +150,8 @@ def test_the_bench_default_calls_bit_exact_vs_oracle_and_its_checksum(full):
     import subprocess
     import sys
     E, O, query = full["E"], full["O"], full["query"]
-    index, pos = E.copy_index_table(), E.copy_pos_table()
-    rcodes = E.copy_ref_codes()
+    index, pos = full["o_index"], full["o_pos"]
+    rcodes = full["o_rcodes"]
     qlen = query.size - 19
     cpc = E.lib().sa_get_chunks_per_call()
     assert cpc == 40
@@ -143,7 +163,7 @@ def test_the_bench_default_calls_bit_exact_vs_oracle_and_its_checksum(full):
     chk_oracle = chk_engine = n_hsps = 0
     for j, got in zip(jobs, outs):
         rev = j["rev"]
-        qcodes = E.copy_query_codes(0, rev)
+        qcodes = full["o_qrc"] if rev else full["o_q"]
         buf = query if not rev else np.frombuffer(O.rev_comp_ascii(query.tobytes(), 0, query.size), dtype=np.uint8)
         want, o_hits = [], 0
         for a in range(j["a"], j["b"], 250000):
@@ -173,10 +193,10 @@ def full_rm(full):
     """run_segalign_repeat_masker's engine state: the query IS the target (repeat_masker_src/seed_filter.cu:951-961)."""
     E, O, target = full["E"], full["O"], full["target"]
     E.RmSendQueryWriteRequest()
-    rcodes = E.copy_ref_codes()
+    rcodes = full["o_rcodes"]   # (the oracle's own codes and table: see the module docstring)
     yield dict(full, rcodes=rcodes, rc_codes=O.rev_comp_codes(rcodes),
                rc_ascii=np.frombuffer(O.rev_comp_ascii(target.tobytes(), 0, target.size), dtype=np.uint8),
-               index=E.copy_index_table(), pos=E.copy_pos_table())
+               index=full["o_index"], pos=full["o_pos"])
     E.RmClearQuery()
 
 
@@ -208,7 +228,7 @@ def test_configs3_repeat_masker_plan_intervals_properties(full_rm):
 @pytest.mark.parametrize("strands", [1, 2])
 def test_configs3_repeat_masker_chunks_bit_exact_vs_oracle(full_rm, strands):
     """Two 250 kbp chunks of one interval, one strand per case: sa_rm_seed_and_filter (windowed SeedAndFilter, rm
-    :724-876) and sa_rm_mask_interval (the whole seeder body) against the oracle, table copied from the device."""
+    :724-876) and sa_rm_mask_interval (the whole seeder body) against the oracle on its own table."""
     E, O, target = full_rm["E"], full_rm["O"], full_rm["target"]
     L, chunk = target.size, 250000
     rev = strands == 2

@@ -147,3 +147,60 @@ def test_hit_counts_by_lookup_equal_the_calls_own_counts(oracle, engine, two_dev
         assert per_chunk == E.CountCallHits(singles, 0, 4)
     finally:
         E.ShutdownProcessor()
+
+
+def test_eight_engine_devices_times_six_slots_on_one_node(oracle, engine):
+    """What the driver's 8-GPU run instantiates in ONE process under the reference's own model (all visible devices behind one token pool,
+    common/seed_filter_interface.cu:49-80): 8 engine devices x 6 slots = 48 tokens, 48 streams + 8 upload streams, 48 engine worker
+    threads, 8 table arenas and 8 work arenas, 8 concurrent table builds.  On a one-GPU box the eight are twins on ordinal 0 (arenas
+    kept small: 8 x the default 40 + 18 GiB would not fit one GPU); on an 8-GPU node they are the eight GPUs.  Checked: every device
+    holds the oracle's table, every device takes calls, the call list's HSPs equal the one-device run's and the oracle's."""
+    E = engine
+    ids = engine_devices(E, 8)
+    E.set_option("slots", 6)
+    E.set_option("arena_gb", 2)
+    E.set_option("work_gb", 1)
+    t, q = synth.make_pair(4_000_000, 51, 52, sub_rate=0.09, mask_frac=0.15, records=3, invert_frac=0.3, invert_block=50_000, indel_every=700)
+    c = Case(t, q, chunk=50_000).oracle_setup(oracle)
+    try:
+        c.engine_setup(E, num_gpu=-1)
+        for d in range(8):
+            assert np.array_equal(E.copy_index_table(d), c.o_index) and np.array_equal(E.copy_pos_table(d), c.o_pos)
+        ivs = shard.plan_intervals(q.size, 19, 1_000_000)
+        jobs = shard.call_jobs(ivs, q.size - 19, 50_000, 2)            # 2-chunk calls: ~80 calls for 48 slots
+        devs, hits = [], []
+        outs, st = E.SeedCalls([(j["a"], j["b"], j["rev"]) for j in jobs], 0, 48, hits_out=hits, devices_out=devs)
+        assert len(jobs) >= 64 and set(devs) == set(range(8)), sorted(set(devs))
+        # the oracle, chunk by chunk
+        n = 0
+        for j, got in zip(jobs, outs):
+            want = [c.oracle_saf(c.host_seeds(a, min(a + 50_000, j["b"]), j["rev"]), j["rev"])[0][1:] for a in range(j["a"], j["b"], 50_000)]
+            want = np.concatenate(want)
+            assert seg_equal(got, want), (j["a"], j["b"], j["rev"])
+            n += want.size
+        assert n > 200
+        # 48 HOST threads through the drop-in and the device-seeded entry at once (the reference's TBB seeder bodies, src/seeder.cpp:78)
+        chunks = [(rev, s, e) for rev in (False, True) for (s, e) in c.chunks()]
+        want1 = {j: c.oracle_saf(c.host_seeds(j[1], j[2], j[0]), j[0])[0] for j in chunks[:96]}
+        bad, seen = [], set()
+        lock = threading.Lock()
+
+        def work(my):
+            for j in my:
+                a = E.SeedAndFilter(c.host_seeds(j[1], j[2], j[0]), j[0], 0)
+                d = E.last_call_stats()["device"]
+                b = E.SeedAndFilterRange(j[1], j[2], j[0], 0)
+                with lock:
+                    seen.add(d)
+                    if not (seg_equal(a, want1[j]) and seg_equal(b, want1[j])):
+                        bad.append(j)
+
+        ths = [threading.Thread(target=work, args=(list(want1)[i::48],)) for i in range(48)]
+        [th.start() for th in ths]
+        [th.join() for th in ths]
+        assert not bad and len(seen) >= 4, (bad[:3], seen)
+    finally:
+        E.ShutdownProcessor()
+        E.select_devices([])
+        E.reset_option(None)
+        E.ReleaseArena()

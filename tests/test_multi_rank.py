@@ -24,10 +24,10 @@ def test_interval_and_chunk_plan_matches_reference_rules():
     assert sorted(parts[0] + parts[1]) == ivs and not set(parts[0]) & set(parts[1])
 
 
-def _run(nproc, steps, scaling="strong", port=29541):
+def _run(nproc, steps, scaling="strong", port=29541, mbp=60, extra=()):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", str(steps), "--warmup", "0",
-            "--dry-run", "--target-mbp", "60", "--scaling", scaling]
+            "--dry-run", "--target-mbp", str(mbp), "--scaling", scaling] + list(extra)
     if nproc == 1:
         cmd = base
     else:
@@ -151,3 +151,17 @@ def test_weak_scaling_rank_walks_and_reduction_match_the_model():
     assert (one["bases"], one["checksum"]) == _model(1, 2, "weak")
     assert (two["bases"], two["checksum"]) == _model(2, 2, "weak")
     assert two["bases"] == 2 * one["bases"]  # weak scaling: per-GPU work is fixed
+
+
+def test_world_8_on_the_human_deal_is_even_and_keeps_the_checksum():
+    """The driver's N = 8 launch on configs[2]'s call list: one 500 Mbp query block in 15-chunk calls = 268 calls per pass (what
+    sa_get_chunks_per_call() gives a 500 Mbp target block: tools/human_grid.py), dealt round-robin with the deal continuing from pass
+    to pass.  Eight gloo ranks, launched as the driver launches them: every call exactly once per pass (checksum and bases equal the
+    one-rank run's), and no rank carries more than 1.04 x the mean share."""
+    extra = ["--chunks-per-call", "15"]
+    one = _run(1, 2, mbp=500, extra=extra)
+    eight = _run(8, 2, port=29549, mbp=500, extra=extra)
+    assert one["config"]["calls_per_step"] == eight["config"]["calls_per_step"] == 268
+    assert eight["n_gpus"] == 8 and (eight["bases"], eight["checksum"]) == (one["bases"], one["checksum"])
+    assert one["bases"] == 2 * (500_000_000 - 19)
+    assert 1.0 <= eight["config"]["partition_imbalance"] <= 1.04, eight["config"]["partition_imbalance"]

@@ -207,6 +207,7 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                 ea.hspthresh = g_hspthresh;
                 ea.noentropy = g_noentropy;
                 ea.left_skip = dc->nbr_left_skip;
+                ea.l2_right_state = (uint32_t)opt_value("l2_right_state");
                 ea.log4_double = g_log4_double;
                 ea.entropy_ulps = g_entropy_ulps;
                 ea.num_hits = bh;
@@ -308,7 +309,15 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                             launch_join_filter(ea, ja, st);
                         } else {
                             ProfScope p(sl, "extend_filter");
-                            launch_extend_filter_cls(ea, st);
+                            if (sl->stream_lo) {  // (option filter_prio: the class filter alone on the slot's low-priority stream)
+                                hipEventRecord(sl->ev_lo_a, st);
+                                hipStreamWaitEvent(sl->stream_lo, sl->ev_lo_a, 0);
+                                launch_extend_filter_cls(ea, sl->stream_lo);
+                                hipEventRecord(sl->ev_lo_b, sl->stream_lo);
+                                hipStreamWaitEvent(st, sl->ev_lo_b, 0);
+                            } else {
+                                launch_extend_filter_cls(ea, st);
+                            }
                         }
                         ExtendArgs e2 = ea;
                         e2.td = 0;

@@ -270,6 +270,8 @@ struct Slot {
     int dev = 0;
     DevCtx* ctx = nullptr;            // the device context this slot belongs to
     hipStream_t stream = nullptr;
+    hipStream_t stream_lo = nullptr;  // option filter_prio: a lowest-priority stream the class filter alone is launched on (the slot's own stream
+    hipEvent_t ev_lo_a = nullptr, ev_lo_b = nullptr;  // is then created with the highest priority), bracketed by these two events
     DevBuf<uint64_t> seeds;
     DevBuf<uint32_t> start, count, flags, flag_prefix;
     DevBuf<uint64_t> prefix;

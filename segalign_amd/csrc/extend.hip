@@ -747,7 +747,9 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
                     best = m;
                     phase = PH_FIN;
                 }
-            } else if (walked >= long_cap) {  // still alive after long_cap bases: real homology -> exact kernel
+            } else if (walked + (uint32_t)(64 - CTX_R_BASES) >= long_cap) {  // still alive after long_cap bases: real homology -> exact kernel
+                // (walks from the anchor count 64, 128, ...; a left walk resumed behind level 1's context 77 + 64; a right walk resumed there
+                //  54 + 64 = 118, which counts as the 128 it replaces: ONE window behind the context instead of two from the anchor)
                 forward = true;
                 phase = PH_FIN;
             }
@@ -846,6 +848,12 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
                         if (SRC == SRC_CAND && mine_flags == 1u) {  // left side settled by level 1
                             left_known = true;
                             left_best = (int)mine_known;
+                            if (a.l2_right_state) {  // ... and the right walk resumes behind level 1's context from its packed state: an upper
+                                walked = (uint32_t)CTX_R_BASES;  // bound of the exact walk's (running score, best) there, like the left one's
+                                const short t16 = (short)(mine_tm & 0xFFFFu), m16 = (short)(mine_tm >> 16);
+                                T = (s16x2){t16, t16};
+                                M = (s16x2){m16, m16};
+                            }
                         }
                     }
                 } else {
@@ -1108,6 +1116,7 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(E
         // alive: never more than xdrop below its best at a field end (:374; without W: at the end of the context)
         const bool r_alive = (int)(short)((CLS_TRACK_DROP ? Wd : P) & 0xFFFFu) >= -xdrop;
         const int bestR = ((int)P >> 16) - (int)(short)(P & 0xFFFFu);  // best = T - N
+        const uint32_t PR = P;  // the right walk's register at the end of its context: level 2 resumes from it (L2Rec, flags 1)
         // ---- left side (:478-604): the seed window bounded by seed_state (no lookup), then 58 bases = 9 fields + a four-base tail ----
         P = seed_state; Wd = 0;
         cls_step(s_cls, cls_field_addr<12>(x3, x4), P, Wd);
@@ -1130,8 +1139,9 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(E
             cr.ref_loc = ref_loc;
             cr.query_loc = query_loc;
             cr.hidx = (uint32_t)(b << 6) + (uint32_t)lane;
-            cr.state = (P & 0xFFFF0000u) | ((0u - P) & 0xFFFFu);  // the left walk's state as {T : D = -N}: used when only the left side is open
             const uint32_t fl = (r_alive ? 1u : 0u) | (l_alive ? 2u : 0u);  // 0 (both settled, the bound passes) -> 3: level 2 re-walks both
+            const uint32_t Ps = (fl == 1u && a.l2_right_state) ? PR : P;    // the walk level 2 resumes: the left one, or the right one when it alone is open
+            cr.state = (Ps & 0xFFFF0000u) | ((0u - Ps) & 0xFFFFu);          // as {T : D = -N}
             cr.meta = (uint32_t)(r_alive ? bestL : bestR) | ((fl ? fl : 3u) << 16);
             // -> the wave's LDS stage (rank by v_mbcnt on the ballot), flushed 64 records at a time
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
@@ -1315,8 +1325,9 @@ __global__ __launch_bounds__(JOIN_THREADS, 8) void join_filter_kernel(ExtendArgs
                         cr.ref_loc = ref_loc;
                         cr.query_loc = query_loc;
                         cr.hidx = tidx;
-                        cr.state = (PL & 0xFFFF0000u) | ((0u - PL) & 0xFFFFu);
                         const uint32_t fl = (r_alive ? 1u : 0u) | (l_alive ? 2u : 0u);
+                        const uint32_t Ps = (fl == 1u && a.l2_right_state) ? PR : PL;  // (1d: the walk level 2 resumes)
+                        cr.state = (Ps & 0xFFFF0000u) | ((0u - Ps) & 0xFFFFu);
                         cr.meta = (uint32_t)(r_alive ? bestL : bestR) | ((fl ? fl : 3u) << 16);
                         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
                         if (fwd) stage[n_stage + (int)rank] = cr;

@@ -47,7 +47,8 @@ struct CandRec {              // a hit the X-drop filter could not reject: exten
 //   state: the packed (score : drop) register of level 1's LEFT walk at the end of its context (seed window + CTX_L_BASES; extend.hip 1d)
 //   meta : known (16 bits) | flags (2 bits) << 16
 //     flags bit 0: right side undecided, bit 1: left side undecided
-//     flags 1: known = bestL (the left side is settled), the right side is walked from the anchor
+//     flags 1: known = bestL (the left side is settled); the right side is walked from the anchor -- or, with ExtendArgs::l2_right_state,
+//              resumes behind level 1's CTX_R_BASES context from `state`, which then holds the RIGHT walk's register (round 6)
 //     flags 2: known = bestR, the left walk continues behind level 1's context from `state`
 //     flags 3: both sides from the anchor (also: both settled but the bound passes -- the exact pair scores of level 2 get a say)
 struct L2Rec {
@@ -116,6 +117,8 @@ struct ExtendArgs {
     int xdrop;
     int hspthresh;
     int noentropy;
+    uint32_t l2_right_state;  // 1: a hit whose RIGHT side alone is open reaches level 2 with the right walk's packed state (L2Rec), and level 2 resumes
+                              // behind the CTX_R_BASES context instead of at the anchor (option l2_right_state)
     uint32_t left_skip;       // bases of the seed window the class filter bounds instead of walking (CtxRec): seed_size, or 0 (option ctx_skip_seed = 0: round 4's layout)
     int log4_double;          // entropy divisor: 0 = (double)logf(4.0f), what the reference's `log(4.0f)` is under nvcc (hazard H2); 1 = log(4.0)
     int entropy_ulps;         // tests (hazard H13): the entropy factor moved by this many ulps (nextafter) before it is used

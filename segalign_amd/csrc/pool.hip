@@ -45,7 +45,21 @@ void slot_init(Slot& s, DevCtx* dc) {
     s.jq_keys.region = s.jq_pairs.region = s.jq_pos.region = s.jq_ent_nt.region = s.jq_qx.region = &s.work;
     s.jq_ent.region = &s.work;
     s.jq_vstart.region = &s.work;
-    hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+    if (opt_value("filter_prio")) {
+        // Experiment (round 6, verdict item 5): with six calls in flight the 20-200 us kernels of a call queue behind the other calls'
+        // class filters (extend_entropy 19 -> 707 us, dedup_seg 50 -> 774 us in the timed region).  Here every slot's stream gets the
+        // highest queue priority and the class filter is launched on a second, lowest-priority stream of the slot.
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // (numerically: lo = least urgent >= hi = most urgent)
+        if (hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, hi) != hipSuccess) hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+        if (hipStreamCreateWithPriority(&s.stream_lo, hipStreamNonBlocking, lo) != hipSuccess) s.stream_lo = nullptr;
+        if (s.stream_lo && (hipEventCreateWithFlags(&s.ev_lo_a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.ev_lo_b, hipEventDisableTiming) != hipSuccess)) {
+            hipStreamDestroy(s.stream_lo);
+            s.stream_lo = nullptr;
+        }
+    } else {
+        hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+    }
     s.d_plan = (IterPlan*)dev_malloc(sizeof(IterPlan) * SA_MAX_CHUNKS_GENERAL, "plan");
     s.d_seg_end = (uint64_t*)dev_malloc(sizeof(uint64_t) * MAX_SEGS, "segment ends");
     s.d_cnt = (Counters*)dev_malloc(sizeof(Counters), "counters");
@@ -117,6 +131,7 @@ void slot_destroy(Slot& s) {
     s.work.used = 0;
     for (auto& e : s.event_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     s.event_pool.clear();
+    if (s.stream_lo) { hipStreamDestroy(s.stream_lo); hipEventDestroy(s.ev_lo_a); hipEventDestroy(s.ev_lo_b); s.stream_lo = nullptr; s.ev_lo_a = s.ev_lo_b = nullptr; }
     if (s.stream) hipStreamDestroy(s.stream);
     s.stream = nullptr;
 }

@@ -340,7 +340,7 @@ def main():
     chunk_hits = None   # {(rev, chunk start): seed hits} of every 250 kbp piece of the pass
 
     def count_chunk_hits():
-        per_chunk = E.CountCallHits([(j["a"], j["b"], j["rev"]) for j in jobs], 0, inflight, per_chunk=True)
+        per_chunk = E.CountCallHits([(j["a"], j["b"], j["rev"]) for j in jobs], qbuf[0], inflight, per_chunk=True)
         keys = [(j["rev"], c) for j in jobs for c in range(j["a"], j["b"], args.chunk)]
         return dict(zip(keys, per_chunk))
 

@@ -42,11 +42,9 @@ size_t saf_core(DevCtx* dc, Slot* sl, uint32_t num_seeds, const CoreArgs& ca, sa
                 chunk_first_seg[c] = (uint32_t)segs.size();
                 chunk_hits[c] = tp.num_hits;
                 sbound[c + 1] = sbound[c] + tp.num_valid * ca.td_words;
-                if (tp.num_hits > 0) {  // num_hits < MAX_HITS: exactly two iterations (:721-724,:732-741)
-                    segs.push_back({0, tp.split});
-                    segs.push_back({0, tp.hit_base + tp.num_hits});
-                    t_stats.num_iter += 2;
-                }
+                // the chunk's reference iterations (:718-745) as probe_plan_kernel planned them: two below MAX_HITS, the greedy groups above
+                for (uint32_t i = 0; i < tp.n_iter && tp.n_iter != TD_PLAN_OVERFLOW; i++) segs.push_back({0, tp.upto[i]});
+                if (tp.n_iter != TD_PLAN_OVERFLOW) t_stats.num_iter += tp.n_iter;
                 num_hits = tp.hit_base + tp.num_hits;
             }
             chunk_first_seg[K] = (uint32_t)segs.size();

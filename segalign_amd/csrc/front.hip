@@ -219,8 +219,9 @@ bool td_eligible(DevCtx* dc, const PackedBuf* query4, const PackedBuf* q2_own, c
 
 // Position probe + chunk plans for query positions [bpos[0], bpos[K]) (chunk c = [bpos[c], bpos[c+1])); one D2H, one sync.
 // Returns the number of seed words the reference would have been handed (0: nothing to do), or UINT32_MAX when the call must
-// take the general path: a chunk with num_hits >= MAX_HITS (more than two reference iterations), hit counts that wrap the
-// reference's uint32 arithmetic, or more than 2^32 hits in the call (the filter indexes hits with 32 bits).
+// take the general path (or be halved): a chunk that needs more than TD_MAX_ITER reference iterations (num_hits >= 6 x MAX_HITS), more
+// than MAX_SEGS iterations in the call, hit counts that wrap the reference's uint32 arithmetic, or more than 2^32 hits in the call
+// (the filter indexes hits with 32 bits).
 uint32_t td_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, int K, const uint32_t* bpos, int rm, uint32_t* words_out) {
     hipStream_t st = sl->stream;
     const uint32_t start = bpos[0], end = bpos[K];
@@ -271,7 +272,8 @@ uint32_t td_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, int K, const uint
         }
         {
             ProfScope p(sl, "iteration_plan");
-            launch_probe_plan(qcodes, sh, tmask, dc->bucket_start, sl->d_td_bounds, K, sl->td_rec.p, sl->d_td_plan, sl->d_seg_end, st);
+            launch_probe_plan(qcodes, sh, tmask, dc->bucket_start, sl->d_td_bounds, K, sl->td_rec.p, (uint64_t)(uint32_t)g_max_hits, rm ? 0 : 1, sl->d_td_plan,
+                              sl->d_seg_end, st);
         }
         check_launch("probe");
         check_memcpy(hipMemcpyAsync(sl->h_td_plan, sl->d_td_plan, sizeof(TdPlan) * K, hipMemcpyDeviceToHost, st), "probe plan");
@@ -282,13 +284,17 @@ uint32_t td_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, int K, const uint
         sl->td_bits.ensure((size_t)need_words + need_words / 4, "probe head bits(grow)");
         t_front_flags |= SA_PATH_HEAD_BITS_REGROWN;
     }
-    uint64_t nvalid = 0;
+    uint64_t nvalid = 0, n_iter = 0;
     for (int c = 0; c < K; c++) {
         const TdPlan& tp = sl->h_td_plan[c];
         nvalid += tp.num_valid;
-        if (tp.num_hits >= (uint64_t)(uint32_t)g_max_hits) return 0xFFFFFFFFu;
+        // a chunk at or above MAX_HITS stays table-direct as long as the reference's greedy groups (:725-741) number <= TD_MAX_ITER and its
+        // counts cannot wrap the reference's uint32 arithmetic (probe_plan_kernel); otherwise the general path plans it
+        if (tp.n_iter == TD_PLAN_OVERFLOW) return 0xFFFFFFFFu;
         if (!rm && tp.num_hits > 0xFFFFFFFFull) return 0xFFFFFFFFu;
+        n_iter += tp.n_iter;
     }
+    if (n_iter > (uint64_t)MAX_SEGS) return 0xFFFFFFFFu;  // (more iterations than one extension batch resolves: the pass is halved, api_calls.hip)
     if (sl->h_td_plan[K - 1].hit_base + sl->h_td_plan[K - 1].num_hits >= 0xFFFFFFFFull) return 0xFFFFFFFFu;  // (hit indices are 32-bit, 2^32 - 1 is a sentinel)
     if (nvalid * words >= 0xFFFFFFFFull) return 0xFFFFFFFFu;
     return (uint32_t)(nvalid * words);
@@ -405,7 +411,9 @@ uint32_t join_front(DevCtx* dc, Slot* sl, const uint8_t* qcodes, uint32_t qlen, 
         TdPlan& tp = sl->h_td_plan[c];
         tp.hit_base = hit_base;
         tp.num_hits = jc.hits;
-        tp.split = hit_base;  // (hit offsets only size the lists of a key-ordered call: its segments are resolved per hit, extend.hip seg_of)
+        tp.n_iter = jc.hits ? 2u : 0u;  // (hit offsets only size the lists of a key-ordered call: its segments are resolved per hit, extend.hip seg_of)
+        tp.upto[0] = hit_base;
+        tp.upto[1] = hit_base + jc.hits;
         tp.num_valid = jc.valid;
         tp.m_lo = tp.m_hi = 0;
         hit_base += jc.hits;

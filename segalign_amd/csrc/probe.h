@@ -14,14 +14,19 @@ struct TdBounds {                 // chunk boundaries of a call: boundary c (c <
     uint32_t start, end, chunk;
 };
 
+constexpr int TD_MAX_ITER = 8;    // reference iterations a chunk of a table-direct call may be planned in: num_hits / MAX_HITS + 2 <= 8, i.e. chunks of up
+                                  // to 6 x MAX_HITS hits (a 500 Mbp block's 60 M-hit chunks under an 8 GiB GPU's 33.5 M: three); beyond: the general path
+
 struct TdPlan {                   // per chunk, written by probe_plan_kernel
     uint64_t hit_base;            // offset of the chunk's first hit inside the call
     uint64_t num_hits;            // src/seed_filter.cu:716
-    uint64_t split;               // call-wide hit offset where the reference's last iteration starts (:732-741, num_hits < MAX_HITS)
+    uint64_t upto[TD_MAX_ITER];   // call-wide hit offsets where the chunk's reference iterations END (:718-745): [0] = where the last iteration starts and
+                                  // [1] = hit_base + num_hits when num_hits < MAX_HITS (always two iterations), the greedy groups of :725-741 otherwise
     uint32_t num_valid;           // valid seed positions (seed words = num_valid * words per position)
     uint32_t m_lo, m_hi;          // the chunk's range of compacted (non-empty) positions
-    uint32_t pad;
-};
+    uint32_t n_iter;              // iterations in upto[] (0: no hits); TD_PLAN_OVERFLOW: the chunk needs more than TD_MAX_ITER, or its counts wrap the
+};                                // reference's uint32 arithmetic: the general path plans it
+constexpr uint32_t TD_PLAN_OVERFLOW = 0xFFFFFFFFu;
 
 struct ZeroList {                 // dword regions the per-call clearing kernel zeroes next to the head-bit map
     static constexpr int N = 4;
@@ -52,7 +57,9 @@ void launch_probe_compact(uint32_t start, uint32_t n, const uint64_t* t_off, con
                           TdRec* c_rec, uint32_t* chunk_rec, uint32_t chunk_cap, uint32_t* head_bits, uint32_t head_words,
                           const ZeroList& zero, const TdBounds& bpos, bool first_pass, hipStream_t s);
 void launch_call_clear(const ZeroList& zero, hipStream_t s);
+// max_hits: MAX_HITS in force (src/seed_filter.cu:832-841); wrap32: the src/ binary's uint32 hit arithmetic (the repeat masker's is 64-bit);
+// seg_end: [MAX_SEGS] the iteration ends of the call in hit order (sum of n_iter over the chunks; the host checks that it fits)
 void launch_probe_plan(const uint8_t* query, SeedShape sh, uint32_t tmask, const uint32_t* bucket_start, const void* bounds_buf, int nchunks,
-                       const TdRec* c_rec, TdPlan* plan, uint64_t* seg_end /* [2 * nchunks] */, hipStream_t s);
+                       const TdRec* c_rec, uint64_t max_hits, int wrap32, TdPlan* plan, uint64_t* seg_end, hipStream_t s);
 
 }  // namespace sa

@@ -474,50 +474,86 @@ __global__ __launch_bounds__(PR_THREADS) void probe_compact_kernel(uint32_t star
     }
 }
 
-// one lane per chunk
+// one lane per chunk: the reference's iteration plan (src/seed_filter.cu:718-745) in terms of HIT offsets.  The reference plans over the
+// inclusive prefix of hits per SEED WORD: iteration i ends behind the last word whose prefix is below limit_i (lower_bound - 1), with
+// limit_0 = min(num_hits, MAX_HITS) and limit_{i+1} = min(num_hits, prefix at that word + MAX_HITS); the last iteration takes the rest.
+// Only the VALUES matter (an iteration is the hit range between two ends): iteration i ends at the largest word boundary below limit_i.
+// Here the word boundaries are: first hit of non-empty position m (c_rec[m].prefix) + the plain bucket sizes of its words in emission
+// order (seeder.cpp:60-69) -- a binary search over the chunk's positions, then a walk over <= 16 buckets.  num_hits < MAX_HITS gives the
+// two iterations "everything in front of the last hit-bearing word / that word's hits"; a chunk at or above MAX_HITS gets the greedy
+// groups, up to TD_MAX_ITER of them (round 6: such a chunk used to leave the table-direct path for the general one, 3.5 x slower at
+// human-block density under an 8 GiB GPU's MAX_HITS -- profiles/r06/bench_line_human_maxhits_m60*.json).
+__device__ __forceinline__ uint64_t plan_boundary_below(const uint8_t* __restrict__ query, const SeedShape& sh, uint32_t tmask, const uint32_t* __restrict__ bucket_start,
+                                                        const TdRec* __restrict__ c_rec, uint32_t m_lo, uint32_t m_hi, uint64_t hit_base, uint64_t limit) {
+    // largest word boundary (chunk-relative inclusive hit prefix) strictly below `limit` (>= 1); 0 when there is none (the reference's
+    // wrapped index of hazard H5, read as "no hits")
+    uint32_t lo = m_lo, hi = m_hi;  // last non-empty position whose FIRST hit lies below the limit: position m_lo does (its first hit is 0)
+    while (lo + 1 < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if ((uint64_t)c_rec[mid].prefix - hit_base < limit) lo = mid; else hi = mid;
+    }
+    const uint64_t at = (uint64_t)c_rec[lo].prefix - hit_base;  // = the boundary behind the previous position's last word (0 for the first)
+    uint32_t key = 0;
+    kmer_at(query, c_rec[lo].qpos, sh, key);
+    uint64_t best = at, cum = at + bucket_len(bucket_start, key);
+    if (cum < limit) best = cum;
+    for (int t = 0; t < sh.weight; t++)
+        if ((tmask >> t) & 1u) {
+            cum += bucket_len(bucket_start, key ^ (2u << (2 * t)));
+            if (cum < limit) best = cum;
+        }
+    return best;
+}
+
 __global__ void probe_plan_kernel(const uint8_t* __restrict__ query, SeedShape sh, uint32_t tmask, const uint32_t* __restrict__ bucket_start,
-                                  const Tri* __restrict__ bounds, int nchunks, const TdRec* __restrict__ c_rec, TdPlan* __restrict__ plan,
-                                  uint64_t* __restrict__ seg_end) {
-    __shared__ uint64_t s_split[TD_MAX_BOUNDS], s_end[TD_MAX_BOUNDS];
+                                  const Tri* __restrict__ bounds, int nchunks, const TdRec* __restrict__ c_rec, uint64_t max_hits, int wrap32,
+                                  TdPlan* __restrict__ plan, uint64_t* __restrict__ seg_end) {
+    __shared__ uint64_t s_upto[TD_MAX_BOUNDS * TD_MAX_ITER];
+    __shared__ uint32_t s_iter[TD_MAX_BOUNDS];
     const int c = threadIdx.x;
     if (c < nchunks) {
-    const Tri lo = bounds[c], hi = bounds[c + 1];
-    TdPlan p;
-    p.hit_base = lo.hits;
-    p.num_hits = hi.hits - lo.hits;
-    p.num_valid = hi.valid - lo.valid;
-    p.m_lo = lo.ne;
-    p.m_hi = hi.ne;
-    p.split = lo.hits;
-    if (p.num_hits > 0) {
-        // the last hit-bearing seed word of the chunk (:732-739 with limit = num_hits) lives in the last non-empty position:
-        // walk that position's words in emission order (seeder.cpp:60-69) over the PLAIN buckets
-        const uint32_t m = hi.ne - 1;
-        uint32_t key = 0;
-        kmer_at(query, c_rec[m].qpos, sh, key);
-        uint64_t before = 0, before_last = 0;
-        uint32_t n0 = bucket_len(bucket_start, key);
-        if (n0) before_last = 0;
-        before = n0;
-        for (int t = 0; t < sh.weight; t++)
-            if ((tmask >> t) & 1u) {
-                const uint32_t nt = bucket_len(bucket_start, key ^ (2u << (2 * t)));
-                if (nt) before_last = before;
-                before += nt;
-            }
-        p.split = (uint64_t)c_rec[m].prefix + before_last;  // iteration 0 = hits [hit_base, split), iteration 1 = [split, hit_base + num_hits)
-    }
-    plan[c] = p;
-    s_split[c] = p.split;
-    s_end[c] = p.num_hits ? p.hit_base + p.num_hits : 0;  // (0: a chunk without hits has no iterations)
+        const Tri lo = bounds[c], hi = bounds[c + 1];
+        TdPlan p;
+        p.hit_base = lo.hits;
+        p.num_hits = hi.hits - lo.hits;
+        p.num_valid = hi.valid - lo.valid;
+        p.m_lo = lo.ne;
+        p.m_hi = hi.ne;
+        p.n_iter = 0;
+        for (int i = 0; i < TD_MAX_ITER; i++) p.upto[i] = lo.hits;
+        if (p.num_hits > 0) {
+            uint32_t n_iter;
+            uint64_t limit;
+            if (p.num_hits < max_hits) { n_iter = 2; limit = p.num_hits; }                        // :721-724
+            else { n_iter = (uint32_t)std::min<uint64_t>(p.num_hits / max_hits + 2, 0xFFFFu); limit = max_hits; }  // :725-728
+            // (the src/ binary counts hits in uint32: a chunk whose counts could wrap there is left to the general path, which restates the wrap)
+            if (n_iter > (uint32_t)TD_MAX_ITER || (wrap32 && p.num_hits + max_hits > 0xFFFFFFFFull)) {
+                p.n_iter = TD_PLAN_OVERFLOW;
+            } else {
+                for (uint32_t i = 0; i + 1 < n_iter; i++) {                                          // :732-739
+                    const uint64_t at = plan_boundary_below(query, sh, tmask, bucket_start, c_rec, lo.ne, hi.ne, lo.hits, limit);
+                    p.upto[i] = lo.hits + at;
+                    limit = std::min<uint64_t>(at + max_hits, p.num_hits);
+                }
+                p.upto[n_iter - 1] = lo.hits + p.num_hits;                                           // :741 (the last one takes what is left: H16)
+                p.n_iter = n_iter;                                                                   // (:743 never fires: limit <= num_hits, so the
+            }                                                                                        //  planned ends lie in front of the last word)
+        }
+        plan[c] = p;
+        s_iter[c] = p.n_iter;
+        for (int i = 0; i < TD_MAX_ITER; i++) s_upto[c * TD_MAX_ITER + i] = p.upto[i];
     }
     __syncthreads();
-    // the segment (reference iteration) ends of the call, in hit order: two per chunk that has hits -- what the host derives from the
-    // same plans for its own bookkeeping (core.hip); the candidate-stage kernels search this array (extend.hip seg_of)
+    // the segment (reference iteration) ends of the call, in hit order -- what the host derives from the same plans for its own
+    // bookkeeping (core.hip); the candidate-stage kernels search this array (extend.hip seg_of).  (A call whose chunks need more than
+    // MAX_SEGS iterations, or hold an overflowed plan, is not run table-direct: td_front halves it.)
     if (threadIdx.x == 0 && seg_end) {
         int n = 0;
-        for (int k = 0; k < nchunks; k++)
-            if (s_end[k]) { seg_end[n++] = s_split[k]; seg_end[n++] = s_end[k]; }
+        for (int k = 0; k < nchunks; k++) {
+            const uint32_t it = s_iter[k];
+            if (it == TD_PLAN_OVERFLOW) continue;
+            for (uint32_t i = 0; i < it && n < MAX_SEGS; i++) seg_end[n++] = s_upto[k * TD_MAX_ITER + i];
+        }
     }
 }
 
@@ -566,9 +602,9 @@ void launch_call_clear(const ZeroList& zero, hipStream_t s) {  // the clearing k
     hipLaunchKernelGGL(call_clear_kernel, dim3(64), dim3(256), 0, s, (const Tri*)nullptr, (uint32_t*)nullptr, 0u, zero);
 }
 void launch_probe_plan(const uint8_t* query, SeedShape sh, uint32_t tmask, const uint32_t* bucket_start, const void* bounds_buf, int nchunks,
-                       const TdRec* c_rec, TdPlan* plan, uint64_t* seg_end, hipStream_t s) {
+                       const TdRec* c_rec, uint64_t max_hits, int wrap32, TdPlan* plan, uint64_t* seg_end, hipStream_t s) {
     hipLaunchKernelGGL(probe_plan_kernel, dim3(1), dim3((nchunks + 63) / 64 * 64), 0, s, query, sh, tmask, bucket_start, reinterpret_cast<const Tri*>(bounds_buf),
-                       nchunks, c_rec, plan, seg_end);
+                       nchunks, c_rec, max_hits, wrap32, plan, seg_end);
 }
 
 }  // namespace sa

@@ -127,6 +127,7 @@ def test_configs2_heaviest_chunks_under_the_reference_gpus_max_hits(human_block,
                 got = E.SeedAndFilterRange(a, b, rev, 0)
                 st = E.last_call_stats()
                 assert got.shape == w.shape and np.all(got == w), (name, rev, a, b, got.size, w.size)
+                assert st["num_iter"] == ost["num_iter"] and st["lookup_path"] == 2 and not (st["path_flags"] & E.PATH_GENERAL_FALLBACK)
                 split += int(ost["num_hits"] >= mh)
                 want.append(w[1:])
             outs, _ = E.SeedCalls([(group[0][0], group[-1][1], rev)], 0, 1)

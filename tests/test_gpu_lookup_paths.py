@@ -68,17 +68,34 @@ def test_every_lookup_path_equals_the_oracle(oracle, clean, mode, env, transitio
 
 @pytest.mark.parametrize("mode,env", MODES)
 def test_lookup_paths_under_a_max_hits_split(oracle, clean, mode, env):
-    """num_hits >= MAX_HITS (hazard H4): more than two reference iterations -- a table-direct call must hand the chunk to the
-    general path (the plan then needs per-seed-word prefixes); below the limit it keeps the two-iteration split."""
+    """num_hits >= MAX_HITS (hazard H4): more than two reference iterations.  A table-direct call plans the reference's greedy groups
+    (src/seed_filter.cu:725-741) itself from the position records and the plain bucket sizes (probe.hip probe_plan_kernel) as long as a
+    chunk needs at most TD_MAX_ITER = 8 of them; beyond that it hands the chunk to the general path (per-seed-word prefixes); below the
+    limit it keeps the two-iteration split."""
     with_env(env)
     t, q = synth.make_pair(100000, 51, 52, sub_rate=0.07, mask_frac=0.1)
     c = Case(t, q, chunk=50000).oracle_setup(oracle).engine_setup(clean)
-    for mh in (8000, 40000, 1 << 30):
+    seen = set()
+    hits = [c.oracle_saf(c.host_seeds(s, e, rev), rev)[1]["num_hits"] for rev in (False, True) for (s, e) in c.chunks()]
+    assert min(hits) > 1000
+    # far above eight iterations for every chunk / three to five / two or three / no split at all
+    for mh in (min(hits) // 10, max(hits) // 3, max(hits) - 1, 1 << 30):
         c.E.set_max_hits(mh)
         for rev in (False, True):
             for (s, e) in c.chunks():
                 want, st = c.oracle_saf(c.host_seeds(s, e, rev), rev, max_hits=mh)
-                assert seg_equal(c.E.SeedAndFilterRange(s, e, rev, 0), want), (mode, mh, rev, s, e)
+                got = c.E.SeedAndFilterRange(s, e, rev, 0)
+                es = c.E.last_call_stats()
+                assert seg_equal(got, want), (mode, mh, rev, s, e)
+                assert es["num_iter"] == st["num_iter"], (mode, mh, rev, s, e, es["num_iter"], st["num_iter"])
+                general = bool(es["path_flags"] & c.E.PATH_GENERAL_FALLBACK) or es["lookup_path"] == 0
+                if mode and st["num_hits"] >= mh:
+                    # planned table-direct up to eight iterations, by the general path above
+                    assert general == (st["num_hits"] // mh + 2 > 8), (mode, mh, rev, s, e, st["num_hits"], es)
+                    seen.add(general)
+                elif mode:
+                    assert not general
+    assert not mode or seen == {False, True}, seen   # both sides of the limit were reached
     c.E.set_max_hits(0)
 
 
@@ -232,7 +249,7 @@ def test_query_block_beyond_the_2bit_copy_limit_takes_the_general_path(oracle, c
 
 @pytest.mark.parametrize("mode,env", MODES)
 def test_passes_that_cannot_hold_their_chunks_halve_themselves(oracle, clean, mode, env):
-    """A multi-chunk pass with chunks at or above MAX_HITS (those need the general path's iteration plan, hazard H4), and a pass of
+    """A multi-chunk pass with chunks far above MAX_HITS (more than eight reference iterations: those need the general path's plan, hazard H4), and a pass of
     more than 32 chunks on the general path, are cut in halves until every piece fits (api_calls.hip chunks_pass): every chunk's
     vector must still be what a call of its own returns, the statistics the sums."""
     with_env(env)
@@ -242,7 +259,7 @@ def test_passes_that_cannot_hold_their_chunks_halve_themselves(oracle, clean, mo
     ch = c.chunks()
     assert len(ch) > 40
     try:
-        for mh in (2500, 1 << 30):   # ~half of the chunks hold more hits than 2500
+        for mh in (300, 2500, 1 << 30):   # ~half of the chunks hold more hits than 2500 (three iterations: they stay table-direct); every chunk far more than 300
             E.set_max_hits(mh)
             for rev in (False, True):
                 wants, hits = [], 0
@@ -255,7 +272,9 @@ def test_passes_that_cannot_hold_their_chunks_halve_themselves(oracle, clean, mo
                 for j, w in enumerate(wants):
                     assert seg_equal(outs[j], w), (mode, mh, rev, j)
                 assert st["num_hits"] == hits
+                if mh == 300 and mode:
+                    assert st["path_flags"] & E.PATH_GENERAL_FALLBACK   # chunks that need more than eight iterations went down the general path ...
                 if mh == 2500 and mode:
-                    assert st["path_flags"] & E.PATH_GENERAL_FALLBACK   # the crowded chunks went down the general path ...
+                    assert not (st["path_flags"] & E.PATH_GENERAL_FALLBACK) and st["num_iter"] > 2 * 48   # ... three or four are planned table-direct
     finally:
         E.set_max_hits(0)

@@ -120,7 +120,7 @@ static Option g_opts[] = {
     {"key_order_hits", 3ll << 30, 1 << 20, 1ll << 34, 0},  // ... capped so that a call stays below about this many seed hits (its lists are sized by them)
     {"key_order_min_pos", 0, 0, 1ll << 31, 0},         // positions a call must hold to go key-ordered under key_order = 1 (0: the number of seed keys)
     {"filter_prio", 0, 0, 1, 0},                       // experiment: slot streams at the highest queue priority, the class filter alone on a lowest-priority stream per slot (wants GPU_MAX_HW_QUEUES >= 2 x slots + 1); measured and left off: profiles/r06/
-    {"l2_right_state", 1, 0, 1, 0},                    // a hit whose right side alone survived the class filter reaches the second level with the right walk's packed state and resumes behind the 54 context bases (one 64-base window instead of two from the anchor); 0: round 5's form (A/B)
+    {"l2_right_state", 0, 0, 1, 0},                    // 1: a hit whose right side alone survived the class filter reaches the second level with the right walk's packed state and resumes behind the 54 context bases (one 64-base window instead of two from the anchor).  Parity-green and audited, and without effect on any clock (profiles/r06/ab_l2state_prio.txt: the second level is priced in random lines, not in windows): default 0 = round 5's form
     {"ctx_skip_seed", 1, 0, 1, 0},                     // context records hold the 58 bases in FRONT of the seed window, which the class filter bounds by seed_size x the largest class score (kernels.h CtxRec); 0: the bases left of the anchor, seed window included (A/B)
     {"clear_ref_frees", 0, 0, 1, 0},                   // 1: g_ClearRef hipFrees the index / position / extent tables like the reference (seed_filter_interface.cu:103-113); 0 (default): it forgets the tables and KEEPS their buffers for the next target block (a fresh allocation pays first-touch page clearing inside the next GenerateSeedPosTable); ShutdownProcessor frees them either way
     {"table_scratch_arena", 1, 0, 1, 0},               // scratch of the seed table build (keys, pair arrays: ~10 GB per 500 Mbp block) carved from the mapped table arena instead of fresh hipMallocs (first-touch page clearing inside every GenerateSeedPosTable)

@@ -48,7 +48,9 @@ def audit_case(O, E, c, chunks_per_call=1, strands=(False, True)):
     return rejected
 
 
-@pytest.mark.parametrize("env_opt", [{}, {"no_ctx": 1}])
+# (l2_right_state = 1: the second level resumes an open RIGHT walk behind the class filter's 54 context bases from its packed state --
+#  off by default since it moves no clock, profiles/r06/ab_l2state_prio.txt -- audited here like the default form)
+@pytest.mark.parametrize("env_opt", [{}, {"no_ctx": 1}, {"l2_right_state": 1}])
 @pytest.mark.parametrize("noentropy", [False, True])
 def test_filters_reject_nothing_that_passes(oracle, audited, env_opt, noentropy):
     for k, v in env_opt.items():

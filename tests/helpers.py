@@ -103,3 +103,24 @@ def check_seed_table_properties(E, target_size, seed_size=19):
     valid = (csum[seed_size:] - csum[:-seed_size]) == 0   # window starting at p = 0 .. len - seed_size
     assert int(valid[1:].sum()) == pos.size               # position 0 excluded
     return index, pos
+
+
+def pos_tables_equal_by_bucket(index, pos_a, pos_b):
+    """Two position tables under the same bucket ends hold the same positions bucket by bucket (order inside a bucket is free, hazard
+    H7): only the buckets in which the two differ are sorted and compared -- at 100 Mbp that is the few hundred buckets too large for
+    the device's in-LDS sort, not 80 M entries."""
+    import numpy as np
+    pos_a, pos_b = np.asarray(pos_a), np.asarray(pos_b)
+    if pos_a.shape != pos_b.shape:
+        return False
+    diff = np.flatnonzero(pos_a != pos_b)
+    if diff.size == 0:
+        return True
+    ends = np.asarray(index, dtype=np.int64)
+    buckets = np.unique(np.searchsorted(ends, diff, side="right"))
+    starts = np.concatenate([[0], ends])
+    for b in buckets:
+        lo, hi = int(starts[b]), int(ends[b])
+        if not np.array_equal(np.sort(pos_a[lo:hi]), np.sort(pos_b[lo:hi])):
+            return False
+    return True

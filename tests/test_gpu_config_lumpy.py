@@ -10,7 +10,7 @@ same target (repeat_masker_src/seeder.cpp:28-195) against the host model."""
 import numpy as np
 import pytest
 
-from helpers import check_seed_table_properties
+from helpers import check_seed_table_properties, pos_tables_equal_by_bucket
 from segalign_amd import shard, synth
 from test_gpu_rm_mask import as_list, model_mask_interval
 
@@ -32,8 +32,11 @@ def lumpy(oracle, engine):
     keep = E.SendRefWriteRequest(target, 0, target.size)
     E.GenerateSeedPosTable(keep, 0, target.size, 1, 19, k)
     E.SendQueryWriteRequest(query, 0, query.size, 0)
-    d = dict(E=E, O=O, target=target, query=query, sub_mat=sub_mat, k=k, index=E.copy_index_table(), pos=E.copy_pos_table(),
-             rcodes=E.copy_ref_codes(), flags=0)
+    # the oracle works on its OWN table and codes, built from the ASCII (common/seed_pos_table.cu:49-109, seed_filter_interface.cu:18-47,
+    # src/seed_filter.cu:110-155): nothing below is borrowed from the device (round 6; the device's copies are held against them first)
+    o_index, o_pos = O.generate_seed_pos_table(target.tobytes(), 0, target.size, 1, 19, k)
+    o_q, o_qrc = O.encode_rev_comp(query.tobytes())
+    d = dict(E=E, O=O, target=target, query=query, sub_mat=sub_mat, k=k, index=o_index, pos=o_pos, rcodes=O.encode(target.tobytes()), o_q=o_q, o_qrc=o_qrc, flags=0)
     d["rc_ascii"] = np.frombuffer(O.rev_comp_ascii(query.tobytes(), 0, query.size), dtype=np.uint8)
     yield d
     E.ShutdownProcessor()
@@ -42,6 +45,12 @@ def lumpy(oracle, engine):
 def test_table_properties_and_spectrum(lumpy):
     E = lumpy["E"]
     check_seed_table_properties(E, lumpy["target"].size, 19)
+    # ... and equality with the oracle's own build: bucket ends word for word, positions bucket by bucket (the device leaves buckets too
+    # large for its in-LDS sort in arrival order, hazard H7), codes of the target and of both query strands
+    assert np.array_equal(E.copy_index_table(), lumpy["index"])
+    assert pos_tables_equal_by_bucket(lumpy["index"], E.copy_pos_table(), lumpy["pos"])
+    assert np.array_equal(E.copy_ref_codes(), lumpy["rcodes"])
+    assert np.array_equal(E.copy_query_codes(0, False), lumpy["o_q"]) and np.array_equal(E.copy_query_codes(0, True), lumpy["o_qrc"])
     sizes = np.diff(np.concatenate([[0], lumpy["index"].astype(np.int64)]))
     assert sizes.max() > 2000 and int((sizes > 1024).sum()) >= 10          # heavy buckets exist (uniform DNA: max ~25)
     assert E.lookup_mode() == 2
@@ -58,7 +67,7 @@ def oracle_chunk(lumpy, a, b, rev):
     O = lumpy["O"]
     buf = lumpy["rc_ascii"] if rev else lumpy["query"]
     seeds = O.make_seeds(buf.tobytes(), 0, a, b, 19, lumpy["k"], True)
-    qcodes = lumpy["E"].copy_query_codes(0, rev)
+    qcodes = lumpy["o_qrc"] if rev else lumpy["o_q"]
     return O.seed_and_filter(lumpy["rcodes"], qcodes, lumpy["index"], lumpy["pos"], seeds, lumpy["sub_mat"])
 
 
@@ -126,7 +135,7 @@ def test_heaviest_chunks_under_the_reference_gpus_max_hits(lumpy, name, mem):
             lo = max(0, min(i - 1, len(ch) - 3))
             group = ch[lo:lo + 3]
             buf = lumpy["rc_ascii"] if rev else lumpy["query"]
-            qcodes = E.copy_query_codes(0, rev)
+            qcodes = lumpy["o_qrc"] if rev else lumpy["o_q"]
             want = []
             for j, (a, b, _) in enumerate(group):
                 seeds = O.make_seeds(buf.tobytes(), 0, a, b, 19, lumpy["k"], True)

@@ -270,7 +270,7 @@ typedef struct sa_call_stats {
 #define SA_PATH_CHAIN_SLICED 8u          /* more candidates than the chain buffers hold: the chain stages ran over the list slice by slice */
 #define SA_PATH_HEAD_BITS_REGROWN 16u    /* the head-bit map of the call's hits was regrown and the compaction repeated */
 #define SA_PATH_KEY_ORDERED 64u          /* the call ran key-ordered: positions sorted by seed key, hits enumerated per key (join.h) */
-#define SA_PATH_GENERAL_FALLBACK 32u     /* a device-seeded call could not take the table-direct path (MAX_HITS split, > 2^32 hits, ...) */
+#define SA_PATH_GENERAL_FALLBACK 32u     /* a device-seeded call could not take the table-direct path (a chunk of 6 x MAX_HITS hits or more, > 2^32 hits, ...) */
 void sa_get_last_call_stats(sa_call_stats* out); /* stats of the calling thread's most recent hot call */
 void sa_set_count_examined(int on);
 /* X-drop filter kernel selected by InitializeProcessor for plain calls: 0 = exact per-base walk, 1 = fast per-base

@@ -144,6 +144,11 @@ __device__ __forceinline__ int classify(const ExtendArgs& a, int total) {
     return (f64_to_i32((double)(float)total) >= a.hspthresh) ? 1 : 0;  // entropy stays 1.0
 }
 
+// "may this bound pass?" for the packed filter levels, whose totals are sums of two int16 walks: classify(total) != 0 without its
+// conversions.  classify returns 2 inside the entropy band (total >= hspthresh there), else 1 iff (int)(double)(float)total >= hspthresh
+// (:633 with entropy 1.0) -- and below 2^24 the float round trip is exact, so both branches say total >= hspthresh.
+__device__ __forceinline__ bool bound_passes(const ExtendArgs& a, int total) { return total >= a.hspthresh; }
+
 __device__ __forceinline__ HspRec make_rec(const ExtendArgs& a, uint32_t ref_loc, uint32_t query_loc, int boffL, int extent,
                                            int score, uint32_t seg) {
     HspRec rec;
@@ -760,7 +765,7 @@ __global__ __launch_bounds__(PK_THREADS) void extend_filter_packed_kernel(Extend
         const unsigned long long live = __ballot(phase < PH_FIN);
         if (fin != 0ull && (__popcll(fin) >= fin_batch || live == 0ull)) {
             bool cand = false;
-            if (phase == PH_FIN && has_hit) cand = forward || classify(a, bestR + best) != 0;
+            if (phase == PH_FIN && has_hit) cand = forward || bound_passes(a, bestR + best);  // (|bestR + best| < 2^16)
             {
                 CandRec cr;
                 cr.ref_loc = ref_loc; cr.query_loc = query_loc; cr.hidx = hidx;
@@ -1131,7 +1136,7 @@ __global__ __launch_bounds__(CTX_THREADS_MAX, 8) void extend_filter_cls_kernel(E
         cls_step(s_tail, (x6 >> 22) & 0x3FCu, P, Wd);
         const bool l_alive = (int)(short)((CLS_TRACK_DROP ? Wd : P) & 0xFFFFu) >= -xdrop;  // (:523)
         const int bestL = ((int)P >> 16) - (int)(short)(P & 0xFFFFu);
-        const bool fwd = !skip && (r_alive || l_alive || classify(a, bestR + bestL) != 0);
+        const bool fwd = !skip && (r_alive || l_alive || bound_passes(a, bestR + bestL));
         // what is known travels with the anchor (kernels.h L2Rec): level 2 walks only what is still open
         const unsigned long long fm = __ballot(fwd);
         if (fm) {
@@ -1317,7 +1322,7 @@ __global__ __launch_bounds__(JOIN_THREADS, 8) void join_filter_kernel(ExtendArgs
                     const int bestR = ((int)PR >> 16) - (int)(short)(PR & 0xFFFFu);
                     const bool l_alive = (int)(short)((CLS_TRACK_DROP ? WL : PL) & 0xFFFFu) >= -xdrop;  // (:523)
                     const int bestL = ((int)PL >> 16) - (int)(short)(PL & 0xFFFFu);
-                    const bool fwd = valid && (r_alive || l_alive || classify(a, bestR + bestL) != 0);
+                    const bool fwd = valid && (r_alive || l_alive || bound_passes(a, bestR + bestL));
                     const uint32_t query_loc = q[0] + a.seed_size;  // :204
                     const unsigned long long fm = __ballot(fwd);
                     if (fm) {

@@ -72,7 +72,17 @@ def one_case(seed, s14):
         E.set_option("audit_cap", 1 << 22)
     if rng.random() < 0.15:
         E.set_option("ctx_skip_seed", 0)  # (the context layout with the seed window inside the record)
+    if rng.random() < 0.2:
+        E.set_option("l2_right_state", 1)  # (the second level resumes an open right walk behind the class filter's context)
+    # MAX_HITS of a smaller GPU (src/seed_filter.cu:832-841, hazard H4): chunks at or above it run in the reference's greedy iteration
+    # groups -- planned table-direct up to eight per chunk (probe.hip), by the general path beyond
+    mh = int(rng.choice([1 << 30, 1 << 30, 1 << 30, 400, 3000, 20000, 150000]))
     c = Case(t, q, **kw).oracle_setup(O).engine_setup(E)
+    if mh < (1 << 30):  # (the engine's general path plans at most 1000 iterations per chunk: keep the heaviest chunk below ~500)
+        per = E.CountCallHits([(s_, e_, r_) for r_ in (False, True) for (s_, e_) in c.chunks()], 0, 2)
+        mh = max(mh, max(per + [0]) // 500 + 1)
+    E.set_max_hits(mh if mh < (1 << 30) else 0)
+    kw["max_hits"] = mh
     kw["key_order"] = ko
     kw["audit"] = audit
     hsps = hits = 0
@@ -87,7 +97,7 @@ def one_case(seed, s14):
                 if seeds.size == 0:
                     want[rev].append(None)
                     continue
-                w, st = c.oracle_saf(seeds, rev)
+                w, st = c.oracle_saf(seeds, rev, max_hits=mh)
                 want[rev].append(w)
                 hits += st["num_hits"]
                 hsps += w.size - 1
@@ -111,10 +121,11 @@ def one_case(seed, s14):
                 for (s, e) in shard.chunks_of((0, q_len), c.chunk, q_len, rev):
                     seeds = c.host_seeds(s, e, rev)
                     if seeds.size:
-                        exp.append(c.oracle_saf(seeds, rev)[0][1:])
+                        exp.append(c.oracle_saf(seeds, rev, max_hits=mh)[0][1:])
                 exp = np.concatenate(exp) if exp else np.zeros(0, dtype=fw.dtype)
                 assert seg_equal(got, exp), ("interval", rev, threads, got.size, exp.size)
     finally:
+        E.set_max_hits(0)
         E.ShutdownProcessor()
     kw["audited"] = audited[0]
     return kind, kw, t.size, hits, hsps
@@ -136,7 +147,7 @@ def main():
             sys.exit(1)
         print("seed %d %-9s %7d bp step %d %s chunk %6d xdrop %4d thresh %4d %s%s: %d hits, %d HSPs ok" % (
             seed, kind, size, kw["step"], "tr" if kw["transition"] else "no-tr", kw["chunk"], kw["xdrop"], kw["hspthresh"],
-            "noentropy " if kw["noentropy"] else "", ("14of22" if "shape" in kw else "12of19") + (" key-ordered" if kw.get("key_order") else "") + (" audited %d" % kw["audited"] if kw.get("audit") else ""), hits, hsps), flush=True)
+            "noentropy " if kw["noentropy"] else "", ("14of22" if "shape" in kw else "12of19") + (" key-ordered" if kw.get("key_order") else "") + (" audited %d" % kw["audited"] if kw.get("audit") else "") + (" MAX_HITS %d" % kw["max_hits"] if kw["max_hits"] < (1 << 30) else ""), hits, hsps), flush=True)
         n += 1
         tot_hits += hits
         tot_hsps += hsps

@@ -207,8 +207,9 @@ int sa_max_hits_for_mem(uint64_t total_global_mem);
  *
  * Deployment options
  *   slots             calls in flight per device (default 4, at most 8; the reference allows 1: its token IS the device).  Every slot
- *                     has its own stream; the library's load-time constructor sets GPU_MAX_HW_QUEUES=8 (unless the variable is
- *                     set) because slots that share one of the runtime's default four hardware queues run one after the other
+ *                     has its own stream, and slots that share one of the runtime's default four hardware queues run one after the
+ *                     other: the HOST exports GPU_MAX_HW_QUEUES=8 before its first HIP call (the library leaves the environment alone
+ *                     and says so once on stderr when the slots + the upload stream outnumber the queues)
  *   chunks_per_call   wga_chunk-sized chunks sa_seed_interval / sa_rm_mask_interval hand to one pass (default 40: a strand's chunks of a 10 Mbp interval; maximum 256; the repeat masker at most 20).
  *                     sa_get_chunks_per_call() adapts it to the resident target: more when seed hits are sparse (option call_hits,
  *                     default 128 M hits per call), fewer when they are dense (option call_hits_max, default 1 G)
@@ -217,6 +218,14 @@ int sa_max_hits_for_mem(uint64_t total_global_mem);
  *   arena_gb          GiB of table arena the engine starts mapping in the background at sa_initialize_processor (default 40:
  *                     the table of a ~100 Mbp block; 0: only on demand).  A larger block raises the goal by itself; setting it
  *                     beforehand (e.g. 180 for 500 Mbp blocks) takes the allocation off the table build's critical path
+ *   clear_ref_frees   1: g_ClearRef frees the index / position / extent tables like the reference's clearRef (seed_filter_interface.cu:103-113);
+ *                     0 (default): it forgets the tables and keeps their buffers for the next target block (ShutdownProcessor frees them)
+ *   key_order, key_order_chunks, key_order_hits, key_order_min_pos   key-ordered calls (off by default)
+ *   ctx_skip_seed, table_scratch_arena, log4_double                  INTEGRATION.md 4
+ *   l2_right_state    1: the second filter level resumes an open RIGHT walk behind the class filter's context from its packed state
+ *                     (default 0: measured without effect, profiles/r06/ab_l2state_prio.txt)
+ *   filter_prio       1 (experiment): slot streams at the highest queue priority, the class filter on a lowest-priority stream of its own
+ *                     (small kernels 2-3 x faster, the pass 2 % slower: default 0; wants GPU_MAX_HW_QUEUES >= 2 x slots + 1)
  *   no_chain          1: every candidate is extended on its own (no chain shortcut, DESIGN.md 4.5')
  *   no_packed_filter / no_fast_filter   1: fall back to the byte-coded / the exact per-base X-drop filter kernels
  *   debug             1: table-build timings on stderr; 2: + synchronise after every kernel scope and name it (fault localisation)

@@ -359,8 +359,11 @@ def main():
         return share
     my_jobs = shard.partition(jobs, rank, world, None) if scaling == "strong" else jobs
     # never more calls in flight than this rank's share of one pass holds (the 1 Mbp plumbing case is two calls per pass: six
-    # tiny calls in flight only contend for the engine's locks, 1.1 -> 0.67 Gbp/s)
-    inflight = max(1, min(inflight, len(my_jobs)))
+    # tiny calls in flight only contend for the engine's locks, 1.1 -> 0.67 Gbp/s) -- unless the calls are whole-strand calls of ten
+    # chunks or more: the passes of the timed region are ONE list of calls (run_steps), so a rank whose share of a pass is two or three
+    # such calls (N = 8: 20 calls per pass) still has six to keep in flight, as the one-rank run does across its pass boundaries
+    big_calls = bool(jobs) and not wl["rm"] and max(j.get("chunks", 1) for j in jobs) >= 10
+    inflight = max(1, min(inflight, len(my_jobs) * (max(args.steps, 1) if big_calls else 1)))
 
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(inflight)  # the reference keeps one seeder body per TBB thread in flight (src/main.cpp:565-573)
@@ -424,8 +427,10 @@ def main():
         torch.cuda.synchronize()
 
     # ---------------- warmup (untimed) ----------------
-    for w in range(args.warmup):
-        run_step(w)
+    # (as one list of calls, like the timed region: every engine slot takes calls and sizes its buffers here, also on a rank whose
+    #  share of a single pass is fewer calls than it keeps in flight)
+    if args.warmup > 0:
+        run_steps(list(range(args.warmup)))
 
     # the same kernels without a second call overlapping them: one extra (untimed) pass with ONE call in flight, before the timed
     # region -- the state the committed single-stream rocprofv3 collection was made in (after twenty passes with six calls in

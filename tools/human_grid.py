@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--query-mbp", type=float, default=500.0)
     ap.add_argument("--in-flight", type=int, default=6)
     ap.add_argument("--check-bench", action="store_true", help="run bench.py --workload human on block pair (0, 0) and compare checksums")
+    ap.add_argument("--max-hits-mem-gb", type=float, default=None,
+                    help="walk the grid under the MAX_HITS of a reference GPU of this many GiB (src/seed_filter.cu:832-841; 8 = the M60 of README.md:27)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     sys.path.insert(0, ROOT)
@@ -51,6 +53,8 @@ def main():
     E.InitializeInterface(1)
     kmer = E.GenerateShapePos(SHAPE)
     E.InitializeProcessor(True, 250000, 19, bench.default_sub_mat(910), 910, 3000, False)
+    if args.max_hits_mem_gb:
+        E.set_max_hits(E.max_hits_for_mem(int(args.max_hits_mem_gb * (1 << 30))))
 
     t_gen0 = time.time()
     targets = [None] * G
@@ -133,6 +137,7 @@ def main():
     warm = [b["table_build_s"] for b in blocks[1:]]
     doc = dict(workload="BASELINE configs[2] stand-in: %d x %d grid of %.0f Mbp target blocks x %.0f Mbp query blocks, 12of19 + transitions, one MI355X"
                         % (G, G, tlen / 1e6, qlen / 1e6),
+               max_hits=int(E.get_max_hits()),
                generate_s=round(t_gen, 2), grid_wall_s=round(grid_s, 3), compute_s=round(compute_s, 3),
                non_scaling_s=round(sum(b["clear_ref_s"] + b["upload_encode_s"] + b["table_build_s"] for b in blocks), 3),
                query_bases_x_target_blocks=q_bases * G, gbp_per_s=round(q_bases * G / grid_s / 1e9, 4),
@@ -147,7 +152,8 @@ def main():
         E.ShutdownProcessor()
         E.lib().sa_release_arena()
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "human", "--query-mbp", str(args.query_mbp), "--target-mbp",
-                              str(args.target_mbp), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-dropin", "--no-roofline"],
+                              str(args.target_mbp), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-dropin", "--no-roofline"] +
+                             (["--max-hits-mem-gb", str(args.max_hits_mem_gb)] if args.max_hits_mem_gb else []),
                              cwd=ROOT, capture_output=True, text=True, timeout=1800)
         line = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
         if out.returncode != 0 or not line:

@@ -4,6 +4,7 @@
 //   R  at uniformly random 32-byte-aligned offsets            (what the filter does today: query order = random key order)
 //   S  at the same offsets, sorted ascending                   (what processing a call's positions in KEY order would give)
 //   W  sorted inside windows of 4096 consecutive pieces        (a cheap partial order)
+//   P<n>  partitioned into n equal table ranges, random inside  (round 6: one counting pass by the top bits of the run offset)
 //   Q  pieces laid end to end                                  (the pure stream)
 // with the filter's load shape (a wave takes 64 records = 2 KB per step, lane L loads bytes [32 L, 32 L + 32)), from a plain
 // hipMalloc and from a range mapped in 1 GiB chunks like the engine's table arena.
@@ -93,6 +94,16 @@ int main(int argc, char** argv) {
     std::sort(S.begin(), S.end());
     W = R;
     for (size_t i = 0; i < W.size(); i += 4096) std::sort(W.begin() + i, W.begin() + std::min(W.size(), i + 4096));
+    // P<n>: a PARTIAL key order -- the pieces partitioned into n equal ranges of the table (one counting pass over a call's position
+    // records by the top bits of their run offset), random inside a range (round 6: would one cheap partition pass buy what S buys?)
+    std::vector<std::vector<uint64_t>> P;
+    const uint32_t parts[3] = {256, 4096, 65536};
+    for (uint32_t np : parts) {
+        std::vector<uint64_t> v = R;
+        const uint64_t width = (bytes + np - 1) / np;
+        std::stable_sort(v.begin(), v.end(), [width](uint64_t a, uint64_t b) { return a / width < b / width; });
+        P.push_back(v);
+    }
     uint64_t* d_off; uint32_t* out;
     hipMalloc(&d_off, (size_t)n * 8); hipMalloc(&out, 4);
     for (int vmm = 0; vmm < 2; vmm++) {
@@ -107,6 +118,9 @@ int main(int argc, char** argv) {
                (double)n * piece / 1e9);
         run(buf, R, piece, d_off, out, "R random order");
         run(buf, W, piece, d_off, out, "W sorted per 4096 pieces");
+        run(buf, P[0], piece, d_off, out, "P256   partitioned into 256 table ranges");
+        run(buf, P[1], piece, d_off, out, "P4096  partitioned into 4096 table ranges");
+        run(buf, P[2], piece, d_off, out, "P65536 partitioned into 65536 table ranges");
         run(buf, S, piece, d_off, out, "S sorted (key order)");
         run(buf, Q, piece, d_off, out, "Q end to end (stream)");
         if (vmm) {

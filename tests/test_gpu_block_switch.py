@@ -162,3 +162,39 @@ def test_work_regions_survive_a_reinitialisation_with_another_layout(oracle, eng
     finally:
         E.ShutdownProcessor()
         E.reset_option(None)
+
+
+@pytest.mark.parametrize("frees", [0, 1])
+def test_clear_ref_keeps_or_frees_the_table_buffers(oracle, engine, frees):
+    """g_ClearRef between target blocks of growing and shrinking size: by default the engine forgets the tables and keeps their buffers
+    (grown before they are re-allocated: freed first), with option clear_ref_frees = 1 it frees them like the reference's clearRef
+    (common/seed_filter_interface.cu:103-113).  Either way every block's tables are the oracle's and its chunk calls bit-exact."""
+    E, O = engine, oracle
+    E.set_option("clear_ref_frees", frees)
+    try:
+        first = True
+        for n, seed in ((600_000, 301), (2_400_000, 302), (900_000, 303)):
+            t, q = synth.make_pair(n, seed, seed + 50, sub_rate=0.08, mask_frac=0.1, records=2, indel_every=600)
+            c = Case(t, q, chunk=100_000).oracle_setup(O)
+            if first:
+                c.engine_setup(E)
+                assert E.get_option("clear_ref_frees") == frees
+                first = False
+            else:  # the reader lambda's order for a later block: main.cpp:613-621,659-661
+                E.ClearRef()
+                E.ClearQuery(0)
+                c.E = E
+                keep = E.SendRefWriteRequest(c.target, 0, c.target.size)
+                E.GenerateSeedPosTable(keep, 0, c.target.size, 1, 19, c.kmer_size)
+                E.SendQueryWriteRequest(c.query, 0, c.query.size, 0)
+            assert np.array_equal(E.copy_index_table(), c.o_index) and np.array_equal(E.copy_pos_table(), c.o_pos)
+            n_hsps = 0
+            for rev in (False, True):
+                for (s, e) in c.chunks()[:4]:
+                    want, _ = c.oracle_saf(c.host_seeds(s, e, rev), rev)
+                    assert seg_equal(E.SeedAndFilterRange(s, e, rev, 0), want), (frees, n, rev, s)
+                    n_hsps += want.size - 1
+            assert n_hsps > 0
+    finally:
+        E.ShutdownProcessor()
+        E.reset_option(None)
